@@ -1,0 +1,173 @@
+/*
+ * gsr.h — C ABI of the MI355X (gfx950) differentiable Gaussian-splatting rasterizer.
+ *
+ * This is the drop-in boundary for the native side of the reference's renderer:
+ *
+ *   reference call site            /root/reference/gaussian_renderer/__init__.py:6,21-48
+ *                                  (`from diff_gaussian_rasterization import
+ *                                    GaussianRasterizationSettings, GaussianRasterizer`)
+ *   native entry points replaced   the un-vendored `diff_gaussian_rasterization._C`
+ *                                  pybind module: `rasterize_gaussians`,
+ *                                  `rasterize_gaussians_backward`, `mark_visible`
+ *                                  (SURVEY.md §2.1 / §8b — behavioural spec, Appendix A).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *     the caller owns every buffer (in the Python binding they are torch tensors,
+ *     so the caching allocator and the autograd ctx manage lifetime);
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); nothing
+ *     blocks the host, there is no device->host read-back on the hot path;
+ *   - matrices are the 16 floats of the torch tensors the reference passes
+ *     (`world_view_transform`, `full_proj_transform`): row-major storage of the
+ *     transposed matrix, i.e. element (row i, col j) of the column-vector-form
+ *     matrix is m[j*4+i]  (/root/reference/scene/dataset_mono.py:248-255);
+ *   - return value 0 = success; non-zero = error, text via gsr_last_error()
+ *     (thread-local). The library has no other global state and is re-entrant.
+ *
+ * Plain C; no HIP or torch types appear in any signature.
+ */
+#ifndef GSR_H
+#define GSR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_ABI_VERSION 1
+#define GSR_TILE 16              /* tile edge in pixels (BLOCK_X = BLOCK_Y = 16)       */
+#define GSR_NUM_CHANNELS 3
+
+/* Error codes */
+#define GSR_OK 0
+#define GSR_ERR_INVALID_ARGUMENT 1
+#define GSR_ERR_WORKSPACE_TOO_SMALL 2
+#define GSR_ERR_LAUNCH 3
+#define GSR_ERR_UNSUPPORTED 4
+
+/* Per-call render settings. Mirrors the 12-field GaussianRasterizationSettings tuple the
+ * reference builds at gaussian_renderer/__init__.py:21-34 (bg/viewmatrix/projmatrix/campos
+ * are device tensors there and stay device pointers here). */
+typedef struct GsrSettings {
+  int32_t image_height;
+  int32_t image_width;
+  float tanfovx;
+  float tanfovy;
+  float scale_modifier;
+  int32_t sh_degree;        /* active SH degree (0..3); ignored when colors_precomp is given */
+  int32_t prefiltered;      /* accepted for API parity; no effect (as upstream)              */
+  int32_t debug;            /* 1: synchronise + check after every launch                      */
+  const float* bg;          /* [3]  device                                                    */
+  const float* viewmatrix;  /* [16] device                                                    */
+  const float* projmatrix;  /* [16] device                                                    */
+  const float* campos;      /* [3]  device (only read for SH colours)                         */
+} GsrSettings;
+
+/* Byte offsets of the named sub-arrays inside the opaque workspace (all 256-B aligned).
+ * The workspace is the state the forward pass leaves for the backward pass (the
+ * reference's geomBuffer / binningBuffer / imgBuffer rolled into one caller-owned
+ * allocation) — published so that parity tests can read the integer outputs. */
+typedef struct GsrLayout {
+  uint64_t total_bytes;
+  /* per Gaussian, P entries */
+  uint64_t depth;          /* float   [P]    view-space z                                   */
+  uint64_t xy;             /* float2  [P]    pixel-space centre                             */
+  uint64_t conic_opacity;  /* float4  [P]    (A, B, C, opacity)                             */
+  uint64_t rgb;            /* float4  [P]    colour used for blending (.w unused)           */
+  uint64_t cov3d;          /* float   [P,6]  world-space covariance (xx,xy,xz,yy,yz,zz)     */
+  uint64_t rect;           /* int32   [P,4]  tile rect x0,y0,x1,y1 (half-open)              */
+  uint64_t tiles_touched;  /* uint32  [P]                                                   */
+  uint64_t clamped;        /* uint8   [P,4]  SH clamp flags rgb, pad                        */
+  /* per tile, T = ceil(W/16)*ceil(H/16) */
+  uint64_t tile_count;     /* uint32  [T]    number of (tile,Gaussian) pairs per tile       */
+  uint64_t tile_offset;    /* uint32  [T+1]  exclusive scan; [T] = total pairs D            */
+  uint64_t tile_cursor;    /* uint32  [T]    scatter cursors (scratch)                      */
+  /* per (tile,Gaussian) pair, capacity max_pairs */
+  uint64_t pair_key;       /* uint64  [cap]  (depth_bits << 32) | gaussian index            */
+  uint64_t point_list;     /* uint32  [cap]  per-tile lists, depth-sorted Gaussian indices  */
+  uint64_t pair_tmp;       /* uint64  [cap]  merge ping-pong buffer for oversized tiles     */
+  /* per pixel */
+  uint64_t final_T;        /* float   [H*W]                                                 */
+  uint64_t n_contrib;      /* uint32  [H*W]                                                 */
+  /* backward scratch: per-Gaussian screen-space gradient accumulators */
+  uint64_t grad_acc;       /* float   [P,12] (dxy2, dconic3, dopac1, drgb3, pad3)           */
+  /* status words */
+  uint64_t status;         /* int32   [8]  [0]=pairs needed (D) [1]=overflow flag
+                                           [2]=visible Gaussians [3]=max pairs in one tile  */
+} GsrLayout;
+
+/* Size in bytes of the workspace for P Gaussians, a W x H image and room for
+ * `max_pairs` (tile,Gaussian) pairs. Returns 0 on invalid arguments. */
+size_t gsr_workspace_bytes(int32_t P, int32_t W, int32_t H, int64_t max_pairs);
+
+/* Fill `out` with the sub-array offsets for the same arguments. */
+int gsr_workspace_layout(int32_t P, int32_t W, int32_t H, int64_t max_pairs, GsrLayout* out);
+
+/*
+ * Forward: replaces `_C.rasterize_gaussians`.
+ *
+ *   means3D        [P,3]
+ *   colors_precomp [P,3] or NULL      exactly one of colors_precomp / shs
+ *   shs            [P,M,3] or NULL    M = sh_coeffs
+ *   opacities      [P] (the reference passes [P,1])
+ *   scales         [P,3] and rotations [P,4] (r,x,y,z; NOT normalised), or cov3D_precomp [P,6]
+ *   workspace      gsr_workspace_bytes(P,W,H,max_pairs) bytes; kept for backward
+ *   out_color      [3,H,W]  (CHW)
+ *   out_radii      [P] int32; 0 = not rendered
+ *
+ * If the scene needs more than max_pairs pairs the call still returns 0 (it cannot know
+ * without a host sync): status[1] is set to 1, status[0] holds the required count, the
+ * surplus pairs are dropped. Callers poll status (gsr_read_status) after the stream has
+ * drained, or asynchronously — see INTEGRATION.md.
+ */
+int gsr_forward(const GsrSettings* settings, int32_t P,
+                const float* means3D, const float* colors_precomp,
+                const float* shs, int32_t sh_coeffs,
+                const float* opacities, const float* scales, const float* rotations,
+                const float* cov3D_precomp,
+                void* workspace, size_t workspace_bytes, int64_t max_pairs,
+                float* out_color, int32_t* out_radii, void* stream);
+
+/*
+ * Backward: replaces `_C.rasterize_gaussians_backward` (SURVEY.md §2.1 rows 7-9,
+ * Appendix A.4-A.5). Same inputs as forward plus the forward's workspace and
+ *   dL_dout_color [3,H,W].
+ * Outputs (any of them may be NULL = "not needed", the work is skipped where possible):
+ *   dL_dmeans3D [P,3], dL_dmeans2D [P,3] (z column 0), dL_dcolors [P,3], dL_dsh [P,M,3],
+ *   dL_dopacity [P], dL_dscales [P,3], dL_drotations [P,4], dL_dcov3D [P,6].
+ * Every non-NULL output is fully overwritten (zeros for Gaussians with radii == 0).
+ * The workspace is not consumed: backward may be called repeatedly (retain_graph).
+ */
+int gsr_backward(const GsrSettings* settings, int32_t P,
+                 const float* means3D, const float* colors_precomp,
+                 const float* shs, int32_t sh_coeffs,
+                 const float* opacities, const float* scales, const float* rotations,
+                 const float* cov3D_precomp,
+                 const int32_t* radii,
+                 void* workspace, size_t workspace_bytes, int64_t max_pairs,
+                 const float* dL_dout_color,
+                 float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors, float* dL_dsh,
+                 float* dL_dopacity, float* dL_dscales, float* dL_drotations,
+                 float* dL_dcov3D, void* stream);
+
+/* Replaces `_C.mark_visible`: out_visible[i] = 1 if Gaussian i passes the near-plane
+ * test of the forward pass (view-space z > 0.2). out_visible is uint8 [P]. */
+int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,
+                     const float* projmatrix, uint8_t* out_visible, void* stream);
+
+/* Blocking helper: waits for `stream`, copies the 8 status words to status_host. */
+int gsr_read_status(const void* workspace, int32_t P, int32_t W, int32_t H,
+                    int64_t max_pairs, int32_t* status_host, void* stream);
+
+/* Text of the last error raised on the calling thread ("" if none). */
+const char* gsr_last_error(void);
+
+/* ABI version of the loaded library (== GSR_ABI_VERSION of the header it was built from). */
+int gsr_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H */
