@@ -1,0 +1,117 @@
+"""ctypes bindings of the in-tree HIP libraries (include/gsr.h, include/galbs.h).
+
+There is NO fallback: if a library is missing the import of the op fails loudly — run
+`python -m gaussianavatar_amd.build` (or `__graft_entry__.build()`) first.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBDIR = os.path.join(_HERE, "_lib")
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+class GsrSettings(ctypes.Structure):
+    """struct GsrSettings (include/gsr.h)."""
+    _fields_ = [
+        ("image_height", c_int32), ("image_width", c_int32),
+        ("tanfovx", c_float), ("tanfovy", c_float), ("scale_modifier", c_float),
+        ("sh_degree", c_int32), ("prefiltered", c_int32), ("debug", c_int32),
+        ("bg", c_void_p), ("viewmatrix", c_void_p), ("projmatrix", c_void_p), ("campos", c_void_p),
+    ]
+
+
+_LAYOUT_FIELDS = ["total_bytes", "depth", "xy", "conic_opacity", "rgb", "cov3d", "rect",
+                  "tiles_touched", "clamped", "tile_count", "tile_offset", "tile_cursor",
+                  "pair_key", "point_list", "pair_tmp", "final_T", "n_contrib", "grad_acc", "status"]
+
+
+class GsrLayout(ctypes.Structure):
+    """struct GsrLayout (include/gsr.h)."""
+    _fields_ = [(n, c_uint64) for n in _LAYOUT_FIELDS]
+
+
+def _load(name: str) -> ctypes.CDLL:
+    path = os.path.join(_LIBDIR, name)
+    if not os.path.exists(path):
+        raise NativeLibraryMissing(
+            f"{path} not found: the HIP extension is not built. Run "
+            f"`python -m gaussianavatar_amd.build` (needs hipcc). There is no CPU fallback.")
+    return ctypes.CDLL(path)
+
+
+_gsr = None
+_galbs = None
+
+GSR_SYMBOLS = ["gsr_workspace_bytes", "gsr_workspace_layout", "gsr_forward", "gsr_backward",
+               "gsr_mark_visible", "gsr_read_status", "gsr_last_error", "gsr_abi_version"]
+GALBS_SYMBOLS = ["galbs_joint_saved_floats", "galbs_joint_transforms_fwd",
+                 "galbs_joint_transforms_bwd", "galbs_skin_fwd", "galbs_skin_bwd",
+                 "galbs_last_error", "galbs_abi_version"]
+
+
+def gsr() -> ctypes.CDLL:
+    global _gsr
+    if _gsr is None:
+        lib = _load("libgsr_hip.so")
+        P = c_void_p
+        lib.gsr_workspace_bytes.restype = c_size_t
+        lib.gsr_workspace_bytes.argtypes = [c_int32, c_int32, c_int32, c_int64]
+        lib.gsr_workspace_layout.restype = c_int
+        lib.gsr_workspace_layout.argtypes = [c_int32, c_int32, c_int32, c_int64, ctypes.POINTER(GsrLayout)]
+        lib.gsr_forward.restype = c_int
+        lib.gsr_forward.argtypes = [ctypes.POINTER(GsrSettings), c_int32, P, P, P, c_int32, P, P, P, P,
+                                    P, c_size_t, c_int64, P, P, P]
+        lib.gsr_backward.restype = c_int
+        lib.gsr_backward.argtypes = [ctypes.POINTER(GsrSettings), c_int32, P, P, P, c_int32, P, P, P, P,
+                                     P, P, c_size_t, c_int64, P, P, P, P, P, P, P, P, P, P]
+        lib.gsr_mark_visible.restype = c_int
+        lib.gsr_mark_visible.argtypes = [c_int32, P, P, P, P, P]
+        lib.gsr_read_status.restype = c_int
+        lib.gsr_read_status.argtypes = [P, c_int32, c_int32, c_int32, c_int64, P, P]
+        lib.gsr_last_error.restype = c_char_p
+        lib.gsr_abi_version.restype = c_int
+        if lib.gsr_abi_version() != 1:
+            raise RuntimeError("libgsr_hip.so ABI version mismatch; rebuild")
+        _gsr = lib
+    return _gsr
+
+
+def galbs() -> ctypes.CDLL:
+    global _galbs
+    if _galbs is None:
+        lib = _load("libgalbs_hip.so")
+        P = c_void_p
+        lib.galbs_joint_saved_floats.restype = c_size_t
+        lib.galbs_joint_saved_floats.argtypes = [c_int32]
+        lib.galbs_joint_transforms_fwd.restype = c_int
+        lib.galbs_joint_transforms_fwd.argtypes = [c_int32, c_int32, P, P, P, P, P, c_int64, P, P, P, P]
+        lib.galbs_joint_transforms_bwd.restype = c_int
+        lib.galbs_joint_transforms_bwd.argtypes = [c_int32, c_int32, P, P, P, P, c_int64, P, P, P, P, P, P]
+        lib.galbs_skin_fwd.restype = c_int
+        lib.galbs_skin_fwd.argtypes = [c_int32, c_int32, c_int32, P, c_int64, P, c_int64, P, c_int64, P, P, P]
+        lib.galbs_skin_bwd.restype = c_int
+        lib.galbs_skin_bwd.argtypes = [c_int32, c_int32, c_int32, P, c_int64, P, c_int64, P, c_int64, P, P,
+                                       P, P, P]
+        lib.galbs_last_error.restype = c_char_p
+        lib.galbs_abi_version.restype = c_int
+        if lib.galbs_abi_version() != 1:
+            raise RuntimeError("libgalbs_hip.so ABI version mismatch; rebuild")
+        _galbs = lib
+    return _galbs
+
+
+def gsr_check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError("gsr: " + gsr().gsr_last_error().decode())
+
+
+def galbs_check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError("galbs: " + galbs().galbs_last_error().decode())

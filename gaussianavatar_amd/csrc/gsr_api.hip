@@ -1,0 +1,268 @@
+// gsr_api.hip — the extern "C" boundary declared in include/gsr.h.
+//
+// Replaces the pybind entry points of the un-vendored diff_gaussian_rasterization._C module
+// (rasterize_gaussians / rasterize_gaussians_backward / mark_visible) reached from
+// /root/reference/gaussian_renderer/__init__.py:40. Plain pointers in, error codes out.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "gsr_common.h"
+
+namespace gsr {
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static inline uint64_t align_up(uint64_t v) { return (v + 255u) & ~(uint64_t)255u; }
+
+int compute_layout(int P, int W, int H, int64_t max_pairs, GsrLayout* out) {
+  if (P < 0 || W <= 0 || H <= 0 || max_pairs < 0 || max_pairs > 0xfffffff0ll) return 1;
+  const Dims d = make_dims(P, W, H, max_pairs);
+  const uint64_t Pn = (uint64_t)(P > 0 ? P : 1);
+  const uint64_t cap = (uint64_t)(max_pairs > 0 ? max_pairs : 1);
+  const uint64_t npix = (uint64_t)W * H;
+  uint64_t off = 0;
+  auto take = [&](uint64_t bytes) { uint64_t o = off; off = align_up(off + bytes); return o; };
+  out->depth = take(Pn * 4);
+  out->xy = take(Pn * 8);
+  out->conic_opacity = take(Pn * 16);
+  out->rgb = take(Pn * 16);
+  out->cov3d = take(Pn * 24);
+  out->rect = take(Pn * 16);
+  out->tiles_touched = take(Pn * 4);
+  out->clamped = take(Pn * 4);
+  out->tile_count = take((uint64_t)d.T * 4);
+  out->tile_offset = take(((uint64_t)d.T + 1) * 4);
+  out->tile_cursor = take((uint64_t)d.T * 4);
+  out->pair_key = take(cap * 8);
+  out->point_list = take(cap * 4);
+  out->pair_tmp = take(cap * 8);
+  out->final_T = take(npix * 4);
+  out->n_contrib = take(npix * 4);
+  out->grad_acc = take(Pn * GSR_GRAD_STRIDE * 4);
+  out->status = take(8 * 4);
+  out->total_bytes = off;
+  return 0;
+}
+
+Workspace resolve(void* base, const GsrLayout& L) {
+  char* b = static_cast<char*>(base);
+  Workspace w;
+  w.depth = reinterpret_cast<float*>(b + L.depth);
+  w.xy = reinterpret_cast<float2*>(b + L.xy);
+  w.conic_opacity = reinterpret_cast<float4*>(b + L.conic_opacity);
+  w.rgb = reinterpret_cast<float4*>(b + L.rgb);
+  w.cov3d = reinterpret_cast<float*>(b + L.cov3d);
+  w.rect = reinterpret_cast<int4*>(b + L.rect);
+  w.tiles_touched = reinterpret_cast<uint32_t*>(b + L.tiles_touched);
+  w.clamped = reinterpret_cast<uint8_t*>(b + L.clamped);
+  w.tile_count = reinterpret_cast<uint32_t*>(b + L.tile_count);
+  w.tile_offset = reinterpret_cast<uint32_t*>(b + L.tile_offset);
+  w.tile_cursor = reinterpret_cast<uint32_t*>(b + L.tile_cursor);
+  w.pair_key = reinterpret_cast<uint64_t*>(b + L.pair_key);
+  w.point_list = reinterpret_cast<uint32_t*>(b + L.point_list);
+  w.pair_tmp = reinterpret_cast<uint64_t*>(b + L.pair_tmp);
+  w.final_T = reinterpret_cast<float*>(b + L.final_T);
+  w.n_contrib = reinterpret_cast<uint32_t*>(b + L.n_contrib);
+  w.grad_acc = reinterpret_cast<float*>(b + L.grad_acc);
+  w.status = reinterpret_cast<int32_t*>(b + L.status);
+  return w;
+}
+
+static int check_hip(hipError_t e, const char* what) {
+  if (e == hipSuccess) return GSR_OK;
+  set_error("%s: %s", what, hipGetErrorString(e));
+  return GSR_ERR_LAUNCH;
+}
+
+static int debug_sync(const GsrSettings* s, hipStream_t stream, const char* what) {
+  if (!s->debug) return GSR_OK;
+  return check_hip(hipStreamSynchronize(stream), what);
+}
+
+static int validate(const GsrSettings* s, int32_t P, const float* means3D,
+                    const float* colors_precomp, const float* shs, const float* opacities,
+                    const float* scales, const float* rotations, const float* cov3D_precomp,
+                    void* workspace, size_t workspace_bytes, int64_t max_pairs, GsrLayout* L) {
+  if (!s) { set_error("settings is NULL"); return GSR_ERR_INVALID_ARGUMENT; }
+  if (P < 0 || s->image_width <= 0 || s->image_height <= 0) {
+    set_error("bad sizes: P=%d W=%d H=%d", P, s->image_width, s->image_height);
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  if (!s->bg || !s->viewmatrix || !s->projmatrix) {
+    set_error("bg, viewmatrix and projmatrix must be device pointers");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  if (P == 0) {   // empty scene: torch hands out NULL data pointers for empty tensors
+    if (compute_layout(P, s->image_width, s->image_height, max_pairs, L)) {
+      set_error("bad workspace arguments (max_pairs=%lld)", (long long)max_pairs);
+      return GSR_ERR_INVALID_ARGUMENT;
+    }
+    if (!workspace || workspace_bytes < L->total_bytes) {
+      set_error("workspace too small: have %zu bytes, need %llu", workspace_bytes,
+                (unsigned long long)L->total_bytes);
+      return GSR_ERR_WORKSPACE_TOO_SMALL;
+    }
+    return GSR_OK;
+  }
+  if ((colors_precomp == nullptr) == (shs == nullptr)) {
+    set_error("Please provide excatly one of either SHs or precomputed colors!");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  const bool has_sr = scales != nullptr || rotations != nullptr;
+  if ((has_sr && (!scales || !rotations)) || (has_sr == (cov3D_precomp != nullptr))) {
+    set_error("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  if (shs) {
+    set_error("spherical-harmonics colours are not implemented yet; pass colors_precomp "
+              "(the reference always does: /root/reference/model/avatar_model.py:350)");
+    return GSR_ERR_UNSUPPORTED;
+  }
+  if (P > 0 && (!means3D || !opacities)) {
+    set_error("means3D / opacities are NULL");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  if (compute_layout(P, s->image_width, s->image_height, max_pairs, L)) {
+    set_error("bad workspace arguments (max_pairs=%lld)", (long long)max_pairs);
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  if (!workspace || workspace_bytes < L->total_bytes) {
+    set_error("workspace too small: have %zu bytes, need %llu", workspace_bytes,
+              (unsigned long long)L->total_bytes);
+    return GSR_ERR_WORKSPACE_TOO_SMALL;
+  }
+  return GSR_OK;
+}
+
+}  // namespace gsr
+
+using namespace gsr;
+
+extern "C" {
+
+size_t gsr_workspace_bytes(int32_t P, int32_t W, int32_t H, int64_t max_pairs) {
+  GsrLayout L;
+  if (compute_layout(P, W, H, max_pairs, &L)) return 0;
+  return (size_t)L.total_bytes;
+}
+
+int gsr_workspace_layout(int32_t P, int32_t W, int32_t H, int64_t max_pairs, GsrLayout* out) {
+  if (!out || compute_layout(P, W, H, max_pairs, out)) {
+    set_error("gsr_workspace_layout: invalid arguments");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  return GSR_OK;
+}
+
+int gsr_forward(const GsrSettings* s, int32_t P, const float* means3D,
+                const float* colors_precomp, const float* shs, int32_t sh_coeffs,
+                const float* opacities, const float* scales, const float* rotations,
+                const float* cov3D_precomp, void* workspace, size_t workspace_bytes,
+                int64_t max_pairs, float* out_color, int32_t* out_radii, void* stream_) {
+  (void)sh_coeffs;
+  GsrLayout L;
+  int rc = validate(s, P, means3D, colors_precomp, shs, opacities, scales, rotations,
+                    cov3D_precomp, workspace, workspace_bytes, max_pairs, &L);
+  if (rc) return rc;
+  if (!out_color || (P > 0 && !out_radii)) {
+    set_error("out_color / out_radii are NULL");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const Dims d = make_dims(P, s->image_width, s->image_height, max_pairs);
+  const Workspace ws = resolve(workspace, L);
+  // tile_count .. tile_cursor are contiguous in the layout: one memset clears the histogram
+  if ((rc = check_hip(hipMemsetAsync(ws.tile_count, 0, L.tile_cursor - L.tile_count, stream),
+                      "memset tile_count")))
+    return rc;
+  if ((rc = check_hip(hipMemsetAsync(ws.status, 0, 8 * sizeof(int32_t), stream), "memset status")))
+    return rc;
+  if ((rc = check_hip(launch_preprocess(*s, d, means3D, colors_precomp, opacities, scales,
+                                        rotations, cov3D_precomp, ws, out_radii, stream),
+                      "preprocess")))
+    return rc;
+  if ((rc = debug_sync(s, stream, "preprocess (sync)"))) return rc;
+  if ((rc = check_hip(launch_binning(d, ws, stream), "binning"))) return rc;
+  if ((rc = debug_sync(s, stream, "binning (sync)"))) return rc;
+  if ((rc = check_hip(launch_render_fwd(*s, d, ws, out_color, stream), "render_fwd"))) return rc;
+  if ((rc = debug_sync(s, stream, "render_fwd (sync)"))) return rc;
+  return GSR_OK;
+}
+
+int gsr_backward(const GsrSettings* s, int32_t P, const float* means3D,
+                 const float* colors_precomp, const float* shs, int32_t sh_coeffs,
+                 const float* opacities, const float* scales, const float* rotations,
+                 const float* cov3D_precomp, const int32_t* radii, void* workspace,
+                 size_t workspace_bytes, int64_t max_pairs, const float* dL_dout_color,
+                 float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors, float* dL_dsh,
+                 float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                 void* stream_) {
+  (void)sh_coeffs; (void)dL_dsh;
+  GsrLayout L;
+  int rc = validate(s, P, means3D, colors_precomp, shs, opacities, scales, rotations,
+                    cov3D_precomp, workspace, workspace_bytes, max_pairs, &L);
+  if (rc) return rc;
+  if (!dL_dout_color || (P > 0 && !radii)) {
+    set_error("dL_dout_color / radii are NULL");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  if (P == 0) return GSR_OK;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const Dims d = make_dims(P, s->image_width, s->image_height, max_pairs);
+  const Workspace ws = resolve(workspace, L);
+  if ((rc = check_hip(hipMemsetAsync(ws.grad_acc, 0, (size_t)P * GSR_GRAD_STRIDE * sizeof(float),
+                                     stream), "memset grad_acc")))
+    return rc;
+  if ((rc = check_hip(launch_render_bwd(*s, d, ws, dL_dout_color, stream), "render_bwd")))
+    return rc;
+  if ((rc = debug_sync(s, stream, "render_bwd (sync)"))) return rc;
+  if ((rc = check_hip(launch_preprocess_bwd(*s, d, means3D, scales, rotations, radii, ws,
+                                            dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity,
+                                            dL_dscales, dL_drotations, dL_dcov3D, stream),
+                      "preprocess_bwd")))
+    return rc;
+  if ((rc = debug_sync(s, stream, "preprocess_bwd (sync)"))) return rc;
+  return GSR_OK;
+}
+
+int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,
+                     const float* projmatrix, uint8_t* out_visible, void* stream_) {
+  (void)projmatrix;
+  if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !out_visible))) {
+    set_error("gsr_mark_visible: invalid arguments");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  return check_hip(launch_mark_visible(P, means3D, viewmatrix, out_visible,
+                                       static_cast<hipStream_t>(stream_)), "mark_visible");
+}
+
+int gsr_read_status(const void* workspace, int32_t P, int32_t W, int32_t H, int64_t max_pairs,
+                    int32_t* status_host, void* stream_) {
+  GsrLayout L;
+  if (!workspace || !status_host || compute_layout(P, W, H, max_pairs, &L)) {
+    set_error("gsr_read_status: invalid arguments");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  int rc = check_hip(hipMemcpyAsync(status_host, static_cast<const char*>(workspace) + L.status,
+                                    8 * sizeof(int32_t), hipMemcpyDeviceToHost, stream),
+                     "status copy");
+  if (rc) return rc;
+  return check_hip(hipStreamSynchronize(stream), "status sync");
+}
+
+const char* gsr_last_error(void) { return g_err; }
+
+int gsr_abi_version(void) { return GSR_ABI_VERSION; }
+
+}  // extern "C"

@@ -1,0 +1,206 @@
+// gsr_binning.hip — K2 tile_scan, K3 scatter, K4 tile_sort.
+//
+// Replaces the reference's global pipeline (InclusiveSum over Gaussians -> blocking D2H read
+// of the pair count -> duplicateWithKeys -> 64-bit global radix sort -> identifyTileRanges;
+// SURVEY.md §2.1) with a per-tile one that never leaves the device:
+//   histogram (in K1) -> one-block scan over tiles -> atomic append per tile -> per-tile sort
+//   of (depth_bits<<32 | gaussian) keys in LDS.
+// The per-tile order is the same total order (depth bits, then Gaussian index; Appendix A.2),
+// so the lists are bit-identical to the reference's however the appends interleave.
+#include "gsr_common.h"
+
+namespace gsr {
+
+namespace {
+
+constexpr int SCAN_THREADS = 1024;
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_CAP = 4096;        // keys sorted in LDS at once (32 KiB)
+constexpr int MERGE_ITEMS = 8;        // outputs per thread per merge step
+
+// ------------------------------------------------------------------ K2
+__global__ void __launch_bounds__(SCAN_THREADS)
+tile_scan_kernel(int T, int64_t max_pairs, const uint32_t* __restrict__ tile_count,
+                 uint32_t* __restrict__ tile_offset, uint32_t* __restrict__ tile_cursor,
+                 int32_t* __restrict__ status) {
+  __shared__ uint32_t s_wave[SCAN_THREADS / GSR_WAVE];
+  __shared__ uint32_t s_max[SCAN_THREADS / GSR_WAVE];
+  const int tid = threadIdx.x;
+  const int per = (T + SCAN_THREADS - 1) / SCAN_THREADS;
+  const int lo = tid * per;
+  const int hi = min(lo + per, T);
+  uint32_t sum = 0, mx = 0;
+  for (int t = lo; t < hi; ++t) {
+    const uint32_t c = tile_count[t];
+    sum += c;
+    mx = max(mx, c);
+  }
+  // inclusive scan of `sum` across the wave, then across the 16 waves
+  const int lane = tid & (GSR_WAVE - 1), wave = tid / GSR_WAVE;
+  uint32_t incl = sum;
+#pragma unroll
+  for (int off = 1; off < GSR_WAVE; off <<= 1) {
+    const uint32_t v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+#pragma unroll
+  for (int off = GSR_WAVE / 2; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
+  if (lane == GSR_WAVE - 1) s_wave[wave] = incl;
+  if (lane == 0) s_max[wave] = mx;
+  __syncthreads();
+  uint32_t base = 0, total = 0, gmax = 0;
+#pragma unroll
+  for (int w = 0; w < SCAN_THREADS / GSR_WAVE; ++w) {
+    if (w < wave) base += s_wave[w];
+    total += s_wave[w];
+    gmax = max(gmax, s_max[w]);
+  }
+  uint32_t run = base + incl - sum;   // exclusive prefix of this thread's chunk
+  for (int t = lo; t < hi; ++t) {
+    tile_offset[t] = run;
+    tile_cursor[t] = run;
+    run += tile_count[t];
+  }
+  if (tid == 0) {
+    tile_offset[T] = total;
+    status[0] = (int32_t)total;
+    status[1] = ((int64_t)total > max_pairs) ? 1 : 0;
+    status[3] = (int32_t)gmax;
+  }
+}
+
+// ------------------------------------------------------------------ K3
+__global__ void __launch_bounds__(256)
+scatter_kernel(int P, int gx, int64_t max_pairs, const int4* __restrict__ rect,
+               const float* __restrict__ depth, uint32_t* __restrict__ tile_cursor,
+               uint64_t* __restrict__ pair_key) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const int4 rc = rect[i];
+  if (rc.z <= rc.x || rc.w <= rc.y) return;
+  const uint64_t key = ((uint64_t)__float_as_uint(depth[i]) << 32) | (uint32_t)i;
+  for (int y = rc.y; y < rc.w; ++y)
+    for (int x = rc.x; x < rc.z; ++x) {
+      const uint32_t pos = atomicAdd(&tile_cursor[y * gx + x], 1u);
+      if ((int64_t)pos < max_pairs) pair_key[pos] = key;
+    }
+}
+
+// ------------------------------------------------------------------ K4
+// Bitonic sort of n2 (power of two) keys held in LDS by SORT_THREADS threads.
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t* s, int n2, int tid) {
+  for (int k = 2; k <= n2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (n2 >> 1); t += SORT_THREADS) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int l = i | j;
+        const uint64_t a = s[i], b = s[l];
+        const bool up = (i & k) == 0;
+        if ((a > b) == up) { s[i] = b; s[l] = a; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__device__ __forceinline__ int next_pow2(int n) {
+  int p = 2;
+  while (p < n) p <<= 1;
+  return p;
+}
+
+// Merge-path split: number of elements taken from A among the first `diag` outputs of
+// merge(A[0..na), B[0..nb)); ties go to A (stable, although keys are unique here).
+__device__ __forceinline__ int merge_split(const uint64_t* A, int na, const uint64_t* B, int nb,
+                                           int diag) {
+  int lo = max(0, diag - nb), hi = min(diag, na);
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (A[mid] <= B[diag - 1 - mid]) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void __launch_bounds__(SORT_THREADS)
+tile_sort_kernel(int64_t max_pairs, const uint32_t* __restrict__ tile_offset,
+                 uint64_t* __restrict__ pair_key, uint64_t* __restrict__ pair_tmp,
+                 uint32_t* __restrict__ point_list) {
+  __shared__ uint64_t s_key[SORT_CAP];
+  const int tile = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int64_t cap = max_pairs;
+  const int64_t start = min((int64_t)tile_offset[tile], cap);
+  const int64_t end = min((int64_t)tile_offset[tile + 1], cap);
+  const int n = (int)(end - start);
+  if (n <= 0) return;
+  uint64_t* keys = pair_key + start;
+  uint32_t* out = point_list + start;
+  if (n == 1) {
+    if (tid == 0) out[0] = (uint32_t)keys[0];
+    return;
+  }
+  if (n <= SORT_CAP) {
+    const int n2 = next_pow2(n);
+    for (int i = tid; i < n2; i += SORT_THREADS) s_key[i] = (i < n) ? keys[i] : ~0ull;
+    __syncthreads();
+    bitonic_sort_lds(s_key, n2, tid);
+    for (int i = tid; i < n; i += SORT_THREADS) out[i] = (uint32_t)s_key[i];
+    return;
+  }
+  // Oversized list: sort SORT_CAP-sized runs in LDS, then merge runs through HBM.
+  for (int c0 = 0; c0 < n; c0 += SORT_CAP) {
+    const int m = min(SORT_CAP, n - c0);
+    const int m2 = next_pow2(m);
+    for (int i = tid; i < m2; i += SORT_THREADS) s_key[i] = (i < m) ? keys[c0 + i] : ~0ull;
+    __syncthreads();
+    bitonic_sort_lds(s_key, m2, tid);
+    for (int i = tid; i < m; i += SORT_THREADS) keys[c0 + i] = s_key[i];
+    __syncthreads();
+  }
+  uint64_t* src = keys;
+  uint64_t* dst = pair_tmp + start;
+  for (int64_t width = SORT_CAP; width < n; width <<= 1) {
+    const int nseg = (n + MERGE_ITEMS - 1) / MERGE_ITEMS;
+    for (int seg = tid; seg < nseg; seg += SORT_THREADS) {
+      const int64_t g0 = (int64_t)seg * MERGE_ITEMS;
+      const int64_t lo = (g0 / (2 * width)) * (2 * width);
+      const int64_t mid = min(lo + width, (int64_t)n);
+      const int64_t hi = min(lo + 2 * width, (int64_t)n);
+      const uint64_t* A = src + lo;
+      const uint64_t* B = src + mid;
+      const int na = (int)(mid - lo), nb = (int)(hi - mid);
+      const int diag = (int)(g0 - lo);
+      int ia = merge_split(A, na, B, nb, diag);
+      int ib = diag - ia;
+      const int cnt = (int)min((int64_t)MERGE_ITEMS, hi - g0);
+      for (int o = 0; o < cnt; ++o) {
+        const bool takeA = (ib >= nb) || (ia < na && A[ia] <= B[ib]);
+        dst[g0 + o] = takeA ? A[ia++] : B[ib++];
+      }
+    }
+    __syncthreads();   // workgroup-scope visibility of dst (one CU, shared L1)
+    uint64_t* t = src; src = dst; dst = t;
+  }
+  for (int i = tid; i < n; i += SORT_THREADS) out[i] = (uint32_t)src[i];
+}
+
+}  // namespace
+
+hipError_t launch_binning(const Dims& d, const Workspace& ws, hipStream_t stream) {
+  hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, d.T, d.max_pairs,
+                     ws.tile_count, ws.tile_offset, ws.tile_cursor, ws.status);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (d.P > 0) {
+    hipLaunchKernelGGL(scatter_kernel, dim3((d.P + 255) / 256), dim3(256), 0, stream, d.P, d.gx,
+                       d.max_pairs, ws.rect, ws.depth, ws.tile_cursor, ws.pair_key);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(d.T), dim3(SORT_THREADS), 0, stream, d.max_pairs,
+                       ws.tile_offset, ws.pair_key, ws.pair_tmp, ws.point_list);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+}  // namespace gsr

@@ -1,0 +1,91 @@
+// gsr_common.h — shared declarations of the gfx950 rasterizer kernels (internal).
+//
+// Pipeline (one frame, everything on one stream, no host read-back):
+//
+//   K1 preprocess      per Gaussian : project, EWA covariance, conic, radius, tile rect;
+//                                     per-tile histogram of (tile,Gaussian) pairs
+//   K2 tile_scan       one block    : exclusive scan of the histogram -> tile_offset, D
+//   K3 scatter         per Gaussian : append (depth_bits<<32 | index) to each touched tile
+//   K4 tile_sort       per tile     : sort the tile's keys in LDS (bitonic; merge passes
+//                                     through HBM for lists that do not fit) -> point_list
+//   K5 render_fwd      per tile     : front-to-back alpha compositing, LDS-staged lists
+//   K6 render_bwd      per tile     : back-to-front re-traversal, wave-reduced gradients
+//   K7 preprocess_bwd  per Gaussian : screen-space grads -> means3D / scales / rotations
+//
+// Behavioural spec: SURVEY.md Appendix A (the reference's rasterizer is the un-vendored
+// diff_gaussian_rasterization package used at /root/reference/gaussian_renderer/__init__.py:6).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gsr.h"
+
+#define GSR_TILE_PIX (GSR_TILE * GSR_TILE)   // 256 threads per tile = 4 wave64
+#define GSR_WAVE 64
+#define GSR_GRAD_STRIDE 12                   // floats per Gaussian in grad_acc
+
+namespace gsr {
+
+struct Dims {
+  int P, W, H, gx, gy, T;
+  int64_t max_pairs;
+};
+
+inline Dims make_dims(int P, int W, int H, int64_t max_pairs) {
+  Dims d;
+  d.P = P; d.W = W; d.H = H;
+  d.gx = (W + GSR_TILE - 1) / GSR_TILE;
+  d.gy = (H + GSR_TILE - 1) / GSR_TILE;
+  d.T = d.gx * d.gy;
+  d.max_pairs = max_pairs;
+  return d;
+}
+
+// Resolved device pointers into the caller-owned workspace.
+struct Workspace {
+  float* depth;
+  float2* xy;
+  float4* conic_opacity;
+  float4* rgb;
+  float* cov3d;
+  int4* rect;
+  uint32_t* tiles_touched;
+  uint8_t* clamped;
+  uint32_t* tile_count;
+  uint32_t* tile_offset;
+  uint32_t* tile_cursor;
+  uint64_t* pair_key;
+  uint32_t* point_list;
+  uint64_t* pair_tmp;
+  float* final_T;
+  uint32_t* n_contrib;
+  float* grad_acc;
+  int32_t* status;
+};
+
+int compute_layout(int P, int W, int H, int64_t max_pairs, GsrLayout* out);
+Workspace resolve(void* base, const GsrLayout& L);
+void set_error(const char* fmt, ...);
+
+// Kernel launchers (each returns a hipError_t from the launch).
+hipError_t launch_preprocess(const GsrSettings& s, const Dims& d, const float* means3D,
+                             const float* colors_precomp, const float* opacities,
+                             const float* scales, const float* rotations,
+                             const float* cov3D_precomp, const Workspace& ws, int32_t* radii,
+                             hipStream_t stream);
+hipError_t launch_binning(const Dims& d, const Workspace& ws, hipStream_t stream);
+hipError_t launch_render_fwd(const GsrSettings& s, const Dims& d, const Workspace& ws,
+                             float* out_color, hipStream_t stream);
+hipError_t launch_render_bwd(const GsrSettings& s, const Dims& d, const Workspace& ws,
+                             const float* dL_dout, hipStream_t stream);
+hipError_t launch_preprocess_bwd(const GsrSettings& s, const Dims& d, const float* means3D,
+                                 const float* scales, const float* rotations,
+                                 const int32_t* radii, const Workspace& ws,
+                                 float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors,
+                                 float* dL_dopacity, float* dL_dscales, float* dL_drotations,
+                                 float* dL_dcov3D, hipStream_t stream);
+hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix,
+                               uint8_t* out, hipStream_t stream);
+
+}  // namespace gsr

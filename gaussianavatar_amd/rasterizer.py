@@ -1,0 +1,374 @@
+"""Python surface of the rasterizer: a mirror of the `diff_gaussian_rasterization` package.
+
+The reference imports `GaussianRasterizationSettings` and `GaussianRasterizer` from that
+(un-vendored, CUDA) package at /root/reference/gaussian_renderer/__init__.py:6 and calls them
+at :21-48. This module provides the same names, argument meaning, return values and error
+behaviour on top of the gfx950 HIP library (include/gsr.h); the top-level package
+`diff_gaussian_rasterization/` re-exports it so the reference's renderer shim runs unchanged.
+
+Everything is enqueued on torch's current HIP stream; the forward pass performs no
+device->host read-back (the reference blocks on a cudaMemcpy of the pair count every frame).
+The only thing the host ever needs to learn — whether the (tile,Gaussian) pair buffer was
+large enough — comes back through an asynchronous copy into pinned memory that is polled
+later (see `_PairCapacity`).
+"""
+from __future__ import annotations
+
+import ctypes
+import warnings
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _native
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    """Same 12 fields, same order as the reference builds them
+    (/root/reference/gaussian_renderer/__init__.py:21-34)."""
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+class RasterizerOverflow(RuntimeError):
+    """The (tile, Gaussian) pair buffer of an earlier forward pass was too small: that frame
+    was rendered from truncated tile lists. The capacity has been raised for later calls."""
+
+
+class _PairCapacity:
+    """Sizing of the pair buffer without a host sync on the hot path.
+
+    capacity = max(pairs_per_gaussian * P, floor, 1.25 * largest count seen so far).
+    After every forward the 8 status words are copied asynchronously into pinned memory;
+    pending copies are polled (never waited for) on later calls, and a detected overflow
+    raises RasterizerOverflow (policy "raise", default) or warns (policy "warn").
+    Under torch.no_grad() (evaluation) and with settings.debug the check is synchronous and
+    an overflowing frame is transparently re-rendered with a larger buffer.
+    """
+
+    def __init__(self):
+        self.pairs_per_gaussian = 16
+        self.floor = 1 << 16
+        self.seen = 0
+        self.policy = "raise"
+        self.pending = []      # (event, pinned status, capacity)
+        self.pool = []
+        self.last_status = None
+
+    def capacity(self, P: int) -> int:
+        cap = max(self.pairs_per_gaussian * P, self.floor, int(self.seen * 1.25) + 1024)
+        return min(cap, 0xfffffff0)
+
+    def _pinned(self):
+        return self.pool.pop() if self.pool else torch.empty(8, dtype=torch.int32).pin_memory()
+
+    def post(self, status_dev: torch.Tensor, cap: int):
+        host = self._pinned()
+        host.copy_(status_dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending.append((ev, host, cap))
+
+    def _consume(self, host, cap):
+        needed, overflow = int(host[0]), int(host[1])
+        self.last_status = host.tolist()
+        self.pool.append(host)
+        self.seen = max(self.seen, needed)
+        if overflow:
+            msg = (f"rasterizer pair buffer overflow: a forward pass needed {needed} "
+                   f"(tile,Gaussian) pairs but had room for {cap}; that frame was rendered from "
+                   f"truncated tile lists. Capacity is now raised; to avoid this up front call "
+                   f"gaussianavatar_amd.rasterizer.set_pair_capacity(pairs_per_gaussian=...).")
+            if self.policy == "raise":
+                raise RasterizerOverflow(msg)
+            warnings.warn(msg)
+        return needed, overflow
+
+    def poll(self, block: bool = False):
+        """Check finished status copies; with block=True wait for all of them."""
+        while self.pending:
+            ev, host, cap = self.pending[0]
+            if not block and len(self.pending) <= 8 and not ev.query():
+                break
+            ev.synchronize()
+            self.pending.pop(0)
+            self._consume(host, cap)
+
+    def wait_last(self):
+        """Synchronously resolve the newest pending copy WITHOUT raising; returns (needed, overflow)."""
+        ev, host, cap = self.pending.pop()
+        ev.synchronize()
+        needed, overflow = int(host[0]), int(host[1])
+        self.last_status = host.tolist()
+        self.pool.append(host)
+        self.seen = max(self.seen, needed)
+        return needed, overflow
+
+
+_capacity = _PairCapacity()
+
+
+def set_pair_capacity(pairs_per_gaussian: Optional[int] = None, floor: Optional[int] = None,
+                      on_overflow: Optional[str] = None) -> None:
+    """Tune the pair-buffer sizing policy (see _PairCapacity)."""
+    if pairs_per_gaussian is not None:
+        _capacity.pairs_per_gaussian = int(pairs_per_gaussian)
+    if floor is not None:
+        _capacity.floor = int(floor)
+    if on_overflow is not None:
+        assert on_overflow in ("raise", "warn")
+        _capacity.policy = on_overflow
+
+
+def check_overflow(block: bool = True) -> None:
+    """Resolve outstanding overflow checks (block=True waits for the device)."""
+    _capacity.poll(block=block)
+
+
+def last_status():
+    """The 8 status words of the most recently checked forward pass:
+    [pairs needed, overflow flag, -, longest tile list, ...]."""
+    return _capacity.last_status
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _f32c(t: torch.Tensor, shape=None) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        t = t.reshape(shape)
+    return t.contiguous()
+
+
+def _stream_ptr(device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _settings_struct(rs: GaussianRasterizationSettings, keep: list) -> "_native.GsrSettings":
+    dev = rs.viewmatrix.device
+    bg = _f32c(rs.bg.to(dev), (3,))
+    view = _f32c(rs.viewmatrix, (16,))
+    proj = _f32c(rs.projmatrix.to(dev), (16,))
+    campos = _f32c(rs.campos.to(dev), (3,))
+    keep += [bg, view, proj, campos]
+    return _native.GsrSettings(int(rs.image_height), int(rs.image_width), float(rs.tanfovx),
+                               float(rs.tanfovy), float(rs.scale_modifier), int(rs.sh_degree),
+                               int(bool(rs.prefiltered)), int(bool(rs.debug)),
+                               bg.data_ptr(), view.data_ptr(), proj.data_ptr(), campos.data_ptr())
+
+
+def workspace_views(workspace: torch.Tensor, P: int, W: int, H: int, max_pairs: int) -> dict:
+    """Typed views of the published sub-arrays of a forward workspace (for tests/tools)."""
+    lib = _native.gsr()
+    L = _native.GsrLayout()
+    _native.gsr_check(lib.gsr_workspace_layout(P, W, H, max_pairs, ctypes.byref(L)))
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+
+    def view(off, nbytes, dtype, shape):
+        return workspace[off:off + nbytes].view(dtype).reshape(shape)
+
+    return dict(
+        depth=view(L.depth, P * 4, torch.float32, (P,)),
+        xy=view(L.xy, P * 8, torch.float32, (P, 2)),
+        conic_opacity=view(L.conic_opacity, P * 16, torch.float32, (P, 4)),
+        rgb=view(L.rgb, P * 16, torch.float32, (P, 4)),
+        cov3d=view(L.cov3d, P * 24, torch.float32, (P, 6)),
+        rect=view(L.rect, P * 16, torch.int32, (P, 4)),
+        tiles_touched=view(L.tiles_touched, P * 4, torch.int32, (P,)),
+        tile_count=view(L.tile_count, T * 4, torch.int32, (T,)),
+        tile_offset=view(L.tile_offset, (T + 1) * 4, torch.int32, (T + 1,)),
+        point_list=view(L.point_list, max_pairs * 4, torch.int32, (max_pairs,)),
+        final_T=view(L.final_T, W * H * 4, torch.float32, (H * W,)),
+        n_contrib=view(L.n_contrib, W * H * 4, torch.int32, (H * W,)),
+        grad_acc=view(L.grad_acc, P * 48, torch.float32, (P, 12)),
+        status=view(L.status, 32, torch.int32, (8,)),
+    )
+
+
+def _forward_once(rs, means3D, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                  max_pairs):
+    lib = _native.gsr()
+    dev = means3D.device
+    P = means3D.shape[0]
+    H, W = int(rs.image_height), int(rs.image_width)
+    nbytes = lib.gsr_workspace_bytes(P, W, H, max_pairs)
+    if nbytes == 0:
+        raise RuntimeError("gsr_workspace_bytes: invalid arguments")
+    workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    keep = []
+    st = _settings_struct(rs, keep)
+    rc = lib.gsr_forward(ctypes.byref(st), P, _ptr(means3D), _ptr(colors_precomp), None, 0,
+                         _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
+                         _ptr(workspace), nbytes, max_pairs, _ptr(color), _ptr(radii),
+                         _stream_ptr(dev))
+    _native.gsr_check(rc)
+    L = _native.GsrLayout()
+    lib.gsr_workspace_layout(P, W, H, max_pairs, ctypes.byref(L))
+    status = workspace[L.status:L.status + 32].view(torch.int32)
+    return color, radii, workspace, status
+
+
+def rasterize_with_state(raster_settings, means3D, colors_precomp, opacities, scales=None,
+                         rotations=None, cov3D_precomp=None, max_pairs: Optional[int] = None):
+    """Forward only, returning the internal state as well (parity tests and tools):
+    (color, radii, views, status_list) where `views` are the typed workspace sub-arrays."""
+    P = means3D.shape[0]
+    means3D = _f32c(means3D, (P, 3))
+    colors_precomp = _f32c(colors_precomp, (P, 3))
+    opacities = _f32c(opacities, (P,))
+    scales = _f32c(scales, (P, 3)) if scales is not None else None
+    rotations = _f32c(rotations, (P, 4)) if rotations is not None else None
+    cov3D_precomp = _f32c(cov3D_precomp, (P, 6)) if cov3D_precomp is not None else None
+    if max_pairs is None:
+        max_pairs = _capacity.capacity(P)
+    color, radii, workspace, status = _forward_once(
+        raster_settings, means3D, colors_precomp, opacities, scales, rotations, cov3D_precomp, max_pairs)
+    views = workspace_views(workspace, P, int(raster_settings.image_width),
+                            int(raster_settings.image_height), max_pairs)
+    torch.cuda.synchronize()
+    return color, radii, views, status.tolist()
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    """Argument order and gradient order follow the upstream autograd Function
+    (SURVEY.md §8b): (means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+    cov3Ds_precomp, raster_settings)."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                cov3Ds_precomp, raster_settings, sync_check=False):
+        rs = raster_settings
+        if not means3D.is_cuda:
+            raise RuntimeError("GaussianRasterizer: tensors must live on a HIP device "
+                               "(there is no CPU fallback)")
+        if sh is not None and sh.numel() > 0:
+            raise NotImplementedError(
+                "spherical-harmonics colours are not implemented yet; pass colors_precomp")
+        P = means3D.shape[0]
+        means3D = _f32c(means3D, (P, 3))
+        colors_precomp = _f32c(colors_precomp, (P, 3))
+        opacities = _f32c(opacities, (P,))
+        scales = _f32c(scales, (P, 3)) if scales is not None else None
+        rotations = _f32c(rotations, (P, 4)) if rotations is not None else None
+        cov3Ds_precomp = _f32c(cov3Ds_precomp, (P, 6)) if cov3Ds_precomp is not None else None
+
+        _capacity.poll()
+        sync_check = bool(rs.debug) or bool(sync_check)
+        max_pairs = _capacity.capacity(P)
+        while True:
+            color, radii, workspace, status = _forward_once(
+                rs, means3D, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, max_pairs)
+            _capacity.post(status, max_pairs)
+            if not sync_check:
+                break
+            needed, overflow = _capacity.wait_last()
+            if not overflow:
+                break
+            max_pairs = min(int(needed * 1.25) + 1024, 0xfffffff0)
+
+        ctx.raster_settings = rs
+        ctx.max_pairs = max_pairs
+        ctx.has_sr = scales is not None
+        ctx.save_for_backward(means3D, colors_precomp, opacities,
+                              scales if scales is not None else torch.empty(0, device=means3D.device),
+                              rotations if rotations is not None else torch.empty(0, device=means3D.device),
+                              cov3Ds_precomp if cov3Ds_precomp is not None else torch.empty(0, device=means3D.device),
+                              radii, workspace)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_color, _grad_radii):
+        lib = _native.gsr()
+        rs = ctx.raster_settings
+        means3D, colors_precomp, opacities, scales, rotations, cov3D, radii, workspace = ctx.saved_tensors
+        if not ctx.has_sr:
+            scales = rotations = None
+        else:
+            cov3D = None
+        _capacity.poll()
+        dev = means3D.device
+        P = means3D.shape[0]
+        H, W = int(rs.image_height), int(rs.image_width)
+        grad_color = _f32c(grad_color, (3, H, W))
+        need = ctx.needs_input_grad
+
+        def out(flag, *shape):
+            return torch.empty(shape, dtype=torch.float32, device=dev) if flag else None
+
+        d_means3D = out(need[0], P, 3)
+        d_means2D = out(need[1], P, 3)
+        d_colors = out(need[3], P, 3)
+        d_opac = out(need[4], P, 1)
+        d_scales = out(need[5] and ctx.has_sr, P, 3)
+        d_rots = out(need[6] and ctx.has_sr, P, 4)
+        d_cov = out(need[7] and not ctx.has_sr, P, 6)
+        keep = []
+        st = _settings_struct(rs, keep)
+        rc = lib.gsr_backward(ctypes.byref(st), P, _ptr(means3D), _ptr(colors_precomp), None, 0,
+                              _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3D),
+                              _ptr(radii), _ptr(workspace), workspace.numel(), ctx.max_pairs,
+                              _ptr(grad_color), _ptr(d_means3D), _ptr(d_means2D), _ptr(d_colors),
+                              None, _ptr(d_opac), _ptr(d_scales), _ptr(d_rots), _ptr(d_cov),
+                              _stream_ptr(dev))
+        _native.gsr_check(rc)
+        return d_means3D, d_means2D, None, d_colors, d_opac, d_scales, d_rots, d_cov, None, None
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                        cov3Ds_precomp, raster_settings):
+    # grad mode is always off inside Function.forward, so decide here whether anybody can
+    # call backward: if not (evaluation), the overflow check is done synchronously.
+    tensors = (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
+    differentiable = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad for t in tensors)
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales,
+                                     rotations, cov3Ds_precomp, raster_settings,
+                                     not differentiable)
+
+
+class GaussianRasterizer(nn.Module):
+    """Drop-in for diff_gaussian_rasterization.GaussianRasterizer."""
+
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        rs = self.raster_settings
+        lib = _native.gsr()
+        with torch.no_grad():
+            P = positions.shape[0]
+            pos = _f32c(positions, (P, 3))
+            out = torch.empty(P, dtype=torch.uint8, device=pos.device)
+            view = _f32c(rs.viewmatrix, (16,))
+            proj = _f32c(rs.projmatrix, (16,))
+            _native.gsr_check(lib.gsr_mark_visible(P, _ptr(pos), _ptr(view), _ptr(proj), _ptr(out),
+                                                   _stream_ptr(pos.device)))
+        return out.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
+                rotations=None, cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales,
+                                   rotations, cov3D_precomp, self.raster_settings)
