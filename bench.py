@@ -1,0 +1,232 @@
+#!/usr/bin/env python
+"""bench.py — train iters/s (fwd+bwd) of the GaussianAvatar render-and-fit hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one stage-1 training iteration on one batch of synthetic frames per GPU:
+AvatarModel.train_stage1 (LBS joint transforms -> feature net -> fused skinning -> HIP Gaussian
+rasterizer) + L1 + DSSIM + regularisers (as /root/reference/train.py:70-77) -> backward -> Adam
+step. Workload (BASELINE.json configs[2] / configs[3]): ~200k Gaussians, 1024x1024, batch of
+2 frames per GPU (the reference's default batch size), frames sharded over GPUs with one RCCL
+all-reduce of the per-Gaussian output gradients. `value` = N * K / T: reference-sized (2-frame)
+iterations per second over the whole job ("weak" scaling: per-GPU work is fixed).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     the dominant rasterizer kernel: algorithmic bytes per launch / HIP-event time
+  cpu_baseline the reference's PyTorch-CPU LBS + skinning + projection + L1 path (a port:
+               oracle/lbs_oracle.py restates it; /root/reference is not on the GPU box),
+               timed on the host cores on a bounded sample, rank 0, N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(P: int, D: float, npix: int) -> dict:
+    """Compulsory fp32 traffic per launch, each datum moved once, split by
+    kernel so that a kernel's time is priced against its own bytes:
+      preprocess      92 P   (read 56 = xyz12+scale12+rot16+opac4+rgb12, write 36)
+      binning         16 D   (write 12/pair, read 4/pair)          [scan+scatter+sort]
+      render_fwd      40 D + 20 Npix
+      render_bwd      44 D + 20 Npix + 36 P   (pixels in: dL 12 + T 4 + n 4; pairs: idx 4 + 40;
+                                               per-Gaussian screen-space grads written once: 36)
+      preprocess_bwd  132 P  (read 56 + 36, write 40)
+    Sum = raster fwd 92P+56D+20Npix, raster bwd 168P+44D+20Npix as in SURVEY.md."""
+    return {
+        "preprocess": 92.0 * P,
+        "binning": 16.0 * D,
+        "render_fwd": 40.0 * D + 20.0 * npix,
+        "render_bwd": 44.0 * D + 20.0 * npix + 36.0 * P,
+        "preprocess_bwd": 132.0 * P,
+    }
+
+
+def cpu_baseline(N: int, B: int, budget_s: float = 12.0) -> dict:
+    """The reference's CPU path restated in oracle/lbs_oracle.py, same N and B
+    as the GPU workload, timed for ~budget_s seconds on all host cores."""
+    from oracle import lbs_oracle as O
+    from gaussianavatar_amd.synthetic import make_assets, make_frames
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    assets = make_assets(num_points=min(N, 64 * 64 * 3 // 4), uv_size=64)        # skeleton, poses, camera
+    frames = make_frames(assets, B, 1024, 1024)
+    J = assets["joints_rest"]
+    parents = torch.tensor(assets["parents"], dtype=torch.long)
+    inv = torch.linalg.inv(assets["cano_joint_mat"]).expand(B, -1, -1, -1)
+    pts = (torch.randn(1, N, 3, generator=g) * 0.4).expand(B, -1, -1)
+    w = torch.rand(N, 24, generator=g) ** 8
+    w = (w / w.sum(1, keepdim=True))[None].expand(B, -1, -1).contiguous()
+    full_proj = torch.tensor(frames["camera"]["full_proj_transform"])
+    pose0, transl = frames["pose"][:B].clone(), frames["transl"][:B].clone()
+
+    def one():
+        pose = pose0.clone().requires_grad_(True)
+        res = (torch.zeros(B, N, 3)).requires_grad_(True)
+        O.cpu_baseline_step(pose, transl, J, parents, inv, pts, res, w, full_proj)
+
+    for _ in range(2):
+        one()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 400:
+            break
+    return {"value": n / el, "unit": "iters/s", "cores": cores, "kind": "port",
+            "sample": f"{n} fwd+bwd iterations of LBS joint transforms + skinning + projection + "
+                      f"L1-to-black (no rasterizer/net exists on the CPU side), B={B} frames, "
+                      f"N={N} points, {el:.1f} s wall; CPU: {_cpu_model()}"}
+
+
+def _cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--points", type=int, default=200_000)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--frames-per-gpu", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="do not bracket rasterizer kernels with HIP events in the timed region")
+    args = ap.parse_args()
+
+    from gaussianavatar_amd import parallel
+    rank, world, local = parallel.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from gaussianavatar_amd import rasterizer
+    from gaussianavatar_amd.avatar_model import AvatarModel, collate_frames, default_params
+    from gaussianavatar_amd.losses import l1_loss_w, ssim
+
+    torch.manual_seed(0)      # identical init on every rank (replicas must start identical)
+    B = args.frames_per_gpu
+    mp, npar, op = default_params(batch_size=B, num_points=args.points, image_width=args.size,
+                                  image_height=args.size, num_frames=max(16, B * world))
+    model = AvatarModel(mp, npar, op, train=True, device=dev)
+    model.training_setup()
+    model.net.train()
+    ds = model.train_dataset
+    H = W = args.size
+    # target images: white background (as the reference composites) with a grey silhouette band
+    gt = torch.ones(B, 3, H, W, device=dev)
+    gt[:, :, H // 5: 4 * H // 5, 2 * W // 5: 3 * W // 5] = 0.6
+    nf = len(ds)
+    batches = []
+    for s in range(4):        # a few distinct batches; rank r takes frames r*B.. of each global batch
+        ids = [(s * world * B + rank * B + k) % nf for k in range(B)]
+        batches.append(collate_frames([ds[i] for i in ids], dev))
+    epoch, iteration = 1, 7   # iteration 7 < 1000: scale warm-up gives ~3.5 mm Gaussians at init
+
+    def step(i):
+        batch = batches[i % len(batches)]
+        image, points, offset_loss, geo_loss, scale_loss = model.train_stage1(batch, iteration)
+        Ll1 = (1.0 - op.lambda_dssim) * l1_loss_w(image, gt)
+        ssim_loss = op.lambda_dssim * (1.0 - ssim(image, gt))
+        loss = op.lambda_scale * scale_loss + op.lambda_rgl * offset_loss + Ll1 + ssim_loss + geo_loss
+        model.zero_grad(epoch)
+        loss.backward()
+        model.step(epoch)
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    rasterizer.check_overflow(block=True)
+    rasterizer.pair_statistics(reset=True)
+    if not args.no_kernel_events:
+        rasterizer.profile_enable(True)
+        rasterizer.profile_read(reset=True)
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    parallel.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    elapsed = parallel.max_over_ranks(elapsed, dev)
+    prof = rasterizer.profile_read(reset=True) if not args.no_kernel_events else {}
+    rasterizer.profile_enable(False)
+    ncalls, mean_pairs = rasterizer.pair_statistics(reset=True)
+    final_loss = float(loss)
+
+    if rank != 0:
+        return
+    N = model.query_points.shape[1]
+    value = world * args.steps / elapsed
+    out = {
+        "metric": "train iters/s (fwd+bwd), 200k Gaussians @1024^2, 1/2/4/8 MI355X",
+        "value": value, "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"stage-1 train iteration (LBS + feature net + skinning + Gaussian rasterizer "
+                               f"fwd+bwd + L1/DSSIM + Adam), {N} Gaussians, {W}x{H}, {B} frames per GPU "
+                               f"(BASELINE.json configs[2]); synthetic SMPL-shaped body, random-init net",
+                   "gaussians": N, "image": [H, W], "frames_per_gpu": B, "global_batch": B * world,
+                   "parallelism": f"frame-sharded dp{world}, one all-reduce of [N,7] output grads",
+                   "mean_tile_pairs_per_frame": mean_pairs, "final_loss": final_loss},
+    }
+    if prof:
+        alg = algorithmic_bytes(N, mean_pairs, H * W)
+        kern = {}
+        for name, (ms, n) in prof.items():
+            if n:
+                kern[name] = {"launches": n, "avg_us": 1e3 * ms / n}
+        groups = {"preprocess": ["preprocess"], "binning": ["tile_scan", "scatter", "tile_sort"],
+                  "render_fwd": ["render_fwd"], "render_bwd": ["render_bwd"],
+                  "preprocess_bwd": ["preprocess_bwd"]}
+        table = {}
+        for gname, members in groups.items():
+            us = sum(kern[m]["avg_us"] for m in members if m in kern)
+            if us > 0:
+                gbs = alg[gname] / (us * 1e-6) / 1e9
+                table[gname] = {"avg_us": us, "algorithmic_bytes": alg[gname], "GBps": gbs,
+                                "frac_of_8TBps": gbs / HBM_PEAK_GBS}
+        dom = max(table, key=lambda k: table[k]["avg_us"])
+        out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": table[dom]["GBps"],
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": table[dom]["frac_of_8TBps"],
+                           "traffic": None, "avg_us": table[dom]["avg_us"],
+                           "algorithmic_bytes_per_launch": table[dom]["algorithmic_bytes"]}
+        fwd_us = sum(table[k]["avg_us"] for k in ("preprocess", "binning", "render_fwd") if k in table)
+        bwd_us = sum(table[k]["avg_us"] for k in ("render_bwd", "preprocess_bwd") if k in table)
+        out["kernels"] = {"per_kernel": kern, "per_stage": table,
+                          "raster_fwd_us": fwd_us, "raster_bwd_us": bwd_us,
+                          "raster_bwd_frac_of_8TBps": (alg["render_bwd"] + alg["preprocess_bwd"]) / (bwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS if bwd_us else None}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(N, B)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -7,6 +7,12 @@ from __future__ import annotations
 
 import ctypes
 import os
+
+# torch bundles its own HIP runtime (torch/lib/libamdhip64.so). It must be the FIRST HIP runtime
+# in the process so that the in-tree libraries bind to the same one (same devices, streams and
+# allocations as the tensors they are handed); loading /opt/rocm's copy first gives the process
+# two runtimes and "no ROCm-capable device is detected".
+import torch  # noqa: F401  (import order matters, see above)
 from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -50,7 +56,8 @@ _gsr = None
 _galbs = None
 
 GSR_SYMBOLS = ["gsr_workspace_bytes", "gsr_workspace_layout", "gsr_forward", "gsr_backward",
-               "gsr_mark_visible", "gsr_read_status", "gsr_last_error", "gsr_abi_version"]
+               "gsr_mark_visible", "gsr_read_status", "gsr_last_error", "gsr_abi_version",
+               "gsr_profile_enable", "gsr_profile_read", "gsr_profile_kernel_name"]
 GALBS_SYMBOLS = ["galbs_joint_saved_floats", "galbs_joint_transforms_fwd",
                  "galbs_joint_transforms_bwd", "galbs_skin_fwd", "galbs_skin_bwd",
                  "galbs_last_error", "galbs_abi_version"]
@@ -77,6 +84,12 @@ def gsr() -> ctypes.CDLL:
         lib.gsr_read_status.argtypes = [P, c_int32, c_int32, c_int32, c_int64, P, P]
         lib.gsr_last_error.restype = c_char_p
         lib.gsr_abi_version.restype = c_int
+        lib.gsr_profile_enable.restype = c_int
+        lib.gsr_profile_enable.argtypes = [c_int]
+        lib.gsr_profile_read.restype = c_int
+        lib.gsr_profile_read.argtypes = [P, P, c_int]
+        lib.gsr_profile_kernel_name.restype = c_char_p
+        lib.gsr_profile_kernel_name.argtypes = [c_int]
         if lib.gsr_abi_version() != 1:
             raise RuntimeError("libgsr_hip.so ABI version mismatch; rebuild")
         _gsr = lib

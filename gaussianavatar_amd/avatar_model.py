@@ -1,0 +1,359 @@
+"""`AvatarModel` — the orchestrator of the render-and-fit hot path with the method surface of
+/root/reference/model/avatar_model.py (so the reference's train.py / eval.py /
+render_novel_pose.py loops drive it unchanged):
+
+    AvatarModel(model_parms, net_parms, opt_parms, load_iteration=None, train=True)
+    training_setup() · zero_grad(epoch) · step(epoch)
+    train_stage1(batch, it) -> (image[B,3,H,W], full_pred[B,N,3], offset_loss, geo_loss, scale_loss)
+    train_stage2(batch, it) -> (image, full_pred, pose_loss, offset_loss)
+    render_free_stage1(batch, it) / render_free_stage2(batch, it) -> image[B,3,H,W]
+    save(it) · load(it) · stage_load(path) · stage2_load(epoch)      (same dict keys / file names)
+    getTrainDataloader() · getTestDataset() · getNovelposeDataset() · getNovelviewDataset()
+
+What is different underneath (all output-preserving):
+  * pose -> joint transforms -> `@ inv_mats` is ONE HIP launch (lbs.joint_transforms) and the two
+    skinning einsums are one fused HIP kernel (lbs.skin) — no [B,N,4,4] intermediate;
+  * the decoder runs once per iteration in stage 1 (its input is batch-invariant) and works
+    point-major; the valid-texel gather happens on that single copy;
+  * camera scalars stay python numbers (no .item() syncs), `uv_coord_map` carries no grad;
+  * data parallelism: frames are sharded over ranks; ONE RCCL all-reduce of the per-Gaussian
+    output gradients [N,7] per iteration keeps the replicas bit-identical (parallel.py).
+Disk assets (SMPL files, uv masks, lbs maps, datasets) are replaced by an `assets` dict
+(synthetic.make_assets) because none of them ship with the reference.
+"""
+from __future__ import annotations
+
+import os
+from types import SimpleNamespace
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import parallel
+from .lbs import SMPLBody, skin
+from .network import POP_no_unet, UnetNoCond5DS
+from .renderer import render_batch
+from .synthetic import make_assets, make_frames
+
+
+def default_params(**overrides):
+    """(model_parms, net_parms, opt_parms) with the reference's defaults
+    (/root/reference/arguments/__init__.py:55-142). Extra synthetic-only knobs: num_points,
+    num_frames, image_width, image_height."""
+    model = SimpleNamespace(
+        source_path="", model_path="./output/synthetic", project_path=os.getcwd(), stage1_out_path="",
+        save_epoch=30, train_stage=1, dataset_type="synthetic", smpl_gender="neutral", smpl_type="smpl",
+        no_mask=0, fixed_inp=0, train_mode=0, cam_static=1, white_background=True,
+        bullet_pose_list=[112, 217, 755], batch_size=2, query_posmap_size=512, inp_posmap_size=128,
+        num_points=200_000, num_frames=16, image_width=1024, image_height=1024)
+    net = SimpleNamespace(c_pose=64, c_geom=64, hsize=128, nf=32, up_mode="upconv", use_dropout=0,
+                          pos_encoding=0, num_emb_freqs=6, posemb_incl_input=0, geom_layer_type="conv",
+                          gaussian_kernel_size=5)
+    epochs = 200
+    opt = SimpleNamespace(epochs=epochs, lambda_dssim=0.2, lambda_scale=3e-2, lambda_lpips=0.2,
+                          lambda_pose=10, lambda_rgl=1e1, log_iter=2000, lpips_start_iter=30,
+                          pose_op_start_iter=1800, lr_net=3e-3, lr_geomfeat=5e-4,
+                          sched_milestones=[int(epochs / 3), int(epochs * 2 / 3)])
+    for k, v in overrides.items():
+        for ns in (model, net, opt):
+            if hasattr(ns, k):
+                setattr(ns, k, v)
+                break
+        else:
+            raise KeyError(k)
+    return model, net, opt
+
+
+class SyntheticFrames(torch.utils.data.Dataset):
+    """Dataset items with the keys of MonoDataset_train.__getitem__
+    (/root/reference/scene/dataset_mono.py:224-257). Camera scalars are python numbers."""
+
+    def __init__(self, frames: dict, stage: int, inp_posmap_size: int, test: bool = False):
+        self.frames, self.stage, self.test = frames, stage, test
+        cam = frames["camera"]
+        self.cam = {k: torch.tensor(cam[k]) for k in ("world_view_transform", "full_proj_transform", "camera_center")}
+        self.cam.update(FovX=cam["FovX"], FovY=cam["FovY"], width=cam["width"], height=cam["height"])
+        g = torch.Generator().manual_seed(1234)
+        self.inp = torch.randn(frames["pose"].shape[0], 3, inp_posmap_size, inp_posmap_size, generator=g) * 0.3
+        self.gt = None
+
+    def __len__(self):
+        return self.frames["pose"].shape[0]
+
+    def __getitem__(self, i):
+        item = dict(self.cam)
+        item["pose_idx"] = i
+        item["original_image"] = self.gt[i] if self.gt is not None else torch.ones(3, self.cam["height"], self.cam["width"])
+        if self.stage == 2:
+            item["inp_pos_map"] = self.inp[i]
+        if self.test:
+            item["pose_data"] = self.frames["pose"][i]
+            item["transl_data"] = self.frames["transl"][i]
+        item["rest_pose"] = self.frames["rest_pose"][i]
+        return item
+
+
+def collate_frames(items, device="cuda"):
+    """Collate to the batch dict the model consumes; tensors go to `device`, camera scalars stay
+    python lists (the reference's to_cuda turns them into 0-d CUDA tensors -> host syncs)."""
+    out = {}
+    for k in items[0]:
+        v0 = items[0][k]
+        if torch.is_tensor(v0):
+            out[k] = torch.stack([it[k] for it in items]).to(device, non_blocking=True)
+        elif k == "pose_idx":
+            out[k] = torch.tensor([it[k] for it in items], dtype=torch.long, device=device)
+        else:
+            out[k] = [it[k] for it in items]
+    return out
+
+
+class AvatarModel:
+    def __init__(self, model_parms, net_parms, opt_parms, load_iteration=None, train=True,
+                 assets: Optional[dict] = None, frames: Optional[dict] = None, device="cuda"):
+        self.model_parms, self.net_parms, self.opt_parms = model_parms, net_parms, opt_parms
+        self.model_path = model_parms.model_path
+        self.loaded_iter = None
+        self.train = train
+        self.train_mode = model_parms.train_mode
+        self.device = torch.device(device)
+        self.batch_size = model_parms.batch_size if train else 1
+        assert model_parms.smpl_type in ("smplx", "smpl")
+        S = model_parms.query_posmap_size
+        if assets is None:
+            assets = make_assets(getattr(model_parms, "num_points", 200_000), S, model_parms.smpl_type)
+        if frames is None:
+            frames = make_frames(assets, getattr(model_parms, "num_frames", 16),
+                                 getattr(model_parms, "image_width", 1024),
+                                 getattr(model_parms, "image_height", 1024))
+        self.assets, self.frames = assets, frames
+        dev = self.device
+        self.train_dataset = SyntheticFrames(frames, model_parms.train_stage, model_parms.inp_posmap_size)
+        joint_num = assets["num_joints"]
+        self.smpl_model = SMPLBody(assets["joints_rest"], assets["parents"]).to(dev).eval()
+        valid = assets["valid_idx"].reshape(-1)
+        self.valid_idx = valid.to(dev)
+        self.valid_index = torch.nonzero(valid, as_tuple=False).reshape(-1).to(dev)      # int64 [N]
+        self.uv_coord_map = assets["uv_coord_map"].to(dev)                               # [HW,2], no grad
+        query_map = assets["query_posmap"].reshape(-1, 3)
+        self.query_points = query_map[valid].to(dev).contiguous()[None].expand(self.batch_size, -1, -1)
+        N = self.query_points.shape[1]
+        # opacity and rotation are fixed (avatar_model.py:79-83)
+        self.fix_opacity = torch.ones((N, 1), device=dev)
+        rots = torch.zeros((N, 4), device=dev)
+        rots[:, 0] = 1
+        self.fix_rotation = rots
+        lbs = assets["lbs_map"].reshape(S * S, joint_num)
+        self.query_lbs = lbs[valid].to(dev).contiguous()[None].expand(self.batch_size, -1, -1)
+        self.inv_mats = torch.linalg.inv(assets["cano_joint_mat"]).to(dev).expand(self.batch_size, -1, -1, -1)
+        self.betas = assets["betas"][0][None].expand(self.batch_size, -1).to(dev)
+        self.pose = nn.Embedding(len(self.train_dataset), frames["pose"].shape[1],
+                                 _weight=frames["pose"].clone(), sparse=True).to(dev)
+        self.transl = nn.Embedding(len(self.train_dataset), 3, _weight=frames["transl"].clone(), sparse=True).to(dev)
+        self.optimizer_pose = torch.optim.SparseAdam(list(self.pose.parameters()) + list(self.transl.parameters()), 5.0e-3)
+        bg_color = [1, 1, 1] if model_parms.white_background else [0, 0, 0]
+        self.background = torch.tensor(bg_color, dtype=torch.float32, device=dev)
+        self.optimizer = None
+        self.scheduler = None
+        self.net_set(model_parms.train_stage)
+        from . import rasterizer
+        if self.device.type == "cuda":
+            rasterizer.reset_capacity_history()      # new model = new scene
+
+    # ------------------------------------------------------------------ construction
+    def net_set(self, mode):
+        assert mode in [0, 1, 2]
+        np_ = self.net_parms
+        self.net = POP_no_unet(c_geom=np_.c_geom, geom_layer_type=np_.geom_layer_type, nf=np_.nf,
+                               hsize=np_.hsize, up_mode=np_.up_mode, use_dropout=bool(np_.use_dropout),
+                               uv_feat_dim=2).to(self.device)
+        S_in = self.model_parms.inp_posmap_size
+        geo = torch.ones(1, np_.c_geom, S_in, S_in).normal_(mean=0.0, std=0.01).float().to(self.device)
+        self.geo_feature = nn.Parameter(geo.requires_grad_(True))
+        if self.model_parms.train_stage == 2:
+            self.pose_encoder = UnetNoCond5DS(input_nc=3, output_nc=np_.c_pose, nf=np_.nf,
+                                              up_mode=np_.up_mode, use_dropout=False).to(self.device)
+
+    def training_setup(self):
+        o = self.opt_parms
+        if self.model_parms.train_stage == 1:
+            groups = [{"params": self.net.parameters(), "lr": o.lr_net},
+                      {"params": self.geo_feature, "lr": o.lr_geomfeat}]
+        else:
+            groups = [{"params": self.net.parameters(), "lr": o.lr_net * 0.1},
+                      {"params": self.pose_encoder.parameters(), "lr": o.lr_net}]
+        self.optimizer = torch.optim.Adam(groups)
+        self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, o.sched_milestones, gamma=0.1)
+
+    # ------------------------------------------------------------------ checkpoints
+    def _ckpt_dir(self, iteration):
+        return os.path.join(self.model_path, "net/iteration_{}".format(iteration))
+
+    def save(self, iteration):
+        path = self._ckpt_dir(iteration)
+        os.makedirs(path, exist_ok=True)
+        state = {"net": self.net.state_dict(), "geo_feature": self.geo_feature,
+                 "pose": self.pose.state_dict(), "transl": self.transl.state_dict(),
+                 "optimizer": self.optimizer.state_dict(), "scheduler": self.scheduler.state_dict()}
+        if self.model_parms.train_stage == 1:
+            torch.save(state, os.path.join(path, "net.pth"))
+        else:
+            state["pose_encoder"] = self.pose_encoder.state_dict()
+            torch.save(state, os.path.join(path, "pose_encoder.pth"))
+
+    def load(self, iteration, test=False):
+        path = self._ckpt_dir(iteration)
+        saved = torch.load(os.path.join(path, "net.pth"), map_location=self.device, weights_only=False)
+        self.net.load_state_dict(saved["net"], strict=False)
+        if self.model_parms.train_stage == 1:
+            if not test:
+                self.pose.load_state_dict(saved["pose"], strict=False)
+                self.transl.load_state_dict(saved["transl"], strict=False)
+            self.geo_feature.data[...] = saved["geo_feature"].data[...]
+        if self.optimizer is not None:
+            self.optimizer.load_state_dict(saved["optimizer"])
+        if self.scheduler is not None:
+            self.scheduler.load_state_dict(saved["scheduler"])
+
+    def stage_load(self, ckpt_path):
+        saved = torch.load(os.path.join(ckpt_path, "net.pth"), map_location=self.device, weights_only=False)
+        self.net.load_state_dict(saved["net"], strict=False)
+        self.pose.load_state_dict(saved["pose"], strict=False)
+        self.transl.load_state_dict(saved["transl"], strict=False)
+        self.geo_feature.data[...] = saved["geo_feature"].data[...]
+
+    def stage2_load(self, epoch):
+        path = os.path.join(self.model_parms.project_path, self.model_path, "net/iteration_{}".format(epoch))
+        st = torch.load(os.path.join(path, "pose_encoder.pth"), map_location=self.device, weights_only=False)
+        self.net.load_state_dict(st["net"], strict=False)
+        self.pose.load_state_dict(st["pose"], strict=False)
+        self.transl.load_state_dict(st["transl"], strict=False)
+        self.geo_feature.data[...] = st["geo_feature"].data[...]
+        self.pose_encoder.load_state_dict(st["pose_encoder"], strict=False)
+
+    # ------------------------------------------------------------------ data
+    def getTrainDataloader(self):
+        return torch.utils.data.DataLoader(self.train_dataset, batch_size=self.batch_size, shuffle=True,
+                                           num_workers=0, drop_last=True,
+                                           collate_fn=lambda items: collate_frames(items, self.device))
+
+    def _free_dataset(self):
+        return SyntheticFrames(self.frames, self.model_parms.train_stage, self.model_parms.inp_posmap_size, test=True)
+
+    def getTestDataset(self):
+        self.test_dataset = self._free_dataset()
+        return self.test_dataset
+
+    def getNovelposeDataset(self):
+        self.novel_pose_dataset = self._free_dataset()
+        return self.novel_pose_dataset
+
+    def getNovelviewDataset(self):
+        self.novel_view_dataset = self._free_dataset()
+        return self.novel_view_dataset
+
+    # ------------------------------------------------------------------ optimisation
+    def _pose_opt_active(self, epoch):
+        return self.model_parms.train_stage == 1 and epoch > self.opt_parms.pose_op_start_iter
+
+    def zero_grad(self, epoch):
+        self.optimizer.zero_grad()
+        if self._pose_opt_active(epoch):
+            self.optimizer_pose.zero_grad()
+
+    def step(self, epoch):
+        if self.model_parms.train_stage == 2:
+            parallel.allreduce_param_grads(list(self.net.parameters()) + list(self.pose_encoder.parameters()))
+        self.optimizer.step()
+        self.scheduler.step()
+        if self._pose_opt_active(epoch):
+            parallel.allgather_sparse_grads([self.pose.weight, self.transl.weight])
+            self.optimizer_pose.step()
+
+    # ------------------------------------------------------------------ the hot path
+    def _body(self, pose, transl, rest_pose):
+        B = pose.shape[0]
+        inv = self.inv_mats[:B] if self.inv_mats.shape[0] >= B else self.inv_mats[:1].expand(B, -1, -1, -1)
+        if self.model_parms.smpl_type == "smplx":
+            return self.smpl_model.forward(
+                betas=self.betas, global_orient=pose[:, :3], transl=transl, body_pose=pose[:, 3:66],
+                jaw_pose=rest_pose[:, :3], leye_pose=rest_pose[:, 3:6], reye_pose=rest_pose[:, 6:9],
+                left_hand_pose=rest_pose[:, 9:54], right_hand_pose=rest_pose[:, 54:], inv_mats=inv)
+        return self.smpl_model.forward(betas=self.betas, global_orient=pose[:, :3], transl=transl,
+                                       body_pose=pose[:, 3:], inv_mats=inv)
+
+    def _decode(self, B, pose_featmap, iteration, warmup: bool):
+        """Net -> per-Gaussian residuals/scales/colours on the valid texels.
+        Returns (pred_res_all [b,HW,3] (x0.02), point_res [B,N,3], scales [B,N,3], colours [B,N,3])."""
+        S_in = self.model_parms.inp_posmap_size
+        geom = self.geo_feature.expand(B, -1, S_in, S_in)                 # broadcast view: dedup in stage 1
+        uv = self.uv_coord_map[None].expand(B, -1, -1)
+        res, scales, shs = self.net.forward_points(pose_featmap, geom, uv)
+        shared = res.shape[0] > 1 and res.stride(0) == 0
+        if shared:
+            res, scales, shs = res[:1], scales[:1], shs[:1]
+        res = res * 0.02
+        if warmup and iteration < 1000:
+            scales = scales * 1e-3 * iteration
+        # gather the valid texels on the single copy; one concatenated [b,N,7] tensor is the DP
+        # exchange point (parallel.exchange_output_grads is the identity on one rank)
+        packed = torch.cat([res, scales, shs], dim=2).index_select(1, self.valid_index)
+        if shared or self.model_parms.train_stage == 1:
+            packed = parallel.exchange_output_grads(packed)
+        if shared:
+            packed = packed.expand(B, -1, -1)
+        point_res, pscale, pshs = packed[..., 0:3], packed[..., 3:4], packed[..., 4:7]
+        return res, point_res, pscale.expand(-1, -1, 3), pshs
+
+    def _render_frames(self, batch_data, full_pred, colors, scales):
+        images = []
+        B = full_pred.shape[0]
+        for b in range(B):
+            images.append(render_batch(
+                points=full_pred[b], shs=None, colors_precomp=colors[b], rotations=self.fix_rotation,
+                scales=scales[b], opacity=self.fix_opacity,
+                FovX=batch_data["FovX"][b], FovY=batch_data["FovY"][b],
+                height=batch_data["height"][b], width=batch_data["width"][b], bg_color=self.background,
+                world_view_transform=batch_data["world_view_transform"][b],
+                full_proj_transform=batch_data["full_proj_transform"][b],
+                active_sh_degree=0, camera_center=batch_data["camera_center"][b]))
+        return torch.stack(images, dim=0)
+
+    def _forward(self, batch_data, iteration, pose, transl, pose_featmap, warmup):
+        B = pose.shape[0]
+        live = self._body(pose, transl, batch_data.get("rest_pose"))
+        res_all, point_res, scales, colors = self._decode(B, pose_featmap, iteration, warmup)
+        full_pred = skin(self.query_points[:B] if self.query_points.shape[0] >= B else self.query_points[:1].expand(B, -1, -1),
+                         point_res, self.query_lbs[0], live.cano2live)
+        image = self._render_frames(batch_data, full_pred, colors, scales)
+        return image, full_pred, res_all, scales
+
+    def train_stage1(self, batch_data, iteration):
+        idx = batch_data["pose_idx"]
+        image, full_pred, res_all, scales = self._forward(
+            batch_data, iteration, self.pose(idx), self.transl(idx), None, warmup=True)
+        offset_loss = torch.mean(res_all ** 2)
+        geo_loss = torch.mean(self.geo_feature ** 2)
+        scale_loss = torch.mean(scales)
+        return image, full_pred, offset_loss, geo_loss, scale_loss
+
+    def train_stage2(self, batch_data, iteration):
+        idx = batch_data["pose_idx"]
+        pose_featmap = self.pose_encoder(batch_data["inp_pos_map"])
+        image, full_pred, res_all, scales = self._forward(
+            batch_data, iteration, self.pose(idx), self.transl(idx), pose_featmap, warmup=False)
+        offset_loss = torch.mean(res_all ** 2)
+        pose_loss = torch.mean(pose_featmap ** 2)
+        return image, full_pred, pose_loss, offset_loss,
+
+    def render_free_stage1(self, batch_data, iteration):
+        image, _, _, _ = self._forward(batch_data, iteration, batch_data["pose_data"],
+                                       batch_data["transl_data"], None, warmup=True)
+        return image
+
+    def render_free_stage2(self, batch_data, iteration):
+        pose_featmap = self.pose_encoder(batch_data["inp_pos_map"])
+        image, _, _, _ = self._forward(batch_data, iteration, batch_data["pose_data"],
+                                       batch_data["transl_data"], pose_featmap, warmup=False)
+        return image

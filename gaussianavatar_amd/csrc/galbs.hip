@@ -1,0 +1,443 @@
+// galbs.hip — SMPL joint transforms and fused point skinning for gfx950 (include/galbs.h).
+//
+// Replaces on the hot path:
+//   batch_rodrigues + batch_rigid_transform + "+= transl" + "@ inv_mats"
+//       /root/reference/submodules/smplx/lbs.py:299-333,349-405,
+//       /root/reference/submodules/smplx/body_models.py:383, /root/reference/model/avatar_model.py:296
+//       (dozens of tiny torch kernels and a python loop over joints) -> ONE launch, one wave/frame
+//   the two skinning einsums /root/reference/model/avatar_model.py:311-314
+//       (materialise pt_mats [B,N,4,4]) -> one fused kernel, blend matrices kept in registers
+#include <cstdarg>
+#include <cstdio>
+
+#include <hip/hip_runtime.h>
+
+#include "galbs.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_hip(hipError_t e, const char* what) {
+  if (e == hipSuccess) return 0;
+  set_error("%s: %s", what, hipGetErrorString(e));
+  return 3;
+}
+
+constexpr int WAVE = 64;
+constexpr int SAVED_PER_JOINT = 21;   // R (9) + G (3x4 = 12)
+
+// ------------------------------------------------------------------ small 3x3 / 3x4 helpers
+struct Aff {   // 3x4 affine [R | t], row-major
+  float m[12];
+};
+
+__device__ __forceinline__ Aff compose(const Aff& a, const Aff& b) {   // a . b
+  Aff r;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      r.m[i * 4 + j] = a.m[i * 4 + 0] * b.m[0 * 4 + j] + a.m[i * 4 + 1] * b.m[1 * 4 + j] +
+                       a.m[i * 4 + 2] * b.m[2 * 4 + j];
+    r.m[i * 4 + 3] = a.m[i * 4 + 0] * b.m[3] + a.m[i * 4 + 1] * b.m[7] + a.m[i * 4 + 2] * b.m[11] +
+                     a.m[i * 4 + 3];
+  }
+  return r;
+}
+
+// R = I + sin(t) K + (1 - cos(t)) K^2, t = |v + 1e-8|, K = skew(v / t)   (lbs.py:299-333)
+__device__ __forceinline__ void rodrigues(const float v[3], float R[9]) {
+  const float ex = v[0] + 1e-8f, ey = v[1] + 1e-8f, ez = v[2] + 1e-8f;
+  const float t = sqrtf(ex * ex + ey * ey + ez * ez);
+  const float kx = v[0] / t, ky = v[1] / t, kz = v[2] / t;
+  const float s = sinf(t), c1 = 1.0f - cosf(t);
+  const float kk = kx * kx + ky * ky + kz * kz;
+  // K^2 = k k^T - (k.k) I
+  R[0] = 1.0f + c1 * (kx * kx - kk);
+  R[1] = -s * kz + c1 * kx * ky;
+  R[2] = s * ky + c1 * kx * kz;
+  R[3] = s * kz + c1 * kx * ky;
+  R[4] = 1.0f + c1 * (ky * ky - kk);
+  R[5] = -s * kx + c1 * ky * kz;
+  R[6] = -s * ky + c1 * kx * kz;
+  R[7] = s * kx + c1 * ky * kz;
+  R[8] = 1.0f + c1 * (kz * kz - kk);
+}
+
+// dL/dv from dL/dR for the map above.
+__device__ __forceinline__ void rodrigues_bwd(const float v[3], const float dR[9], float dv[3]) {
+  const float e[3] = {v[0] + 1e-8f, v[1] + 1e-8f, v[2] + 1e-8f};
+  const float t = sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+  const float k[3] = {v[0] / t, v[1] / t, v[2] / t};
+  const float s = sinf(t), c = cosf(t), c1 = 1.0f - c;
+  const float kk = k[0] * k[0] + k[1] * k[1] + k[2] * k[2];
+  const float K[9] = {0.f, -k[2], k[1], k[2], 0.f, -k[0], -k[1], k[0], 0.f};
+  float K2[9];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) K2[a * 3 + b] = k[a] * k[b] - (a == b ? kk : 0.f);
+  float dt = 0.f;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) dt += dR[q] * (c * K[q] + s * K2[q]);
+  const float tr = dR[0] + dR[4] + dR[8];
+  float dk[3];
+  dk[0] = s * (dR[7] - dR[5]);
+  dk[1] = s * (dR[2] - dR[6]);
+  dk[2] = s * (dR[3] - dR[1]);
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    float acc = -2.0f * k[m] * tr;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) acc += dR[m * 3 + b] * k[b] + dR[b * 3 + m] * k[b];
+    dk[m] += c1 * acc;
+  }
+  // k = v / t, t = |v + eps|
+  const float dkv = dk[0] * v[0] + dk[1] * v[1] + dk[2] * v[2];
+  const float dt_total = dt - dkv / (t * t);
+#pragma unroll
+  for (int m = 0; m < 3; ++m) dv[m] = dk[m] / t + dt_total * e[m] / t;
+}
+
+// ------------------------------------------------------------------ joint transforms
+__global__ void __launch_bounds__(WAVE)
+joint_fwd_kernel(int J, const float* __restrict__ pose, const float* __restrict__ transl,
+                 const float* __restrict__ joints_rest, const int32_t* __restrict__ parents,
+                 const float* __restrict__ inv_mats, int64_t inv_stride, float* __restrict__ A,
+                 float* __restrict__ cano2live, float* __restrict__ saved) {
+  __shared__ Aff s_local[GALBS_MAX_JOINTS];
+  __shared__ Aff s_glob[GALBS_MAX_JOINTS];
+  const int b = blockIdx.x;
+  const int j = threadIdx.x;
+  float R[9];
+  if (j < J) {
+    const float v[3] = {pose[(size_t)b * J * 3 + j * 3], pose[(size_t)b * J * 3 + j * 3 + 1],
+                        pose[(size_t)b * J * 3 + j * 3 + 2]};
+    rodrigues(v, R);
+    const int p = parents[j];
+    Aff L;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) L.m[r * 4 + c] = R[r * 3 + c];
+      L.m[r * 4 + 3] = joints_rest[j * 3 + r] - (j > 0 ? joints_rest[p * 3 + r] : 0.f);
+    }
+    s_local[j] = L;
+  }
+  __syncthreads();
+  if (j == 0) {   // the kinematic chain is inherently sequential (parents[i] < i)
+    s_glob[0] = s_local[0];
+    for (int i = 1; i < J; ++i) s_glob[i] = compose(s_glob[parents[i]], s_local[i]);
+  }
+  __syncthreads();
+  if (j < J) {
+    const Aff G = s_glob[j];
+    float* sv = saved + ((size_t)b * J + j) * SAVED_PER_JOINT;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) sv[q] = R[q];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) sv[9 + q] = G.m[q];
+    float a[16];
+    const float jx = joints_rest[j * 3], jy = joints_rest[j * 3 + 1], jz = joints_rest[j * 3 + 2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a[r * 4 + c] = G.m[r * 4 + c];
+      a[r * 4 + 3] = G.m[r * 4 + 3] - (G.m[r * 4] * jx + G.m[r * 4 + 1] * jy + G.m[r * 4 + 2] * jz);
+      if (transl) a[r * 4 + 3] += transl[b * 3 + r];
+    }
+    a[12] = 0.f; a[13] = 0.f; a[14] = 0.f; a[15] = 1.f;
+    float* Ao = A + ((size_t)b * J + j) * 16;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Ao[q] = a[q];
+    const float* inv = inv_mats + (size_t)b * inv_stride + (size_t)j * 16;
+    float* Mo = cano2live + ((size_t)b * J + j) * 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        Mo[r * 4 + c] = a[r * 4] * inv[c] + a[r * 4 + 1] * inv[4 + c] + a[r * 4 + 2] * inv[8 + c] +
+                        a[r * 4 + 3] * inv[12 + c];
+  }
+}
+
+__global__ void __launch_bounds__(WAVE)
+joint_bwd_kernel(int J, const float* __restrict__ pose, const float* __restrict__ joints_rest,
+                 const int32_t* __restrict__ parents, const float* __restrict__ inv_mats,
+                 int64_t inv_stride, const float* __restrict__ saved,
+                 const float* __restrict__ dM, const float* __restrict__ dA_in,
+                 float* __restrict__ dpose, float* __restrict__ dtransl) {
+  __shared__ Aff s_dG[GALBS_MAX_JOINTS];    // gradient w.r.t. global transforms
+  __shared__ float s_dRl[GALBS_MAX_JOINTS][9];
+  __shared__ float s_dt[GALBS_MAX_JOINTS][3];
+  const int b = blockIdx.x;
+  const int j = threadIdx.x;
+  if (j < J) {
+    float dA[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) dA[q] = dA_in ? dA_in[((size_t)b * J + j) * 16 + q] : 0.f;
+    if (dM) {
+      const float* g = dM + ((size_t)b * J + j) * 16;
+      const float* inv = inv_mats + (size_t)b * inv_stride + (size_t)j * 16;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          dA[r * 4 + c] += g[r * 4] * inv[c * 4] + g[r * 4 + 1] * inv[c * 4 + 1] +
+                           g[r * 4 + 2] * inv[c * 4 + 2] + g[r * 4 + 3] * inv[c * 4 + 3];
+    }
+    const float jx = joints_rest[j * 3], jy = joints_rest[j * 3 + 1], jz = joints_rest[j * 3 + 2];
+    Aff dG;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      dG.m[r * 4 + 0] = dA[r * 4 + 0] - dA[r * 4 + 3] * jx;
+      dG.m[r * 4 + 1] = dA[r * 4 + 1] - dA[r * 4 + 3] * jy;
+      dG.m[r * 4 + 2] = dA[r * 4 + 2] - dA[r * 4 + 3] * jz;
+      dG.m[r * 4 + 3] = dA[r * 4 + 3];
+      s_dt[j][r] = dA[r * 4 + 3];
+    }
+    s_dG[j] = dG;
+  }
+  __syncthreads();
+  if (j == 0) {   // reverse sweep over the tree
+    for (int i = J - 1; i >= 1; --i) {
+      const int p = parents[i];
+      const float* svp = saved + ((size_t)b * J + p) * SAVED_PER_JOINT + 9;   // G_p (3x4)
+      const float* svi = saved + ((size_t)b * J + i) * SAVED_PER_JOINT;       // R_i
+      const Aff dGi = s_dG[i];
+      float Lt[3];
+      for (int r = 0; r < 3; ++r) Lt[r] = joints_rest[i * 3 + r] - joints_rest[p * 3 + r];
+      // local rotation gradient: dR_i = G_p.R^T dG_i.R
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+          s_dRl[i][r * 3 + c] = svp[0 * 4 + r] * dGi.m[0 * 4 + c] + svp[1 * 4 + r] * dGi.m[1 * 4 + c] +
+                                svp[2 * 4 + r] * dGi.m[2 * 4 + c];
+      // parent: dG_p.R += dG_i.R R_i^T + dG_i.t (x) t_i ; dG_p.t += dG_i.t
+      Aff dGp = s_dG[p];
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c)
+          dGp.m[r * 4 + c] += dGi.m[r * 4 + 0] * svi[c * 3 + 0] + dGi.m[r * 4 + 1] * svi[c * 3 + 1] +
+                              dGi.m[r * 4 + 2] * svi[c * 3 + 2] + dGi.m[r * 4 + 3] * Lt[c];
+        dGp.m[r * 4 + 3] += dGi.m[r * 4 + 3];
+      }
+      s_dG[p] = dGp;
+    }
+    const Aff d0 = s_dG[0];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) s_dRl[0][r * 3 + c] = d0.m[r * 4 + c];
+    if (dtransl) {
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+      for (int i = 0; i < J; ++i) { t0 += s_dt[i][0]; t1 += s_dt[i][1]; t2 += s_dt[i][2]; }
+      dtransl[b * 3] = t0; dtransl[b * 3 + 1] = t1; dtransl[b * 3 + 2] = t2;
+    }
+  }
+  __syncthreads();
+  if (j < J && dpose) {
+    const float v[3] = {pose[(size_t)b * J * 3 + j * 3], pose[(size_t)b * J * 3 + j * 3 + 1],
+                        pose[(size_t)b * J * 3 + j * 3 + 2]};
+    float dR[9], dv[3];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) dR[q] = s_dRl[j][q];
+    rodrigues_bwd(v, dR, dv);
+#pragma unroll
+    for (int m = 0; m < 3; ++m) dpose[(size_t)b * J * 3 + j * 3 + m] = dv[m];
+  }
+}
+
+// ------------------------------------------------------------------ point skinning
+constexpr int SKIN_THREADS = 256;
+constexpr int SKIN_FB = 8;   // frames handled per block (blend matrices staged in LDS)
+
+template <bool BWD>
+__global__ void __launch_bounds__(SKIN_THREADS)
+skin_kernel(int B, int N, int J, const float* __restrict__ points, int64_t pts_stride,
+            const float* __restrict__ res, int64_t res_stride,
+            const float* __restrict__ weights, int64_t w_stride,
+            const float* __restrict__ mats, float* __restrict__ out,
+            const float* __restrict__ dout, float* __restrict__ dres, float* __restrict__ dmats) {
+  __shared__ float s_m[SKIN_FB][GALBS_MAX_JOINTS][12];
+  __shared__ float s_dm[BWD ? SKIN_FB : 1][BWD ? GALBS_MAX_JOINTS : 1][12];
+  const int tid = threadIdx.x;
+  const int lane = tid & (WAVE - 1);
+  const int b0 = blockIdx.y * SKIN_FB;
+  const int nb = min(SKIN_FB, B - b0);
+  for (int q = tid; q < nb * J * 12; q += SKIN_THREADS) {
+    const int f = q / (J * 12), rem = q % (J * 12), jj = rem / 12, e = rem % 12;
+    s_m[f][jj][e] = mats[((size_t)(b0 + f) * J + jj) * 16 + e];
+    if (BWD) s_dm[f][jj][e] = 0.f;
+  }
+  __syncthreads();
+  for (int n0 = blockIdx.x * SKIN_THREADS; n0 < N; n0 += gridDim.x * SKIN_THREADS) {
+    const int n = n0 + tid;
+    const bool valid = n < N;
+    for (int f = 0; f < nb; ++f) {
+      const int b = b0 + f;
+      const float* wrow = weights + (size_t)b * w_stride + (size_t)n * J;
+      float x[3] = {0.f, 0.f, 0.f};
+      if (valid) {
+        const float* p = points + (size_t)b * pts_stride + (size_t)n * 3;
+        x[0] = p[0]; x[1] = p[1]; x[2] = p[2];
+        if (res) {
+          const float* r = res + (size_t)b * res_stride + (size_t)n * 3;
+          x[0] += r[0]; x[1] += r[1]; x[2] += r[2];
+        }
+      }
+      float T[12];
+#pragma unroll
+      for (int e = 0; e < 12; ++e) T[e] = 0.f;
+      if (valid) {
+        for (int jj = 0; jj < J; ++jj) {
+          const float w = wrow[jj];
+#pragma unroll
+          for (int e = 0; e < 12; ++e) T[e] = fmaf(w, s_m[f][jj][e], T[e]);
+        }
+      }
+      if (!BWD) {
+        if (valid) {
+          float* o = out + ((size_t)b * N + n) * 3;
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+            o[r] = T[r * 4] * x[0] + T[r * 4 + 1] * x[1] + T[r * 4 + 2] * x[2] + T[r * 4 + 3];
+        }
+      } else {
+        float g[3] = {0.f, 0.f, 0.f};
+        if (valid) {
+          const float* gp = dout + ((size_t)b * N + n) * 3;
+          g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2];
+          if (dres) {
+            float* d = dres + ((size_t)b * N + n) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d[c] = T[c] * g[0] + T[4 + c] * g[1] + T[8 + c] * g[2];
+          }
+        }
+        if (dmats) {
+          // dL/dM_j = sum_n w_nj [g (x) x | g] ; wave-reduce per joint, skip joints that no
+          // lane of the wave is bound to (skinning weights are sparse)
+          float o12[12];
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            o12[r * 4] = g[r] * x[0]; o12[r * 4 + 1] = g[r] * x[1];
+            o12[r * 4 + 2] = g[r] * x[2]; o12[r * 4 + 3] = g[r];
+          }
+          for (int jj = 0; jj < J; ++jj) {
+            const float w = valid ? wrow[jj] : 0.f;
+            if (__ballot(w != 0.f) == 0ull) continue;
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {
+              float v = w * o12[e];
+#pragma unroll
+              for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);
+              if (lane == 0) atomicAdd(&s_dm[f][jj][e], v);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (BWD && dmats) {
+    __syncthreads();
+    for (int q = tid; q < nb * J * 12; q += SKIN_THREADS) {
+      const int f = q / (J * 12), rem = q % (J * 12), jj = rem / 12, e = rem % 12;
+      const float v = s_dm[f][jj][e];
+      if (v != 0.f) unsafeAtomicAdd(&dmats[((size_t)(b0 + f) * J + jj) * 16 + e], v);
+    }
+  }
+}
+
+int check_common(int B, int J) {
+  if (B <= 0 || J <= 0 || J > GALBS_MAX_JOINTS) {
+    set_error("bad sizes: B=%d J=%d (J <= %d)", B, J, GALBS_MAX_JOINTS);
+    return 1;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t galbs_joint_saved_floats(int32_t J) { return (size_t)J * SAVED_PER_JOINT; }
+
+int galbs_joint_transforms_fwd(int32_t B, int32_t J, const float* pose, const float* transl,
+                               const float* joints_rest, const int32_t* parents,
+                               const float* inv_mats, int64_t inv_batch_stride, float* A,
+                               float* cano2live, float* saved, void* stream) {
+  if (check_common(B, J)) return 1;
+  if (!pose || !joints_rest || !parents || !inv_mats || !A || !cano2live || !saved) {
+    set_error("galbs_joint_transforms_fwd: NULL argument");
+    return 1;
+  }
+  hipLaunchKernelGGL(joint_fwd_kernel, dim3(B), dim3(WAVE), 0, static_cast<hipStream_t>(stream), J,
+                     pose, transl, joints_rest, parents, inv_mats, inv_batch_stride, A, cano2live,
+                     saved);
+  return check_hip(hipGetLastError(), "joint_fwd_kernel");
+}
+
+int galbs_joint_transforms_bwd(int32_t B, int32_t J, const float* pose, const float* joints_rest,
+                               const int32_t* parents, const float* inv_mats,
+                               int64_t inv_batch_stride, const float* saved,
+                               const float* dL_dcano2live, const float* dL_dA, float* dL_dpose,
+                               float* dL_dtransl, void* stream) {
+  if (check_common(B, J)) return 1;
+  if (!pose || !joints_rest || !parents || !inv_mats || !saved || (!dL_dcano2live && !dL_dA)) {
+    set_error("galbs_joint_transforms_bwd: NULL argument");
+    return 1;
+  }
+  hipLaunchKernelGGL(joint_bwd_kernel, dim3(B), dim3(WAVE), 0, static_cast<hipStream_t>(stream), J,
+                     pose, joints_rest, parents, inv_mats, inv_batch_stride, saved, dL_dcano2live,
+                     dL_dA, dL_dpose, dL_dtransl);
+  return check_hip(hipGetLastError(), "joint_bwd_kernel");
+}
+
+static dim3 skin_grid(int B, int N) {
+  int gx = (N + SKIN_THREADS - 1) / SKIN_THREADS;
+  if (gx > 2048) gx = 2048;
+  if (gx < 1) gx = 1;
+  return dim3(gx, (B + SKIN_FB - 1) / SKIN_FB);
+}
+
+int galbs_skin_fwd(int32_t B, int32_t N, int32_t J, const float* points, int64_t pts_batch_stride,
+                   const float* res, int64_t res_batch_stride, const float* weights,
+                   int64_t w_batch_stride, const float* mats, float* out, void* stream) {
+  if (check_common(B, J) || N < 0) { if (N < 0) set_error("N < 0"); return 1; }
+  if (N == 0) return 0;
+  if (!points || !weights || !mats || !out) { set_error("galbs_skin_fwd: NULL argument"); return 1; }
+  hipLaunchKernelGGL(skin_kernel<false>, skin_grid(B, N), dim3(SKIN_THREADS), 0,
+                     static_cast<hipStream_t>(stream), B, N, J, points, pts_batch_stride, res,
+                     res_batch_stride, weights, w_batch_stride, mats, out, nullptr, nullptr, nullptr);
+  return check_hip(hipGetLastError(), "skin_kernel<fwd>");
+}
+
+int galbs_skin_bwd(int32_t B, int32_t N, int32_t J, const float* points, int64_t pts_batch_stride,
+                   const float* res, int64_t res_batch_stride, const float* weights,
+                   int64_t w_batch_stride, const float* mats, const float* dL_dout, float* dL_dres,
+                   float* dL_dmats, void* stream) {
+  if (check_common(B, J) || N < 0) { if (N < 0) set_error("N < 0"); return 1; }
+  if (!dL_dres && !dL_dmats) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dL_dmats) {
+    int rc = check_hip(hipMemsetAsync(dL_dmats, 0, (size_t)B * J * 16 * sizeof(float), s), "memset dmats");
+    if (rc) return rc;
+  }
+  if (N == 0) return 0;
+  if (!points || !weights || !mats || !dL_dout) { set_error("galbs_skin_bwd: NULL argument"); return 1; }
+  dim3 grid = skin_grid(B, N);
+  if (dL_dmats && grid.x > 512) grid.x = 512;   // fewer blocks -> fewer global atomics
+  hipLaunchKernelGGL(skin_kernel<true>, grid, dim3(SKIN_THREADS), 0, s, B, N, J, points,
+                     pts_batch_stride, res, res_batch_stride, weights, w_batch_stride, mats, nullptr,
+                     dL_dout, dL_dres, dL_dmats);
+  return check_hip(hipGetLastError(), "skin_kernel<bwd>");
+}
+
+const char* galbs_last_error(void) { return g_err; }
+int galbs_abi_version(void) { return GALBS_ABI_VERSION; }
+
+}  // extern "C"

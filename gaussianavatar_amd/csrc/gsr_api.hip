@@ -6,6 +6,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #include "gsr_common.h"
 
@@ -20,6 +22,35 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// ---------------------------------------------------------------- opt-in profiler
+namespace {
+struct ProfRec { hipEvent_t start, stop; int id; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;     // recorded, not yet read
+std::vector<ProfRec> g_prof_free;     // recycled event pairs
+double g_prof_ms[K_COUNT] = {0};
+int64_t g_prof_n[K_COUNT] = {0};
+}  // namespace
+
+ProfScope::ProfScope(KernelId id, hipStream_t s) : slot(-1), stream(s) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfRec r;
+  if (!g_prof_free.empty()) { r = g_prof_free.back(); g_prof_free.pop_back(); }
+  else { if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return; }
+  r.id = id;
+  hipEventRecord(r.start, s);
+  g_prof_recs.push_back(r);
+  slot = (int)g_prof_recs.size() - 1;
+}
+
+ProfScope::~ProfScope() {
+  if (slot < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (slot < (int)g_prof_recs.size()) hipEventRecord(g_prof_recs[slot].stop, stream);
 }
 
 static inline uint64_t align_up(uint64_t v) { return (v + 255u) & ~(uint64_t)255u; }
@@ -259,6 +290,38 @@ int gsr_read_status(const void* workspace, int32_t P, int32_t W, int32_t H, int6
                      "status copy");
   if (rc) return rc;
   return check_hip(hipStreamSynchronize(stream), "status sync");
+}
+
+int gsr_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = on != 0;
+  return GSR_OK;
+}
+
+int gsr_profile_read(double* ms_sum, int64_t* launches, int reset) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& r : g_prof_recs) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.stop) == hipSuccess &&
+        hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+      g_prof_ms[r.id] += ms;
+      g_prof_n[r.id] += 1;
+    }
+    g_prof_free.push_back(r);
+  }
+  g_prof_recs.clear();
+  for (int k = 0; k < K_COUNT; ++k) {
+    if (ms_sum) ms_sum[k] = g_prof_ms[k];
+    if (launches) launches[k] = g_prof_n[k];
+    if (reset) { g_prof_ms[k] = 0; g_prof_n[k] = 0; }
+  }
+  return GSR_OK;
+}
+
+const char* gsr_profile_kernel_name(int id) {
+  static const char* names[K_COUNT] = {"preprocess", "tile_scan", "scatter", "tile_sort",
+                                       "render_fwd", "render_bwd", "preprocess_bwd"};
+  return (id >= 0 && id < K_COUNT) ? names[id] : "";
 }
 
 const char* gsr_last_error(void) { return g_err; }

@@ -187,17 +187,26 @@ tile_sort_kernel(int64_t max_pairs, const uint32_t* __restrict__ tile_offset,
 }  // namespace
 
 hipError_t launch_binning(const Dims& d, const Workspace& ws, hipStream_t stream) {
-  hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, d.T, d.max_pairs,
+  {
+    ProfScope prof_(K_SCAN, stream);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, d.T, d.max_pairs,
                      ws.tile_count, ws.tile_offset, ws.tile_cursor, ws.status);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (d.P > 0) {
-    hipLaunchKernelGGL(scatter_kernel, dim3((d.P + 255) / 256), dim3(256), 0, stream, d.P, d.gx,
+    {
+      ProfScope prof_(K_SCATTER, stream);
+      hipLaunchKernelGGL(scatter_kernel, dim3((d.P + 255) / 256), dim3(256), 0, stream, d.P, d.gx,
                        d.max_pairs, ws.rect, ws.depth, ws.tile_cursor, ws.pair_key);
+    }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(d.T), dim3(SORT_THREADS), 0, stream, d.max_pairs,
+    {
+      ProfScope prof_(K_SORT, stream);
+      hipLaunchKernelGGL(tile_sort_kernel, dim3(d.T), dim3(SORT_THREADS), 0, stream, d.max_pairs,
                        ws.tile_offset, ws.pair_key, ws.pair_tmp, ws.point_list);
+    }
     e = hipGetLastError();
   }
   return e;

@@ -85,6 +85,16 @@ hipError_t launch_preprocess_bwd(const GsrSettings& s, const Dims& d, const floa
                                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors,
                                  float* dL_dopacity, float* dL_dscales, float* dL_drotations,
                                  float* dL_dcov3D, hipStream_t stream);
+// Opt-in per-kernel timing (gsr_profile_* in gsr.h).
+enum KernelId { K_PREPROCESS = 0, K_SCAN, K_SCATTER, K_SORT, K_RENDER_FWD, K_RENDER_BWD,
+                K_PREPROCESS_BWD, K_COUNT };
+struct ProfScope {
+  ProfScope(KernelId id, hipStream_t stream);
+  ~ProfScope();
+  int slot;
+  hipStream_t stream;
+};
+
 hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix,
                                uint8_t* out, hipStream_t stream);
 

@@ -344,10 +344,13 @@ hipError_t launch_preprocess(const GsrSettings& s, const Dims& d, const float* m
   if (d.P == 0) return hipSuccess;
   const int block = 256;
   const int grid = (d.P + block - 1) / block;
-  hipLaunchKernelGGL(preprocess_kernel, dim3(grid), dim3(block), 0, stream, d.P, d.W, d.H, d.gx,
+  {
+    ProfScope prof_(K_PREPROCESS, stream);
+    hipLaunchKernelGGL(preprocess_kernel, dim3(grid), dim3(block), 0, stream, d.P, d.W, d.H, d.gx,
                      d.gy, s.tanfovx, s.tanfovy, s.scale_modifier, s.viewmatrix, s.projmatrix,
                      means3D, colors_precomp, opacities, scales, rotations, cov3D_precomp, ws,
                      radii);
+  }
   return hipGetLastError();
 }
 
@@ -360,10 +363,13 @@ hipError_t launch_preprocess_bwd(const GsrSettings& s, const Dims& d, const floa
   if (d.P == 0) return hipSuccess;
   const int block = 256;
   const int grid = (d.P + block - 1) / block;
-  hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(grid), dim3(block), 0, stream, d.P, d.W, d.H,
+  {
+    ProfScope prof_(K_PREPROCESS_BWD, stream);
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(grid), dim3(block), 0, stream, d.P, d.W, d.H,
                      s.tanfovx, s.tanfovy, s.scale_modifier, s.viewmatrix, s.projmatrix,
                      means3D, scales, rotations, radii, ws, dL_dmeans3D, dL_dmeans2D,
                      dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D);
+  }
   return hipGetLastError();
 }
 

@@ -233,18 +233,24 @@ render_bwd_kernel(int W, int H, int gx, int64_t max_pairs,
 hipError_t launch_render_fwd(const GsrSettings& s, const Dims& d, const Workspace& ws,
                              float* out_color, hipStream_t stream) {
   if (d.T == 0) return hipSuccess;
-  hipLaunchKernelGGL(render_fwd_kernel, dim3(d.T), dim3(BATCH), 0, stream, d.W, d.H, d.gx,
+  {
+    ProfScope prof_(K_RENDER_FWD, stream);
+    hipLaunchKernelGGL(render_fwd_kernel, dim3(d.T), dim3(BATCH), 0, stream, d.W, d.H, d.gx,
                      d.max_pairs, ws.tile_offset, ws.point_list, ws.xy, ws.conic_opacity, ws.rgb,
                      s.bg, out_color, ws.final_T, ws.n_contrib);
+  }
   return hipGetLastError();
 }
 
 hipError_t launch_render_bwd(const GsrSettings& s, const Dims& d, const Workspace& ws,
                              const float* dL_dout, hipStream_t stream) {
   if (d.T == 0 || d.P == 0) return hipSuccess;
-  hipLaunchKernelGGL(render_bwd_kernel, dim3(d.T), dim3(BATCH), 0, stream, d.W, d.H, d.gx,
+  {
+    ProfScope prof_(K_RENDER_BWD, stream);
+    hipLaunchKernelGGL(render_bwd_kernel, dim3(d.T), dim3(BATCH), 0, stream, d.W, d.H, d.gx,
                      d.max_pairs, ws.tile_offset, ws.point_list, ws.xy, ws.conic_opacity, ws.rgb,
                      s.bg, ws.final_T, ws.n_contrib, dL_dout, ws.grad_acc);
+  }
   return hipGetLastError();
 }
 

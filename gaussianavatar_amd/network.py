@@ -1,0 +1,231 @@
+"""Feature networks of the hot path on PyTorch-ROCm (rocBLAS/MIOpen do the GEMMs/convs).
+
+State-dict compatible re-implementation of the modules the reference instantiates for its
+default flags (`geom_layer_type='conv'`, /root/reference/arguments/__init__.py:111):
+
+  POP_no_unet      /root/reference/model/network.py:9-83
+  GeomConvLayers   /root/reference/model/modules.py:114-137   3x conv5x5, no bias, no activation
+  ShapeDecoder     /root/reference/model/modules.py:508-582   1x1-conv MLP + BN1d + softplus, 3 heads
+  UnetNoCond5DS    /root/reference/model/modules.py:185-232   stage-2 pose encoder
+  uv_to_grid       /root/reference/model/modules.py:745-754
+
+Parameter/buffer names and shapes are identical, so reference checkpoints load
+(`net.pth` keys, /root/reference/model/avatar_model.py:163-186). The computation is laid out
+differently:
+  * the decoder works point-major ([B*HW, C] row-major GEMMs instead of Conv1d over
+    [B, C, HW]) — the layout rocBLAS likes and the one the downstream gather/skin wants;
+  * `forward_points` returns [B, HW, C] directly (no permutes in the caller);
+  * a stage-1 call with batch-invariant input (geo_feature.expand, pose_featmap=None) is
+    evaluated ONCE and broadcast — BatchNorm batch statistics over B identical copies equal
+    those of one copy, so outputs and gradients are unchanged.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def uv_to_grid(uv_idx_map: torch.Tensor, resolution: int) -> torch.Tensor:
+    """[B, S*S, 2] in [0,1] -> grid_sample grid [B, S, S, 2] in [-1,1], with the reference's
+    (row, col) -> (x, y) transpose (modules.py:745-754)."""
+    bs = uv_idx_map.shape[0]
+    grid = uv_idx_map.reshape(bs, resolution, resolution, 2) * 2 - 1.0
+    return grid.transpose(1, 2)
+
+
+class GeomConvLayers(nn.Module):
+    def __init__(self, input_nc=16, hidden_nc=16, output_nc=16, use_relu=False):
+        super().__init__()
+        self.use_relu = use_relu
+        chans = [(input_nc, hidden_nc), (hidden_nc, hidden_nc), (hidden_nc, output_nc)]
+        for i, (ci, co) in enumerate(chans, start=1):
+            setattr(self, f"conv{i}", nn.Conv2d(ci, co, kernel_size=5, stride=1, padding=2, bias=False))
+
+    def forward(self, x):
+        for i in (1, 2, 3):
+            x = getattr(self, f"conv{i}")(x)
+            if self.use_relu and i < 3:
+                x = F.leaky_relu(x, 0.2)
+        return x
+
+
+class ShapeDecoder(nn.Module):
+    """Trunk of 5 layers with a DeepSDF-style skip into layer 5, then three 3-layer heads:
+    position residual (conv6/7/8), scale (conv6N/7N/8N, sigmoid), colour (conv6SH/7SH/8SH,
+    sigmoid). BatchNorm (batch statistics) + softplus after every hidden layer."""
+
+    HEADS = ("", "N", "SH")
+
+    def __init__(self, in_size, hsize=256, actv_fn="softplus"):
+        super().__init__()
+        self.hsize = hsize
+        self.in_size = in_size
+        h = hsize
+        dims = {"conv1": (in_size, h), "conv2": (h, h), "conv3": (h, h), "conv4": (h, h),
+                "conv5": (h + in_size, h)}
+        out_dims = {"": 3, "SH": 3, "N": 1}
+        for tag in ("", "SH", "N"):           # registration order of the reference
+            dims[f"conv6{tag}"] = (h, h)
+            dims[f"conv7{tag}"] = (h, h)
+            dims[f"conv8{tag}"] = (h, out_dims[tag])
+        for name in ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv8",
+                     "conv6SH", "conv7SH", "conv8SH", "conv6N", "conv7N", "conv8N"):
+            ci, co = dims[name]
+            setattr(self, name, nn.Conv1d(ci, co, 1))
+        for name in ("bn1", "bn2", "bn3", "bn4", "bn5", "bn6", "bn7", "bn6N", "bn7N", "bn6SH", "bn7SH"):
+            setattr(self, name, nn.BatchNorm1d(h))
+        self.use_relu = actv_fn == "relu"
+
+    def _layer(self, x, conv: str, bn: str):
+        c = getattr(self, conv)
+        y = F.linear(x, c.weight.squeeze(-1), c.bias)
+        b = getattr(self, bn)
+        y = b(y)                                   # [M, C]: statistics over all points
+        return F.relu(y) if self.use_relu else F.softplus(y)
+
+    def _out(self, x, conv: str):
+        c = getattr(self, conv)
+        return F.linear(x, c.weight.squeeze(-1), c.bias)
+
+    def forward_points(self, x):
+        """x [M, in_size] -> (residual [M,3], scale [M,1], colour [M,3])."""
+        x1 = self._layer(x, "conv1", "bn1")
+        x2 = self._layer(x1, "conv2", "bn2")
+        x3 = self._layer(x2, "conv3", "bn3")
+        x4 = self._layer(x3, "conv4", "bn4")
+        x5 = self._layer(torch.cat([x, x4], dim=1), "conv5", "bn5")
+        outs = []
+        for tag in self.HEADS:
+            h6 = self._layer(x5, f"conv6{tag}", f"bn6{tag}")
+            h7 = self._layer(h6, f"conv7{tag}", f"bn7{tag}")
+            outs.append(self._out(h7, f"conv8{tag}"))
+        return outs[0], torch.sigmoid(outs[1]), torch.sigmoid(outs[2])
+
+    def forward(self, x):
+        """Reference layout: x [B, C, L] -> ([B,3,L], [B,1,L], [B,3,L])."""
+        B, C, L = x.shape
+        r, s, c = self.forward_points(x.transpose(1, 2).reshape(B * L, C))
+        back = lambda t: t.reshape(B, L, -1).transpose(1, 2)
+        return back(r), back(s), back(c)
+
+
+class _Down(nn.Module):
+    """LeakyReLU(0.2) -> conv4x4/s2 -> BN(affine=False) (modules.py:62-78)."""
+
+    def __init__(self, ci, co, use_bn=True, use_relu=True):
+        super().__init__()
+        self.use_bn, self.use_relu = use_bn, use_relu
+        self.conv = nn.Conv2d(ci, co, kernel_size=4, stride=2, padding=1, bias=False)
+        if use_bn:
+            self.bn = nn.BatchNorm2d(co, affine=False)
+
+    def forward(self, x):
+        x = self.conv(x)
+        return self.bn(x) if self.use_bn else x
+
+
+class _Up(nn.Module):
+    """ReLU -> convT4x4/s2 -> BN(affine=False) -> cat skip (modules.py:81-111)."""
+
+    def __init__(self, ci, co, use_bn=True, use_bias=False, up_mode="upconv", use_dropout=False):
+        super().__init__()
+        self.use_bn, self.use_dropout = use_bn, use_dropout
+        if up_mode == "upconv":
+            self.up = nn.ConvTranspose2d(ci, co, kernel_size=4, stride=2, padding=1, bias=use_bias)
+        else:
+            self.up = nn.Sequential(nn.Upsample(mode="bilinear", scale_factor=2, align_corners=False),
+                                    nn.Conv2d(ci, co, kernel_size=3, padding=1, stride=1))
+        if use_bn:
+            self.bn = nn.BatchNorm2d(co, affine=False)
+        if use_dropout:
+            self.drop = nn.Dropout(0.5)
+
+    def forward(self, x, skip=None):
+        x = self.up(F.relu(x))
+        if self.use_bn:
+            x = self.bn(x)
+        if self.use_dropout:
+            x = self.drop(x)
+        return x if skip is None else torch.cat([x, skip], 1)
+
+
+class UnetNoCond5DS(nn.Module):
+    """5-down / 5-up UNet. NOTE the reference's Conv2DBlock applies LeakyReLU *in place* on its
+    input (modules.py:70), so every skip tensor d1..d4 that is later concatenated has already
+    been LeakyReLU'd by the next down block — reproduced explicitly here."""
+
+    def __init__(self, input_nc=3, output_nc=3, nf=64, up_mode="upconv", use_dropout=False,
+                 return_lowres=False, return_2branches=False):
+        super().__init__()
+        assert not return_2branches, "two-branch variant is unused by the reference's hot path"
+        self.conv1 = _Down(input_nc, nf, use_bn=False, use_relu=False)
+        self.conv2 = _Down(nf, 2 * nf)
+        self.conv3 = _Down(2 * nf, 4 * nf)
+        self.conv4 = _Down(4 * nf, 8 * nf)
+        self.conv5 = _Down(8 * nf, 8 * nf, use_bn=False)
+        self.upconv1 = _Up(8 * nf, 8 * nf, up_mode=up_mode)
+        self.upconv2 = _Up(16 * nf, 4 * nf, up_mode=up_mode, use_dropout=use_dropout)
+        self.upconv3 = _Up(8 * nf, 2 * nf, up_mode=up_mode, use_dropout=use_dropout)
+        self.upconv4 = _Up(4 * nf, nf, up_mode=up_mode)
+        self.upconv5 = _Up(2 * nf, output_nc, use_bn=False, use_bias=True, up_mode=up_mode)
+
+    def forward(self, x):
+        a1 = F.leaky_relu(self.conv1(x), 0.2)          # = d1 after the in-place activation
+        a2 = F.leaky_relu(self.conv2(a1), 0.2)
+        a3 = F.leaky_relu(self.conv3(a2), 0.2)
+        a4 = F.leaky_relu(self.conv4(a3), 0.2)
+        d5 = self.conv5(a4)
+        u1 = self.upconv1(d5, a4)
+        u2 = self.upconv2(u1, a3)
+        u3 = self.upconv3(u2, a2)
+        u4 = self.upconv4(u3, a1)
+        return self.upconv5(u4)
+
+
+class POP_no_unet(nn.Module):
+    def __init__(self, c_geom=64, geom_layer_type="conv", nf=64, hsize=256, up_mode="upconv",
+                 use_dropout=False, uv_feat_dim=2):
+        super().__init__()
+        self.geom_layer_type = geom_layer_type
+        if geom_layer_type == "conv":
+            self.geom_proc_layers = GeomConvLayers(c_geom, c_geom, c_geom, use_relu=False)
+        elif geom_layer_type == "unet":
+            self.geom_proc_layers = UnetNoCond5DS(c_geom, c_geom, nf, up_mode, use_dropout)
+        elif geom_layer_type is not None:
+            raise NotImplementedError(f"geom_layer_type={geom_layer_type!r} (the reference default is 'conv')")
+        self.decoder = ShapeDecoder(in_size=uv_feat_dim + c_geom, hsize=hsize, actv_fn="softplus")
+
+    @staticmethod
+    def _is_broadcast(t: torch.Tensor) -> bool:
+        return t.shape[0] > 1 and t.stride(0) == 0
+
+    def forward_points(self, pose_featmap, geom_featmap, uv_loc, dedup: bool = True):
+        """-> (residuals [B,HW,3], scales [B,HW,1], colours [B,HW,3]).
+
+        If `dedup` and the inputs are batch-invariant (stage 1: pose_featmap None, geom_featmap
+        and uv_loc expanded views of single maps) the net runs once and the result is expanded."""
+        B = geom_featmap.shape[0]
+        shared = (dedup and pose_featmap is None and self._is_broadcast(geom_featmap)
+                  and (uv_loc.shape[0] == 1 or self._is_broadcast(uv_loc)))
+        if shared:
+            geom_featmap, uv_loc = geom_featmap[:1], uv_loc[:1]
+        if self.geom_layer_type is not None:
+            geom_featmap = self.geom_proc_layers(geom_featmap)
+        pix = geom_featmap if pose_featmap is None else pose_featmap + geom_featmap
+        feat_res = geom_featmap.shape[2]
+        uv_res = int(uv_loc.shape[1] ** 0.5)
+        if feat_res != uv_res:
+            pix = F.grid_sample(pix, uv_to_grid(uv_loc, uv_res), mode="bilinear", align_corners=False)
+        b, C, H, W = pix.shape
+        x = torch.cat([pix.reshape(b, C, H * W).transpose(1, 2), uv_loc], dim=2)     # [b, HW, C+2]
+        r, s, c = self.decoder.forward_points(x.reshape(b * H * W, C + uv_loc.shape[-1]))
+        r, s, c = (t.reshape(b, H * W, -1) for t in (r, s, c))
+        if shared:
+            r, s, c = (t.expand(B, -1, -1) for t in (r, s, c))
+        return r, s, c
+
+    def forward(self, pose_featmap, geom_featmap, uv_loc):
+        """Reference signature/layout (network.py:39-83): -> ([B,3,HW], [B,1,HW], [B,3,HW])."""
+        r, s, c = self.forward_points(pose_featmap, geom_featmap, uv_loc, dedup=False)
+        return r.transpose(1, 2), s.transpose(1, 2), c.transpose(1, 2)

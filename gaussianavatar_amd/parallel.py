@@ -1,0 +1,144 @@
+"""Frame-sharded data parallelism: one process per GPU, `torch.distributed` (backend "nccl" is
+RCCL on ROCm; "gloo" on CPU for the logic tests).
+
+The reference is single-process (no distributed code anywhere); its only batch
+parallelism is a python loop over frames (/root/reference/model/avatar_model.py:332-365).
+Frames are independent through LBS -> skin -> rasterize -> image loss, so the path shards by
+frame. What couples the ranks in stage 1 is only the shared decoder output, hence:
+
+  stage 1  every rank evaluates the (batch-invariant) net once — identical outputs and BatchNorm
+           statistics everywhere; rank r renders its own frames; in backward the gradient of the
+           packed per-Gaussian outputs [N,7] (residual 3, scale 1, colour 3) is exchanged with
+           ONE all-reduce (5.6 MB at N=200k — latency-bound on xGMI, so a single flat message);
+           the net backward + Adam step then run redundantly and identically on every rank.
+           No parameter-gradient all-reduce, no SyncBN, replicas stay bit-identical.
+  stage 2  decoder inputs differ per frame; parameter gradients are averaged with one flat
+           all-reduce (net + pose encoder, ~19 MB). BatchNorm uses per-rank statistics
+           (documented deviation from a single-process global batch).
+  pose/transl embeddings (sparse, per frame): all-gather of the sparse rows when the pose
+           optimiser is active.
+
+Losses are means over the local frames; averaging the exchanged gradients over ranks makes the
+update equal to the reference's update on the global batch (equal frames per rank).
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+_group = None
+_enabled = False
+
+
+def init_from_env(backend: Optional[str] = None) -> tuple:
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun). Returns
+    (rank, world_size, local_rank). A single process needs no initialisation."""
+    global _enabled
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    _enabled = world > 1
+    return rank, world, local
+
+
+def enable(flag: bool = True, group=None) -> None:
+    global _enabled, _group
+    _enabled, _group = flag, group
+
+
+def world_size() -> int:
+    return dist.get_world_size(_group) if (_enabled and dist.is_initialized()) else 1
+
+
+def rank() -> int:
+    return dist.get_rank(_group) if (_enabled and dist.is_initialized()) else 0
+
+
+class _ExchangeGrad(torch.autograd.Function):
+    """Identity in forward; in backward the incoming gradient is averaged over all ranks with a
+    single all-reduce (the 'all-reduce of Gaussian-parameter grads' of BASELINE.json)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=_group)
+        return g / dist.get_world_size(_group)
+
+
+def exchange_output_grads(x: torch.Tensor) -> torch.Tensor:
+    if world_size() == 1:
+        return x
+    return _ExchangeGrad.apply(x)
+
+
+def allreduce_param_grads(params: List[torch.Tensor]) -> None:
+    """Average dense parameter gradients over ranks with one flat all-reduce."""
+    if world_size() == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=_group)
+    flat /= dist.get_world_size(_group)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+
+
+def allgather_sparse_grads(params: List[torch.Tensor]) -> None:
+    """Sparse embedding gradients (per-frame rows) -> every rank gets every rank's rows, scaled
+    by 1/world (the local losses are local means)."""
+    if world_size() == 1:
+        return
+    W = dist.get_world_size(_group)
+    for p in params:
+        if p.grad is None:
+            continue
+        g = p.grad.coalesce() if p.grad.is_sparse else p.grad.to_sparse().coalesce()
+        idx, val = g.indices(), g.values()
+        n = torch.tensor([idx.shape[1]], device=val.device)
+        counts = [torch.zeros_like(n) for _ in range(W)]
+        dist.all_gather(counts, n, group=_group)
+        m = int(max(int(c) for c in counts))
+        pad_i = torch.zeros(idx.shape[0], m, dtype=idx.dtype, device=idx.device)
+        pad_v = torch.zeros((m,) + val.shape[1:], dtype=val.dtype, device=val.device)
+        pad_i[:, :idx.shape[1]] = idx
+        pad_v[:idx.shape[1]] = val
+        all_i = [torch.zeros_like(pad_i) for _ in range(W)]
+        all_v = [torch.zeros_like(pad_v) for _ in range(W)]
+        dist.all_gather(all_i, pad_i, group=_group)
+        dist.all_gather(all_v, pad_v, group=_group)
+        ii = torch.cat([all_i[r][:, :int(counts[r])] for r in range(W)], dim=1)
+        vv = torch.cat([all_v[r][:int(counts[r])] for r in range(W)], dim=0) / W
+        p.grad = torch.sparse_coo_tensor(ii, vv, g.shape).coalesce()
+
+
+def barrier() -> None:
+    if world_size() > 1:
+        dist.barrier(group=_group)
+
+
+def max_over_ranks(value: float, device) -> float:
+    if world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_group)
+    return float(t[0])

@@ -15,6 +15,7 @@ later (see `_PairCapacity`).
 from __future__ import annotations
 
 import ctypes
+import time
 import warnings
 from typing import NamedTuple, Optional
 
@@ -47,73 +48,92 @@ class RasterizerOverflow(RuntimeError):
 
 
 class _PairCapacity:
-    """Sizing of the pair buffer without a host sync on the hot path.
+    """Sizing of the (tile,Gaussian) pair buffer without a host sync on the steady-state path.
 
-    capacity = max(pairs_per_gaussian * P, floor, 1.25 * largest count seen so far).
-    After every forward the 8 status words are copied asynchronously into pinned memory;
-    pending copies are polled (never waited for) on later calls, and a detected overflow
-    raises RasterizerOverflow (policy "raise", default) or warns (policy "warn").
-    Under torch.no_grad() (evaluation) and with settings.debug the check is synchronous and
-    an overflowing frame is transparently re-rendered with a larger buffer.
+    Per problem shape (P, W, H):
+      * the FIRST forward is checked synchronously and transparently re-rendered with a larger
+        buffer if it overflowed (one sync, once);
+      * afterwards capacity = max(pairs_per_gaussian * P, floor, 2 x the largest count seen),
+        the 8 status words are copied asynchronously into pinned memory after every forward and
+        polled (never waited for) on later calls — so the buffer tracks the scene with a 2x
+        margin and only a frame-to-frame doubling of the pair count can overflow it;
+      * an overflow that still happens is detected on a later poll and raises
+        RasterizerOverflow (policy "raise", default) or warns (policy "warn");
+      * forwards that nobody can differentiate (evaluation) and settings.debug are always
+        checked synchronously and re-rendered when needed.
     """
 
     def __init__(self):
         self.pairs_per_gaussian = 16
         self.floor = 1 << 16
-        self.seen = 0
+        self.seen = {}         # (P, W, H) -> largest pair count seen
+        self.stamp = {}        # (P, W, H) -> time of the last status seen
         self.policy = "raise"
-        self.pending = []      # (event, pinned status, capacity)
+        self.pending = []      # (event, pinned status, capacity, key)
         self.pool = []
         self.last_status = None
+        self.pairs_sum = 0       # running statistics over checked forward passes
+        self.calls = 0
 
-    def capacity(self, P: int) -> int:
-        cap = max(self.pairs_per_gaussian * P, self.floor, int(self.seen * 1.25) + 1024)
+    STALE_SECONDS = 2.0
+
+    def known(self, key) -> bool:
+        """History exists and is fresh (training calls arrive every few ms; after a pause the
+        next forward is re-checked synchronously, which costs one sync, once)."""
+        return key in self.seen and (time.monotonic() - self.stamp.get(key, 0.0)) < self.STALE_SECONDS
+
+    def reset(self):
+        self.poll(block=True)
+        self.seen.clear()
+        self.stamp.clear()
+
+    def capacity(self, key) -> int:
+        cap = max(self.pairs_per_gaussian * key[0], self.floor, 2 * self.seen.get(key, 0) + 1024)
         return min(cap, 0xfffffff0)
 
     def _pinned(self):
         return self.pool.pop() if self.pool else torch.empty(8, dtype=torch.int32).pin_memory()
 
-    def post(self, status_dev: torch.Tensor, cap: int):
+    def post(self, status_dev: torch.Tensor, cap: int, key):
         host = self._pinned()
         host.copy_(status_dev, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self.pending.append((ev, host, cap))
+        self.pending.append((ev, host, cap, key))
 
-    def _consume(self, host, cap):
+    def _account(self, host, key):
         needed, overflow = int(host[0]), int(host[1])
         self.last_status = host.tolist()
         self.pool.append(host)
-        self.seen = max(self.seen, needed)
-        if overflow:
-            msg = (f"rasterizer pair buffer overflow: a forward pass needed {needed} "
-                   f"(tile,Gaussian) pairs but had room for {cap}; that frame was rendered from "
-                   f"truncated tile lists. Capacity is now raised; to avoid this up front call "
-                   f"gaussianavatar_amd.rasterizer.set_pair_capacity(pairs_per_gaussian=...).")
-            if self.policy == "raise":
-                raise RasterizerOverflow(msg)
-            warnings.warn(msg)
+        self.seen[key] = max(self.seen.get(key, 0), needed)
+        self.stamp[key] = time.monotonic()
+        self.pairs_sum += needed
+        self.calls += 1
         return needed, overflow
 
     def poll(self, block: bool = False):
         """Check finished status copies; with block=True wait for all of them."""
         while self.pending:
-            ev, host, cap = self.pending[0]
+            ev, host, cap, key = self.pending[0]
             if not block and len(self.pending) <= 8 and not ev.query():
                 break
             ev.synchronize()
             self.pending.pop(0)
-            self._consume(host, cap)
+            needed, overflow = self._account(host, key)
+            if overflow:
+                msg = (f"rasterizer pair buffer overflow: a forward pass needed {needed} "
+                       f"(tile,Gaussian) pairs but had room for {cap}; that frame was rendered "
+                       f"from truncated tile lists. Capacity is now raised; to avoid this up front "
+                       f"call gaussianavatar_amd.rasterizer.set_pair_capacity(pairs_per_gaussian=...).")
+                if self.policy == "raise":
+                    raise RasterizerOverflow(msg)
+                warnings.warn(msg)
 
     def wait_last(self):
         """Synchronously resolve the newest pending copy WITHOUT raising; returns (needed, overflow)."""
-        ev, host, cap = self.pending.pop()
+        ev, host, cap, key = self.pending.pop()
         ev.synchronize()
-        needed, overflow = int(host[0]), int(host[1])
-        self.last_status = host.tolist()
-        self.pool.append(host)
-        self.seen = max(self.seen, needed)
-        return needed, overflow
+        return self._account(host, key)
 
 
 _capacity = _PairCapacity()
@@ -131,9 +151,39 @@ def set_pair_capacity(pairs_per_gaussian: Optional[int] = None, floor: Optional[
         _capacity.policy = on_overflow
 
 
+def reset_capacity_history() -> None:
+    """Forget the pair counts seen so far (call when the scene changes abruptly, e.g. a new
+    model): the next forward of every shape is checked synchronously again."""
+    _capacity.reset()
+
+
 def check_overflow(block: bool = True) -> None:
     """Resolve outstanding overflow checks (block=True waits for the device)."""
     _capacity.poll(block=block)
+
+
+def pair_statistics(reset: bool = False):
+    """(forward passes checked, mean (tile,Gaussian) pairs per pass) since the last reset."""
+    check_overflow(block=True)
+    n, s = _capacity.calls, _capacity.pairs_sum
+    if reset:
+        _capacity.calls, _capacity.pairs_sum = 0, 0
+    return n, (s / n if n else 0.0)
+
+
+def profile_enable(on: bool = True) -> None:
+    """Bracket every rasterizer kernel launch with HIP events on its stream (bench only)."""
+    _native.gsr_check(_native.gsr().gsr_profile_enable(1 if on else 0))
+
+
+def profile_read(reset: bool = True) -> dict:
+    """{kernel name: (total ms, launches)} measured by the in-library HIP events. Blocks until
+    the recorded events have completed."""
+    lib = _native.gsr()
+    ms = (ctypes.c_double * 7)()
+    n = (ctypes.c_int64 * 7)()
+    _native.gsr_check(lib.gsr_profile_read(ms, n, 1 if reset else 0))
+    return {lib.gsr_profile_kernel_name(i).decode(): (ms[i], int(n[i])) for i in range(7)}
 
 
 def last_status():
@@ -236,7 +286,7 @@ def rasterize_with_state(raster_settings, means3D, colors_precomp, opacities, sc
     rotations = _f32c(rotations, (P, 4)) if rotations is not None else None
     cov3D_precomp = _f32c(cov3D_precomp, (P, 6)) if cov3D_precomp is not None else None
     if max_pairs is None:
-        max_pairs = _capacity.capacity(P)
+        max_pairs = _capacity.capacity((P, int(raster_settings.image_width), int(raster_settings.image_height)))
     color, radii, workspace, status = _forward_once(
         raster_settings, means3D, colors_precomp, opacities, scales, rotations, cov3D_precomp, max_pairs)
     views = workspace_views(workspace, P, int(raster_settings.image_width),
@@ -269,18 +319,19 @@ class _RasterizeGaussians(torch.autograd.Function):
         cov3Ds_precomp = _f32c(cov3Ds_precomp, (P, 6)) if cov3Ds_precomp is not None else None
 
         _capacity.poll()
-        sync_check = bool(rs.debug) or bool(sync_check)
-        max_pairs = _capacity.capacity(P)
+        key = (P, int(rs.image_width), int(rs.image_height))
+        sync_check = bool(rs.debug) or bool(sync_check) or not _capacity.known(key)
+        max_pairs = _capacity.capacity(key)
         while True:
             color, radii, workspace, status = _forward_once(
                 rs, means3D, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, max_pairs)
-            _capacity.post(status, max_pairs)
+            _capacity.post(status, max_pairs, key)
             if not sync_check:
                 break
             needed, overflow = _capacity.wait_last()
             if not overflow:
                 break
-            max_pairs = min(int(needed * 1.25) + 1024, 0xfffffff0)
+            max_pairs = _capacity.capacity(key)
 
         ctx.raster_settings = rs
         ctx.max_pairs = max_pairs

@@ -22,7 +22,8 @@
  *     transposed matrix, i.e. element (row i, col j) of the column-vector-form
  *     matrix is m[j*4+i]  (/root/reference/scene/dataset_mono.py:248-255);
  *   - return value 0 = success; non-zero = error, text via gsr_last_error()
- *     (thread-local). The library has no other global state and is re-entrant.
+ *     (thread-local). Apart from the opt-in profiler (gsr_profile_*) the library has no
+ *     global state and is re-entrant.
  *
  * Plain C; no HIP or torch types appear in any signature.
  */
@@ -160,6 +161,19 @@ int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,
 /* Blocking helper: waits for `stream`, copies the 8 status words to status_host. */
 int gsr_read_status(const void* workspace, int32_t P, int32_t W, int32_t H,
                     int64_t max_pairs, int32_t* status_host, void* stream);
+
+/*
+ * Optional per-kernel timing (bench/profiling only; off by default, the one piece of
+ * process-global state in the library). When enabled every kernel launch is bracketed by
+ * hipEvents recorded on the launch stream; gsr_profile_read waits for them and returns, per
+ * kernel id, the summed GPU time in milliseconds and the number of launches since the last
+ * reset. Kernel ids: 0 preprocess, 1 tile_scan, 2 scatter, 3 tile_sort, 4 render_fwd,
+ * 5 render_bwd, 6 preprocess_bwd.
+ */
+#define GSR_NUM_KERNELS 7
+int gsr_profile_enable(int on);
+int gsr_profile_read(double* ms_sum, int64_t* launches, int reset);
+const char* gsr_profile_kernel_name(int id);
 
 /* Text of the last error raised on the calling thread ("" if none). */
 const char* gsr_last_error(void);

@@ -1,0 +1,207 @@
+"""Generates tests/golden/*.npz by RUNNING THE REFERENCE'S OWN PYTHON CODE in the build
+container (python oracle/make_golden.py). /root/reference does not exist on the GPU box, so
+the vectors are committed; this script is the provenance record.
+
+What is imported from /root/reference (read-only), unmodified:
+    submodules.smplx.lbs        lbs(), batch_rodrigues(), batch_rigid_transform()
+    model.network               POP_no_unet
+    model.modules               UnetNoCond5DS, ShapeDecoder, GeomConvLayers
+    utils.graphics_utils        geom_transform_points, getWorld2View2, getProjectionMatrix, focal2fov
+    utils.loss_utils            l1_loss_w, ssim
+    utils.general_utils         getIdxMap_torch
+Two lines that cannot be imported (model/avatar_model.py needs trimesh + CUDA at import) are
+restated verbatim in spirit: the skinning einsums of model/avatar_model.py:311-314.
+The rasterizer has no reference implementation in the tree (parity unpinned, see
+oracle/gsr_oracle.c); its golden vectors (raster_golden.npz) are produced by the C oracle and
+serve as regression vectors, not as pins.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+SMPL_PARENTS = [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21]
+
+
+def synthetic_body(V, Jn, parents, seed):
+    g = torch.Generator().manual_seed(seed)
+    v_template = torch.randn(V, 3, generator=g) * torch.tensor([0.3, 0.8, 0.15])
+    shapedirs = torch.randn(V, 3, 10, generator=g) * 0.01
+    posedirs = torch.randn((Jn - 1) * 9, V * 3, generator=g) * 0.001
+    Jr = torch.rand(Jn, V, generator=g)
+    Jr = Jr / Jr.sum(1, keepdim=True)
+    w = torch.rand(V, Jn, generator=g) ** 8
+    w = w / w.sum(1, keepdim=True)
+    return dict(v_template=v_template, shapedirs=shapedirs, posedirs=posedirs, J_regressor=Jr,
+                parents=torch.tensor(parents, dtype=torch.long), lbs_weights=w)
+
+
+def make_lbs():
+    from submodules.smplx.lbs import lbs, batch_rodrigues, batch_rigid_transform
+    parms = torch.load(os.path.join(REF, "assets/test_pose/smpl_parms.pth"))
+    out = {}
+    # SMPL-shaped (24 joints, the real kinematic tree) with poses shipped by the reference
+    body = synthetic_body(64, 24, SMPL_PARENTS, seed=0)
+    rows = [0, 37, 111, 250, 479]
+    pose = torch.cat([torch.zeros(1, 72), parms["body_pose"][rows]], 0)          # incl. T-pose
+    transl = torch.cat([torch.zeros(1, 3), parms["trans"][rows]], 0)
+    betas = parms["beta"].expand(pose.shape[0], -1).contiguous()
+    verts, joints, A = lbs(betas, pose, body["v_template"], body["shapedirs"], body["posedirs"],
+                           body["J_regressor"], body["parents"], body["lbs_weights"],
+                           pose2rot=True, return_affine_mat=True)
+    A = A.clone()
+    A[:, :, :3, 3] += transl.unsqueeze(dim=1)            # body_models.py:383
+    R = batch_rodrigues(pose.view(-1, 3))
+    out.update(smpl_pose=pose, smpl_transl=transl, smpl_betas=betas, smpl_A=A, smpl_rodrigues=R,
+               **{"smpl_" + k: v for k, v in body.items()})
+    # SMPL-X-shaped: 55 joints, random valid tree, random poses (config 5)
+    g = torch.Generator().manual_seed(1)
+    parents55 = [-1] + [int(torch.randint(0, i, (1,), generator=g)) for i in range(1, 55)]
+    body55 = synthetic_body(96, 55, parents55, seed=2)
+    pose55 = torch.randn(3, 165, generator=g) * 0.4
+    transl55 = torch.randn(3, 3, generator=g)
+    betas55 = torch.randn(1, 10, generator=g).expand(3, -1).contiguous()
+    _, _, A55 = lbs(betas55, pose55, body55["v_template"], body55["shapedirs"], body55["posedirs"],
+                    body55["J_regressor"], body55["parents"], body55["lbs_weights"],
+                    pose2rot=True, return_affine_mat=True)
+    A55 = A55.clone()
+    A55[:, :, :3, 3] += transl55.unsqueeze(dim=1)
+    out.update(smplx_pose=pose55, smplx_transl=transl55, smplx_betas=betas55, smplx_A=A55,
+               **{"smplx_" + k: v for k, v in body55.items()})
+    # chain only (batch_rigid_transform), arbitrary rotations
+    Rm = batch_rodrigues(torch.randn(2 * 24, 3, generator=g)).view(2, 24, 3, 3)
+    Jrest = torch.randn(2, 24, 3, generator=g)
+    posed, rel = batch_rigid_transform(Rm, Jrest, torch.tensor(SMPL_PARENTS))
+    out.update(chain_R=Rm, chain_J=Jrest, chain_posed=posed, chain_A=rel)
+    np.savez_compressed(os.path.join(OUT, "lbs_golden.npz"), **{k: v.numpy() for k, v in out.items()})
+    return out
+
+
+def make_skin(lbs_out):
+    g = torch.Generator().manual_seed(3)
+    B, N, Jn = 2, 700, 24
+    A = lbs_out["smpl_A"][1:3]
+    inv_mats = torch.linalg.inv(lbs_out["smpl_A"][0:1]).expand(B, -1, -1, -1)
+    cano2live = torch.matmul(A, inv_mats)                                          # avatar_model.py:296
+    query_points = (torch.randn(1, N, 3, generator=g) * 0.4).expand(B, -1, -1)
+    res = torch.randn(B, N, 3, generator=g) * 0.02
+    w = torch.rand(N, Jn, generator=g) ** 6
+    w[w < 0.05] = 0
+    w = (w / w.sum(1, keepdim=True).clamp(min=1e-8))[None].expand(B, -1, -1).contiguous()
+    cano_deform_point = res + query_points                                         # :309
+    pt_mats = torch.einsum('bnj,bjxy->bnxy', w, cano2live)                         # :311
+    full_pred = torch.einsum('bnxy,bny->bnx', pt_mats[..., :3, :3], cano_deform_point) + pt_mats[..., :3, 3]
+    np.savez_compressed(os.path.join(OUT, "skin_golden.npz"), A=A.numpy(), inv_mats=inv_mats.numpy(),
+                        cano2live=cano2live.numpy(), query_points=query_points.numpy(),
+                        res=res.numpy(), weights=w.numpy(), full_pred=full_pred.numpy())
+
+
+def make_net():
+    from model.network import POP_no_unet
+    from model.modules import UnetNoCond5DS
+    from utils.general_utils import getIdxMap_torch
+    torch.manual_seed(4)
+    net = POP_no_unet(c_geom=8, geom_layer_type='conv', nf=4, hsize=16, up_mode='upconv',
+                      use_dropout=False, uv_feat_dim=2)
+    net.train()
+    B, S_in, S_q = 2, 16, 32
+    geom = torch.randn(B, 8, S_in, S_in) * 0.5
+    posef = torch.randn(B, 8, S_in, S_in) * 0.5
+    uv = getIdxMap_torch(torch.rand(3, S_q, S_q))[None].expand(B, -1, -1).contiguous()
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    r1, s1, c1 = net(None, geom, uv)                 # stage-1 call (pose_featmap=None)
+    net.load_state_dict(sd0)                         # reset BN running stats
+    r2, s2, c2 = net(posef, geom, uv)                # stage-2 call
+    save = {"net." + k: v.numpy() for k, v in sd0.items()}
+    save.update(geom=geom.numpy(), posef=posef.numpy(), uv=uv.numpy(),
+                res1=r1.detach().numpy(), scales1=s1.detach().numpy(), shs1=c1.detach().numpy(),
+                res2=r2.detach().numpy(), scales2=s2.detach().numpy(), shs2=c2.detach().numpy())
+    unet = UnetNoCond5DS(input_nc=3, output_nc=8, nf=4, up_mode='upconv', use_dropout=False)
+    unet.train()
+    x = torch.randn(2, 3, 64, 64)
+    usd = {k: v.clone() for k, v in unet.state_dict().items()}
+    y = unet(x.clone())
+    save.update({"unet." + k: v.numpy() for k, v in usd.items()})
+    save.update(unet_x=x.numpy(), unet_y=y.detach().numpy())
+    np.savez_compressed(os.path.join(OUT, "net_golden.npz"), **save)
+
+
+def make_camera_loss():
+    from utils.graphics_utils import getWorld2View2, getProjectionMatrix, focal2fov, geom_transform_points
+    from utils.loss_utils import l1_loss_w, ssim
+    c = np.load(os.path.join(REF, "assets/test_pose/cam_parms.npz"))
+    K = c["intrinsic"].astype(np.float64)
+    E = c["extrinsic"]
+    out = {}
+    for size in (1024, 512, 256):
+        s = size / 1024.0
+        Ks = K.copy()
+        Ks[:2] *= s
+        fovx, fovy = focal2fov(Ks[0, 0], size), focal2fov(Ks[1, 1], size)
+        R, T = np.transpose(E[:3, :3]), E[:3, 3]
+        wvt = torch.tensor(getWorld2View2(R, T, np.array([0.0, 0.0, 0.0]), 1.0)).transpose(0, 1)
+        # python floats for K: the reference's float32-numpy K breaks under numpy>=2
+        Kn = np.array([[float(v) for v in row] for row in Ks])
+        proj = getProjectionMatrix(znear=0.01, zfar=100, fovX=fovx, fovY=fovy, K=Kn, h=size, w=size).transpose(0, 1)
+        full = wvt.unsqueeze(0).bmm(proj.unsqueeze(0)).squeeze(0)
+        out[f"wvt_{size}"] = wvt.numpy()
+        out[f"full_{size}"] = full.numpy()
+        out[f"center_{size}"] = wvt.inverse()[3, :3].numpy()
+        out[f"fov_{size}"] = np.array([fovx, fovy])
+    g = torch.Generator().manual_seed(5)
+    pts = torch.randn(50, 3, generator=g) * 0.5
+    out["proj_pts"] = pts.numpy()
+    out["proj_out"] = geom_transform_points(pts, torch.tensor(out["full_1024"])).numpy()
+    a = torch.rand(2, 3, 40, 56, generator=g)
+    b = (a + 0.1 * torch.randn(2, 3, 40, 56, generator=g)).clamp(0, 1)
+    out.update(loss_a=a.numpy(), loss_b=b.numpy(), l1=np.array(l1_loss_w(a, b).item()),
+               ssim=np.array(ssim(a, b).item()))
+    np.savez_compressed(os.path.join(OUT, "camera_loss_golden.npz"), **out)
+    # the poses the reference ships (first 16 of 480) + the camera, for bench/synthetic data
+    parms = torch.load(os.path.join(REF, "assets/test_pose/smpl_parms.pth"))
+    np.savez_compressed(os.path.join(OUT, "test_pose.npz"), intrinsic=c["intrinsic"], extrinsic=c["extrinsic"],
+                        beta=parms["beta"].numpy(), body_pose=parms["body_pose"][::30].numpy(),
+                        trans=parms["trans"][::30].numpy())
+
+
+def make_raster():
+    """Regression vectors from the C oracle (NOT a pin — see module docstring)."""
+    from oracle.gsr_oracle import RasterOracle
+    from tests.scenes import cam_kwargs, random_scene
+    O = RasterOracle()
+    save = {}
+    for name, kind in (("gen", "general"), ("ava", "avatar")):
+        sc = random_scene(64, 48, 32, seed=123, kind=kind, scale_med=0.06)
+        st = O.forward(sc["means3D"], sc["colors"], sc["opacities"], sc["scales"], sc["rotations"], **cam_kwargs(sc))
+        g = np.random.default_rng(9).normal(0, 1, (3, 32, 48)).astype(np.float32)
+        b = O.backward(st, g)
+        for k in ("means3D", "colors", "opacities", "scales", "rotations", "viewmatrix", "projmatrix", "bg"):
+            save[f"{name}_{k}"] = sc[k]
+        save[f"{name}_tan"] = np.array([sc["tanfovx"], sc["tanfovy"]])
+        for k in ("color", "radii", "rect", "tiles_touched", "ranges", "point_list", "n_contrib", "final_T"):
+            save[f"{name}_{k}"] = st[k]
+        save[f"{name}_g"] = g
+        for k in ("dmeans3D", "dcolors", "dopacity", "dscales", "drots", "dmeans2D"):
+            save[f"{name}_{k}"] = b[k]
+    np.savez_compressed(os.path.join(OUT, "raster_golden.npz"), **save)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    lo = make_lbs()
+    make_skin(lo)
+    make_net()
+    make_camera_loss()
+    make_raster()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))

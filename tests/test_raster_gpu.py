@@ -111,9 +111,11 @@ def test_overflow_is_flagged_and_recovered(raster_oracle):
     got = hip_forward_state(sc, max_pairs=ref["D"] // 2)
     assert got["status"][1] == 1 and got["status"][0] == ref["D"]
     # evaluation-mode call re-renders transparently with a larger buffer
-    old = (R._capacity.pairs_per_gaussian, R._capacity.floor, R._capacity.seen)
+    saved = (R._capacity.pairs_per_gaussian, R._capacity.floor, dict(R._capacity.seen))
+    key = (3000, 128, 128)
     try:
-        R._capacity.pairs_per_gaussian, R._capacity.floor, R._capacity.seen = 0, 64, 0
+        R._capacity.pairs_per_gaussian, R._capacity.floor = 0, 64
+        R._capacity.seen.pop(key, None)
         rs = settings_from_scene(sc)
         t = scene_tensors(sc)
         with torch.no_grad():
@@ -121,16 +123,31 @@ def test_overflow_is_flagged_and_recovered(raster_oracle):
                 means3D=t["means3D"], means2D=None, opacities=t["opacities"], colors_precomp=t["colors"],
                 scales=t["scales"], rotations=t["rotations"])
         assert np.abs(color.cpu().numpy() - ref["color"]).mean() <= IMG_L1_TOL
-        # training-mode call: deferred detection raises on a later poll
-        R._capacity.seen = 0
+        assert R._capacity.seen[key] == ref["D"]
+        # training mode, first call for an unknown shape: also exact (one-time synchronous check)
+        R._capacity.seen.pop(key, None)
         t = scene_tensors(sc, requires_grad=True)
+        color, radii = R.GaussianRasterizer(rs)(
+            means3D=t["means3D"], means2D=None, opacities=t["opacities"], colors_precomp=t["colors"],
+            scales=t["scales"], rotations=t["rotations"])
+        assert np.abs(color.detach().cpu().numpy() - ref["color"]).mean() <= IMG_L1_TOL
+        # steady state with a stale history (scene suddenly needs > 2x the pairs): detected on a later poll
+        R._capacity.seen[key] = 10
+        R._capacity.stamp[key] = __import__("time").monotonic()
         color, radii = R.GaussianRasterizer(rs)(
             means3D=t["means3D"], means2D=None, opacities=t["opacities"], colors_precomp=t["colors"],
             scales=t["scales"], rotations=t["rotations"])
         with pytest.raises(R.RasterizerOverflow):
             R.check_overflow(block=True)
+        # ... after which the capacity has adapted
+        color, radii = R.GaussianRasterizer(rs)(
+            means3D=t["means3D"], means2D=None, opacities=t["opacities"], colors_precomp=t["colors"],
+            scales=t["scales"], rotations=t["rotations"])
+        R.check_overflow(block=True)
+        assert np.abs(color.detach().cpu().numpy() - ref["color"]).mean() <= IMG_L1_TOL
     finally:
-        R._capacity.pairs_per_gaussian, R._capacity.floor, R._capacity.seen = old
+        R._capacity.pairs_per_gaussian, R._capacity.floor = saved[0], saved[1]
+        R._capacity.seen = saved[2]
         R._capacity.pending.clear()
 
 
