@@ -1,0 +1,83 @@
+"""CPU tests: the C-ABI libraries load and export every symbol the headers declare; layout
+queries work without a GPU; the drop-in package exposes the reference's names."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:gsr|galbs)_[a-z_0-9]+)\s*\(", src)))
+
+
+@pytest.mark.parametrize("header,loader", [("gsr.h", "gsr"), ("galbs.h", "galbs")])
+def test_every_declared_symbol_is_exported(header, loader):
+    from gaussianavatar_amd import _native
+    lib = getattr(_native, loader)()
+    names = _declared(header)
+    assert len(names) >= 7
+    for n in names:
+        assert hasattr(lib, n), n
+    listed = _native.GSR_SYMBOLS if loader == "gsr" else _native.GALBS_SYMBOLS
+    assert set(names) == set(listed), set(names) ^ set(listed)
+
+
+def test_layout_is_consistent_without_gpu():
+    from gaussianavatar_amd import _native
+    lib = _native.gsr()
+    L = _native.GsrLayout()
+    assert lib.gsr_workspace_layout(1000, 100, 70, 5000, ctypes.byref(L)) == 0
+    assert L.total_bytes == lib.gsr_workspace_bytes(1000, 100, 70, 5000)
+    offs = [getattr(L, f) for f in _native._LAYOUT_FIELDS[1:]]
+    assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
+    assert lib.gsr_workspace_bytes(-1, 100, 70, 5000) == 0
+    assert lib.gsr_workspace_layout(10, 0, 70, 5000, ctypes.byref(L)) != 0
+    assert b"invalid" in lib.gsr_last_error()
+    assert _native.galbs().galbs_joint_saved_floats(24) == 24 * 21
+
+
+def test_forward_rejects_bad_arguments_before_touching_the_device():
+    from gaussianavatar_amd import _native
+    lib = _native.gsr()
+    st = _native.GsrSettings(64, 64, 0.5, 0.5, 1.0, 0, 0, 0, None, None, None, None)
+    rc = lib.gsr_forward(ctypes.byref(st), 10, None, None, None, 0, None, None, None, None, None, 0, 100,
+                         None, None, None)
+    assert rc == 1 and b"device pointers" in lib.gsr_last_error()
+
+
+def test_dropin_package_surface():
+    import diff_gaussian_rasterization as d
+    fields = d.GaussianRasterizationSettings._fields
+    assert fields == ("image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier",
+                      "viewmatrix", "projmatrix", "sh_degree", "campos", "prefiltered", "debug")
+    assert callable(d.GaussianRasterizer) and hasattr(d.GaussianRasterizer, "markVisible")
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "gaussianavatar_amd")):
+        for f in files:
+            if f.endswith(".py") or f.endswith(".hip") or f.endswith(".h"):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+    assert "oracle" not in open(os.path.join(ROOT, "diff_gaussian_rasterization", "__init__.py")).read()
+
+
+def test_ops_fail_loudly_without_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from gaussianavatar_amd.lbs import skin
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        skin(torch.zeros(4, 3), None, torch.zeros(4, 24), torch.zeros(1, 24, 4, 4))
+    from gaussianavatar_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    rs = GaussianRasterizationSettings(16, 16, 0.5, 0.5, torch.ones(3), 1.0, torch.eye(4), torch.eye(4), 0,
+                                       torch.zeros(3), False, False)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        GaussianRasterizer(rs)(means3D=torch.zeros(4, 3), means2D=None, opacities=torch.ones(4, 1),
+                               colors_precomp=torch.zeros(4, 3), scales=torch.ones(4, 3),
+                               rotations=torch.zeros(4, 4))

@@ -1,0 +1,88 @@
+"""CPU tests of the N>1 path: world_size-2 gloo processes exercise the gradient exchange that
+RCCL performs on the GPUs (gaussianavatar_amd/parallel.py)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from gaussianavatar_amd import parallel
+    from gaussianavatar_amd.network import POP_no_unet
+    parallel.init_from_env(backend="gloo")
+    torch.manual_seed(0)                      # identical replicas
+    net = POP_no_unet(c_geom=8, hsize=16)
+    net.train()
+    geo = torch.randn(1, 8, 16, 16, requires_grad=True)
+    idx = torch.stack(torch.meshgrid(torch.arange(32), torch.arange(32), indexing="ij"), -1).reshape(-1, 2).float() / 31
+    B_local = 2
+    # per-frame "render losses": frame f weights the packed outputs with its own tensor
+    g = torch.Generator().manual_seed(100)
+    frame_w = torch.randn(world * B_local, 1024, 7, generator=g)
+    r, s, c = net.forward_points(None, geo.expand(B_local, -1, -1, -1), idx[None].expand(B_local, -1, -1))
+    packed = torch.cat([r[:1], s[:1], c[:1]], 2)
+    packed = parallel.exchange_output_grads(packed).expand(B_local, -1, -1)
+    mine = frame_w[rank * B_local:(rank + 1) * B_local]
+    image_loss = (packed * mine).sum(dim=(1, 2)).mean()          # mean over LOCAL frames
+    reg = (r[:1] ** 2).mean() + (geo ** 2).mean()
+    (image_loss + reg).backward()
+    grads = [geo.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+    # sparse embedding rows
+    emb = torch.nn.Embedding(8, 3, sparse=True)
+    with torch.no_grad():
+        emb.weight.copy_(torch.arange(24.0).view(8, 3))
+    ids = torch.tensor([rank * 2, rank * 2 + 1])
+    (emb(ids) * torch.tensor([[1.0, 2.0, 3.0]])).sum().backward()
+    parallel.allgather_sparse_grads([emb.weight])
+    out[rank] = dict(grads=grads, emb=emb.weight.grad.to_dense(), frame_w=frame_w)
+    parallel.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_exchange_equals_single_process_global_batch():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    r0, r1 = out[0], out[1]
+    # replicas got identical gradients
+    for a, b in zip(r0["grads"], r1["grads"]):
+        torch.testing.assert_close(a, b, rtol=0, atol=0)
+    # ... equal to one process evaluating the global batch of 4 frames
+    sys.path.insert(0, ROOT)
+    from gaussianavatar_amd.network import POP_no_unet
+    torch.manual_seed(0)
+    net = POP_no_unet(c_geom=8, hsize=16)
+    net.train()
+    geo = torch.randn(1, 8, 16, 16, requires_grad=True)
+    idx = torch.stack(torch.meshgrid(torch.arange(32), torch.arange(32), indexing="ij"), -1).reshape(-1, 2).float() / 31
+    Bg = 4
+    r, s, c = net.forward_points(None, geo.expand(Bg, -1, -1, -1), idx[None].expand(Bg, -1, -1))
+    packed = torch.cat([r, s, c], 2)
+    loss = (packed * r0["frame_w"]).sum(dim=(1, 2)).mean() + (r[:1] ** 2).mean() + (geo ** 2).mean()
+    loss.backward()
+    ref = [geo.grad] + [p.grad for p in net.parameters()]
+    gmax = max(float(t.abs().max()) for t in ref)
+    for a, b in zip(r0["grads"], ref):       # float32 summation-order noise only
+        assert float((a - b).abs().max()) <= 1e-4 * max(1.0, gmax)
+    # sparse rows: every rank sees all four touched rows, scaled by 1/world
+    e = r0["emb"]
+    torch.testing.assert_close(e, r1["emb"])
+    assert (e[:4] != 0).all() and (e[4:] == 0).all()
+    torch.testing.assert_close(e[0], torch.tensor([0.5, 1.0, 1.5]))
