@@ -76,31 +76,67 @@ scatter_kernel(int P, int gx, int64_t max_pairs, const int4* __restrict__ rect,
                uint64_t* __restrict__ pair_key) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
+  const int lane = threadIdx.x & (GSR_WAVE - 1);
   const int4 rc = rect[i];
-  if (rc.z <= rc.x || rc.w <= rc.y) return;
   const uint64_t key = ((uint64_t)__float_as_uint(depth[i]) << 32) | (uint32_t)i;
-  for (int y = rc.y; y < rc.w; ++y)
-    for (int x = rc.x; x < rc.z; ++x) {
-      const uint32_t pos = atomicAdd(&tile_cursor[y * gx + x], 1u);
-      if ((int64_t)pos < max_pairs) pair_key[pos] = key;
+  // wave-aggregated append: lanes that target the same tile share one returning atomic and
+  // write their keys to consecutive slots (see the histogram in K1)
+  int cx = rc.x, cy = rc.y;
+  while (true) {
+    const bool active = cy < rc.w && cx < rc.z;
+    unsigned long long remaining = __ballot(active);
+    if (remaining == 0ull) break;
+    const int tile = active ? cy * gx + cx : -1;
+    while (remaining) {
+      const int leader = __ffsll((long long)remaining) - 1;
+      const int ltile = __shfl(tile, leader);
+      const bool mine = active && tile == ltile;
+      const unsigned long long same = __ballot(mine);
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(&tile_cursor[ltile], (uint32_t)__popcll(same));
+      base = __shfl(base, leader);
+      if (mine) {
+        const uint32_t pos = base + (uint32_t)__builtin_amdgcn_mbcnt_hi(
+            (unsigned)(same >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)same, 0));
+        if ((int64_t)pos < max_pairs) pair_key[pos] = key;
+      }
+      remaining &= ~same;
     }
+    if (++cx >= rc.z) { cx = rc.x; ++cy; }
+  }
 }
 
 // ------------------------------------------------------------------ K4
 // Bitonic sort of n2 (power of two) keys held in LDS by SORT_THREADS threads.
+// Thread t owns compare-exchange pair t of a stage; the 64 threads of a wave own 64
+// consecutive pairs = one aligned block of 128 keys. Every stage with distance j <= 64 stays
+// inside such a block, so runs of those stages need no workgroup barrier (LDS operations of one
+// wave execute in order) — only the j >= 128 stages exchange data between waves.
+__device__ __forceinline__ void cmp_swap(uint64_t* s, int t, int j, int k) {
+  const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+  const int l = i | j;
+  const uint64_t a = s[i], b = s[l];
+  const bool up = (i & k) == 0;
+  if ((a > b) == up) { s[i] = b; s[l] = a; }
+}
+
 __device__ __forceinline__ void bitonic_sort_lds(uint64_t* s, int n2, int tid) {
+  const int half = n2 >> 1;
   for (int k = 2; k <= n2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < (n2 >> 1); t += SORT_THREADS) {
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int l = i | j;
-        const uint64_t a = s[i], b = s[l];
-        const bool up = (i & k) == 0;
-        if ((a > b) == up) { s[i] = b; s[l] = a; }
-      }
+    int j = k >> 1;
+    for (; j >= 2 * GSR_WAVE; j >>= 1) {          // cross-wave stages
+      for (int t = tid; t < half; t += SORT_THREADS) cmp_swap(s, t, j, k);
       __syncthreads();
     }
+    for (int t = tid; t < half; t += SORT_THREADS) {   // wave-local stages j = min(k/2,64)..1
+      for (int jj = j; jj > 0; jj >>= 1) {
+        cmp_swap(s, t, jj, k);
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (k >= 2 * GSR_WAVE) __syncthreads();       // next k starts with a cross-wave stage
   }
+  __syncthreads();
 }
 
 __device__ __forceinline__ int next_pow2(int n) {

@@ -162,9 +162,25 @@ preprocess_kernel(int P, int W, int H, int gx, int gy, float tanfovx, float tanf
   ws.conic_opacity[i] = co;
   ws.rect[i] = rc;
   ws.tiles_touched[i] = ntiles;
-  // per-tile histogram of pairs (consumed by K2/K3)
-  for (int y = rc.y; y < rc.w; ++y)
-    for (int x = rc.x; x < rc.z; ++x) atomicAdd(&ws.tile_count[y * gx + x], 1u);
+  // per-tile histogram of pairs (consumed by K2/K3). Neighbouring Gaussians (adjacent UV
+  // texels) mostly hit the same tiles, so the wave first groups its lanes by tile id and
+  // issues ONE atomic per distinct tile instead of one per lane.
+  int cx = rc.x, cy = rc.y;
+  while (true) {
+    const bool active = cy < rc.w && cx < rc.z;
+    unsigned long long remaining = __ballot(active);
+    if (remaining == 0ull) break;
+    const int tile = active ? cy * gx + cx : -1;
+    while (remaining) {
+      const int leader = __ffsll((long long)remaining) - 1;
+      const int ltile = __shfl(tile, leader);
+      const unsigned long long same = __ballot(active && tile == ltile);
+      if ((int)(threadIdx.x & (GSR_WAVE - 1)) == leader)
+        atomicAdd(&ws.tile_count[ltile], (uint32_t)__popcll(same));
+      remaining &= ~same;
+    }
+    if (++cx >= rc.z) { cx = rc.x; ++cy; }
+  }
 }
 
 // K7 — Appendix A.5. One thread per Gaussian; reads the screen-space gradient accumulators
