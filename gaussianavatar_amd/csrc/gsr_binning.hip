@@ -14,7 +14,7 @@ namespace gsr {
 namespace {
 
 constexpr int SCAN_THREADS = 1024;
-constexpr int SORT_THREADS = 256;
+constexpr int SORT_THREADS = 1024;
 constexpr int SORT_CAP = 4096;        // keys sorted in LDS at once (32 KiB)
 constexpr int MERGE_ITEMS = 8;        // outputs per thread per merge step
 

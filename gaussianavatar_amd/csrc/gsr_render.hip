@@ -200,20 +200,30 @@ render_fwd_kernel(int W, int H, int gx, int64_t max_pairs,
           power[u] = eval_power(co, c.x - fpx, c.y - fpy);
           alpha[u] = fminf(ALPHA_MAX, co.w * __expf(power[u]));
         }
+        // transmittance before each entry as a short multiply chain (an entry that does not
+        // contribute has a = 0); everything else hangs off it with selects
+        float a[ILP], Tpre[ILP + 1];
+        Tpre[0] = T;
 #pragma unroll
         for (int u = 0; u < ILP; ++u) {
-          const bool hit = !done & (power[u] <= 0.0f) & (alpha[u] >= ALPHA_MIN);
-          const float Tn = T * (1.0f - alpha[u]);
-          const bool stop = hit & (Tn < T_EPS);
-          const bool upd = hit & !stop;
-          const float w = upd ? alpha[u] * T : 0.f;
+          a[u] = ((power[u] <= 0.0f) & (alpha[u] >= ALPHA_MIN)) ? alpha[u] : 0.f;
+          Tpre[u + 1] = Tpre[u] * (1.0f - a[u]);
+        }
+        bool alive = !done;
+#pragma unroll
+        for (int u = 0; u < ILP; ++u) {
+          const bool contributes = a[u] > 0.f;
+          const bool stop = contributes & (Tpre[u + 1] < T_EPS);
+          const bool upd = alive & contributes & !stop;
+          const float w = upd ? a[u] * Tpre[u] : 0.f;
           C0 = fmaf(col[u].x, w, C0);
           C1 = fmaf(col[u].y, w, C1);
           C2 = fmaf(col[u].z, w, C2);
-          T = upd ? Tn : T;
+          T = upd ? Tpre[u + 1] : T;
           last = upd ? (uint32_t)kk[u] + 1u : last;
-          done = done | stop;
+          alive = alive & !stop;
         }
+        done = !alive;
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -336,7 +346,8 @@ render_bwd_kernel(int W, int H, int gx, int64_t max_pairs,
         const bool h = hit[u];
         const float a = h ? alpha[u] : 0.f;
         const float dx = c[u].x - fpx, dy = c[u].y - fpy;
-        T = T / (1.0f - a);
+        const float rcp_1ma = __builtin_amdgcn_rcpf(1.0f - a);   // a <= 0.99
+        T = T * rcp_1ma;
         const float w = a * T;
         const float n0 = last_alpha * lc0 + (1.0f - last_alpha) * acc0;
         const float n1 = last_alpha * lc1 + (1.0f - last_alpha) * acc1;
@@ -346,7 +357,7 @@ render_bwd_kernel(int W, int H, int gx, int64_t max_pairs,
         float dL_dalpha = (col[u].x - acc0) * g0 + (col[u].y - acc1) * g1 + (col[u].z - acc2) * g2;
         dL_dalpha *= T;
         last_alpha = h ? a : last_alpha;
-        dL_dalpha += (-Tf / (1.0f - a)) * bg_dot_g;
+        dL_dalpha += (-Tf * rcp_1ma) * bg_dot_g;
         dL_dalpha = h ? dL_dalpha : 0.f;
         const float dL_dG = co[u].w * dL_dalpha;
         const float gdx = G[u] * dx, gdy = G[u] * dy;
