@@ -120,6 +120,44 @@ def galbs() -> ctypes.CDLL:
     return _galbs
 
 
+_ganet = None
+GANET_SYMBOLS = ["ganet_linear_wgrad_workspace", "ganet_linear_wgrad", "ganet_bn_workspace",
+                 "ganet_bn_act_fwd", "ganet_bn_act_bwd", "ganet_ssim_fwd", "ganet_ssim_bwd",
+                 "ganet_last_error", "ganet_abi_version"]
+
+
+def ganet() -> ctypes.CDLL:
+    global _ganet
+    if _ganet is None:
+        lib = _load("libganet_hip.so")
+        P = c_void_p
+        lib.ganet_linear_wgrad_workspace.restype = c_size_t
+        lib.ganet_linear_wgrad_workspace.argtypes = [c_int64, c_int32, c_int32]
+        lib.ganet_linear_wgrad.restype = c_int
+        lib.ganet_linear_wgrad.argtypes = [c_int64, c_int32, c_int32, P, c_int64, P, c_int64, P, P, P, c_size_t, P]
+        lib.ganet_bn_workspace.restype = c_size_t
+        lib.ganet_bn_workspace.argtypes = [c_int64, c_int32]
+        lib.ganet_bn_act_fwd.restype = c_int
+        lib.ganet_bn_act_fwd.argtypes = [c_int64, c_int32, P, P, P, c_float, c_int32, P, P, P, P, c_size_t, P]
+        lib.ganet_bn_act_bwd.restype = c_int
+        lib.ganet_bn_act_bwd.argtypes = [c_int64, c_int32, P, P, P, P, P, c_int32, P, P, P, P, P, c_size_t, P]
+        lib.ganet_ssim_fwd.restype = c_int
+        lib.ganet_ssim_fwd.argtypes = [c_int32, c_int32, c_int32, P, P, P, P, P]
+        lib.ganet_ssim_bwd.restype = c_int
+        lib.ganet_ssim_bwd.argtypes = [c_int32, c_int32, c_int32, P, P, P, P, P, P]
+        lib.ganet_last_error.restype = c_char_p
+        lib.ganet_abi_version.restype = c_int
+        if lib.ganet_abi_version() != 1:
+            raise RuntimeError("libganet_hip.so ABI version mismatch; rebuild")
+        _ganet = lib
+    return _ganet
+
+
+def ganet_check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError("ganet: " + ganet().ganet_last_error().decode())
+
+
 def gsr_check(rc: int) -> None:
     if rc != 0:
         raise RuntimeError("gsr: " + gsr().gsr_last_error().decode())

@@ -5,6 +5,7 @@
 Outputs (git-ignored, but they travel to the GPU box with the repo snapshot):
     gaussianavatar_amd/_lib/libgsr_hip.so     rasterizer   (include/gsr.h)
     gaussianavatar_amd/_lib/libgalbs_hip.so   LBS kernels  (include/galbs.h)
+    gaussianavatar_amd/_lib/libganet_hip.so   fused net/loss kernels (include/ganet.h)
 """
 from __future__ import annotations
 
@@ -33,6 +34,11 @@ LIBS = {
     ],
     "libgalbs_hip.so": [
         ("galbs.hip", []),
+    ],
+    "libganet_hip.so": [
+        ("ganet_bn.hip", []),
+        ("ganet_wgrad.hip", []),
+        ("ganet_ssim.hip", []),
     ],
 }
 

@@ -25,6 +25,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import fused
+
 
 def uv_to_grid(uv_idx_map: torch.Tensor, resolution: int) -> torch.Tensor:
     """[B, S*S, 2] in [0,1] -> grid_sample grid [B, S, S, 2] in [-1,1], with the reference's
@@ -78,15 +80,16 @@ class ShapeDecoder(nn.Module):
         self.use_relu = actv_fn == "relu"
 
     def _layer(self, x, conv: str, bn: str):
+        # on a HIP device: vendor GEMM forward + MFMA weight-gradient kernel, and one fused
+        # BatchNorm(batch statistics)+softplus kernel pair (gaussianavatar_amd/fused.py);
+        # on the CPU the same calls reduce to F.linear / BatchNorm1d / softplus
         c = getattr(self, conv)
-        y = F.linear(x, c.weight.squeeze(-1), c.bias)
-        b = getattr(self, bn)
-        y = b(y)                                   # [M, C]: statistics over all points
-        return F.relu(y) if self.use_relu else F.softplus(y)
+        y = fused.linear(x, c.weight.squeeze(-1), c.bias)
+        return fused.batchnorm_act(y, getattr(self, bn), "relu" if self.use_relu else "softplus")
 
     def _out(self, x, conv: str):
         c = getattr(self, conv)
-        return F.linear(x, c.weight.squeeze(-1), c.bias)
+        return fused.linear(x, c.weight.squeeze(-1), c.bias)
 
     def forward_points(self, x):
         """x [M, in_size] -> (residual [M,3], scale [M,1], colour [M,3])."""
