@@ -38,15 +38,19 @@ Plan make_plan(int64_t M, int C) {
   return p;
 }
 
+// softplus(u) = log1p(exp(u)) (torch.nn.Softplus: beta 1, threshold 20). For tiny e = exp(u) the
+// series e - e^2/2 keeps full relative precision; elsewhere the hardware log of (1 + e) is within
+// 1e-7 absolute.
 __device__ __forceinline__ float act_fwd(float u, int act) {
   if (act == 0) return u;
-  return u > 20.0f ? u : log1pf(__expf(u));
+  const float e = __expf(u);
+  const float sp = e < 1e-3f ? e * (1.0f - 0.5f * e) : __logf(1.0f + e);
+  return u > 20.0f ? u : sp;
 }
 __device__ __forceinline__ float act_grad(float u, int act) {
   if (act == 0) return 1.0f;
-  if (u > 20.0f) return 1.0f;
-  const float z = __expf(u);
-  return z / (z + 1.0f);
+  const float z = __expf(fminf(u, 20.0f));
+  return u > 20.0f ? 1.0f : z * __builtin_amdgcn_rcpf(z + 1.0f);
 }
 
 // (count, mean, M2) merge
@@ -106,36 +110,52 @@ bn_stats_kernel(int64_t M, int C, const float* __restrict__ x, float* __restrict
   }
 }
 
-__global__ void __launch_bounds__(MAX_C)
+// one wave per channel: lanes stride over the per-block partials, then a butterfly of Chan merges
+__global__ void __launch_bounds__(64)
 bn_stats_final_kernel(int nblocks, int C, float eps, const float* __restrict__ part,
                       float* __restrict__ mean, float* __restrict__ rstd) {
-  const int c = threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x;
+  const int lane = threadIdx.x;
   float n = 0.f, mu = 0.f, m2 = 0.f;
-  for (int b = 0; b < nblocks; ++b) {
+  for (int b = lane; b < nblocks; b += 64) {
     const float* o = part + (size_t)b * (1 + 2 * C);
     chan(n, mu, m2, o[0], o[1 + c], o[1 + C + c]);
   }
-  mean[c] = mu;
-  rstd[c] = rsqrtf(m2 / n + eps);       // biased variance, as F.batch_norm in training mode
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float nb = __shfl_xor(n, off), mub = __shfl_xor(mu, off), m2b = __shfl_xor(m2, off);
+    chan(n, mu, m2, nb, mub, m2b);
+  }
+  if (lane == 0) {
+    mean[c] = mu;
+    rstd[c] = rsqrtf(m2 / n + eps);       // biased variance, as F.batch_norm in training mode
+  }
 }
 
+// Element-wise passes: a thread always lands on the same 4 channels (grid stride is a multiple
+// of C/4), so the per-channel constants are loaded once.
 __global__ void __launch_bounds__(WG)
 bn_apply_kernel(int64_t M, int C, const float* __restrict__ x, const float* __restrict__ gamma,
                 const float* __restrict__ beta, const float* __restrict__ mean,
                 const float* __restrict__ rstd, int act, float* __restrict__ y) {
   const int64_t total4 = M * C / 4;
   const int c4 = C / 4;
-  for (int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x; i < total4; i += (int64_t)gridDim.x * WG) {
-    const int c = (int)(i % c4) * 4;
-    const float4 v = reinterpret_cast<const float4*>(x)[i];
-    float in[4] = {v.x, v.y, v.z, v.w}, o[4];
+  const int64_t first = (int64_t)blockIdx.x * WG + threadIdx.x;
+  const int c = (int)(first % c4) * 4;
+  float a[4], b[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float a = gamma[c + k] * rstd[c + k];
-      o[k] = act_fwd(fmaf(a, in[k] - mean[c + k], beta[c + k]), act);
-    }
-    reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  for (int k = 0; k < 4; ++k) {
+    a[k] = gamma[c + k] * rstd[c + k];
+    b[k] = beta[c + k] - mean[c + k] * a[k];
+  }
+  for (int64_t i = first; i < total4; i += (int64_t)gridDim.x * WG) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    float4 o;
+    o.x = act_fwd(fmaf(a[0], v.x, b[0]), act);
+    o.y = act_fwd(fmaf(a[1], v.y, b[1]), act);
+    o.z = act_fwd(fmaf(a[2], v.z, b[2]), act);
+    o.w = act_fwd(fmaf(a[3], v.w, b[3]), act);
+    reinterpret_cast<float4*>(y)[i] = o;
   }
 }
 
@@ -185,20 +205,27 @@ bn_bwd_reduce_kernel(int64_t M, int C, const float* __restrict__ x, const float*
   }
 }
 
-__global__ void __launch_bounds__(MAX_C)
+__global__ void __launch_bounds__(64)
 bn_bwd_final_kernel(int nblocks, int C, const float* __restrict__ part, float* __restrict__ dgamma,
                     float* __restrict__ dbeta, float* __restrict__ sums) {
-  const int c = threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x;
+  const int lane = threadIdx.x;
   float a = 0.f, b = 0.f;
-  for (int k = 0; k < nblocks; ++k) {
+  for (int k = lane; k < nblocks; k += 64) {
     a += part[(size_t)k * 2 * C + c];
     b += part[(size_t)k * 2 * C + C + c];
   }
-  sums[c] = a;
-  sums[C + c] = b;
-  if (dbeta) dbeta[c] = a;
-  if (dgamma) dgamma[c] = b;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_xor(a, off);
+    b += __shfl_xor(b, off);
+  }
+  if (lane == 0) {
+    sums[c] = a;
+    sums[C + c] = b;
+    if (dbeta) dbeta[c] = a;
+    if (dgamma) dgamma[c] = b;
+  }
 }
 
 __global__ void __launch_bounds__(WG)
@@ -209,18 +236,26 @@ bn_bwd_apply_kernel(int64_t M, int C, const float* __restrict__ x, const float* 
   const int64_t total4 = M * C / 4;
   const int c4 = C / 4;
   const float invM = 1.0f / (float)M;
-  for (int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x; i < total4; i += (int64_t)gridDim.x * WG) {
-    const int c = (int)(i % c4) * 4;
+  const int64_t first = (int64_t)blockIdx.x * WG + threadIdx.x;
+  const int c = (int)(first % c4) * 4;
+  float mu[4], rs[4], ga[4], be[4], k0[4], k1[4], k2[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    mu[k] = mean[c + k]; rs[k] = rstd[c + k]; ga[k] = gamma[c + k]; be[k] = beta[c + k];
+    k0[k] = ga[k] * rs[k];                      // dx = k0 * (ds - k1 - xhat * k2)
+    k1[k] = sums[c + k] * invM;
+    k2[k] = sums[C + c + k] * invM;
+  }
+  for (int64_t i = first; i < total4; i += (int64_t)gridDim.x * WG) {
     const float4 v = reinterpret_cast<const float4*>(x)[i];
     const float4 g = reinterpret_cast<const float4*>(dy)[i];
     const float in[4] = {v.x, v.y, v.z, v.w}, gg[4] = {g.x, g.y, g.z, g.w};
     float o[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float rs = rstd[c + k], ga = gamma[c + k];
-      const float xh = (in[k] - mean[c + k]) * rs;
-      const float ds = gg[k] * act_grad(fmaf(ga, xh, beta[c + k]), act);
-      o[k] = ga * rs * (ds - sums[c + k] * invM - xh * sums[C + c + k] * invM);
+      const float xh = (in[k] - mu[k]) * rs[k];
+      const float ds = gg[k] * act_grad(fmaf(ga[k], xh, be[k]), act);
+      o[k] = k0[k] * (ds - k1[k] - xh * k2[k]);
     }
     reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
   }
@@ -281,7 +316,7 @@ int ganet_bn_act_fwd(int64_t M, int32_t C, const float* x, const float* gamma, c
   const Plan p = make_plan(M, C);
   float* part = static_cast<float*>(workspace);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(p.nblocks), dim3(WG), 0, stream, M, C, x, part, p);
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(1), dim3(MAX_C), 0, stream, p.nblocks, C, eps, part,
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(64), 0, stream, p.nblocks, C, eps, part,
                      mean, rstd);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(elementwise_grid(M * C / 4)), dim3(WG), 0, stream, M, C, x,
                      gamma, beta, mean, rstd, act, y);
@@ -305,7 +340,7 @@ int ganet_bn_act_bwd(int64_t M, int32_t C, const float* x, const float* gamma, c
   float* sums = part + (size_t)p.nblocks * (1 + 2 * (size_t)C);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(p.nblocks), dim3(WG), 0, stream, M, C, x, dy, gamma,
                      beta, mean, rstd, act, part, p);
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(1), dim3(MAX_C), 0, stream, p.nblocks, C, part, dgamma,
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(64), 0, stream, p.nblocks, C, part, dgamma,
                      dbeta, sums);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elementwise_grid(M * C / 4)), dim3(WG), 0, stream, M, C,
                      x, dy, gamma, beta, mean, rstd, sums, act, dx);

@@ -203,6 +203,38 @@ class POP_no_unet(nn.Module):
     def _is_broadcast(t: torch.Tensor) -> bool:
         return t.shape[0] > 1 and t.stride(0) == 0
 
+    def _separable_bilinear(self, uv_loc, feat_res: int, uv_res: int):
+        """If uv_loc[b, i*S+j] = (u_i, v_j) for every b (true for getIdxMap_torch's grid,
+        /root/reference/utils/general_utils.py:165-176), return the two [S, R] matrices of
+        bilinear weights that reproduce F.grid_sample(align_corners=False, zero padding) at those
+        locations; otherwise None. The (one-off, synchronising) check is cached per uv tensor."""
+        key = (uv_loc.data_ptr(), uv_loc._version, tuple(uv_loc.shape), tuple(uv_loc.stride()), feat_res)
+        cache = getattr(self, "_bilinear_cache", None)
+        if cache is not None and cache[0] == key:
+            return cache[1]
+        S, R = uv_res, feat_res
+        result = None
+        if uv_loc.shape[1] == S * S and uv_loc.shape[2] == 2:
+            g = uv_loc.detach().reshape(uv_loc.shape[0], S, S, 2)
+            u, v = g[0, :, 0, 0], g[0, 0, :, 1]
+            same = bool(((g[..., 0] == u[None, :, None]) & (g[..., 1] == v[None, None, :])).all())
+            if same:
+                def weights(coord):
+                    # grid_sample: x = 2*coord - 1 ; ix = ((x + 1) * R - 1) / 2 ; taps floor(ix), +1
+                    ix = (((coord * 2 - 1.0) + 1.0) * R - 1.0) / 2.0
+                    i0 = torch.floor(ix)
+                    w1 = ix - i0
+                    i0 = i0.long()
+                    Wm = torch.zeros(S, R + 2, dtype=coord.dtype, device=coord.device)
+                    rows = torch.arange(S, device=coord.device)
+                    Wm[rows, (i0 + 1).clamp(0, R + 1)] += (1.0 - w1) * ((i0 >= -1) & (i0 <= R)).to(coord.dtype)
+                    Wm[rows, (i0 + 2).clamp(0, R + 1)] += w1 * ((i0 + 1 >= -1) & (i0 + 1 <= R)).to(coord.dtype)
+                    return Wm[:, 1:R + 1].contiguous()      # columns -1 and R are the zero padding
+                # uv_to_grid transposes: output (i, j) samples input row <- v_i, column <- u_j
+                result = (weights(v), weights(u))
+        self._bilinear_cache = (key, result)
+        return result
+
     def forward_points(self, pose_featmap, geom_featmap, uv_loc, dedup: bool = True):
         """-> (residuals [B,HW,3], scales [B,HW,1], colours [B,HW,3]).
 
@@ -212,18 +244,36 @@ class POP_no_unet(nn.Module):
         shared = (dedup and pose_featmap is None and self._is_broadcast(geom_featmap)
                   and (uv_loc.shape[0] == 1 or self._is_broadcast(uv_loc)))
         if shared:
-            geom_featmap, uv_loc = geom_featmap[:1], uv_loc[:1]
+            # [0].unsqueeze(0) rather than [:1]: a size-1 batch dimension that keeps the expand's
+            # stride 0 makes MIOpen treat the tensor as non-packed and run its naive conv kernels
+            # (14-30 ms per conv instead of 50 us)
+            geom_featmap, uv_loc = geom_featmap[0].unsqueeze(0), uv_loc[0].unsqueeze(0)
         if self.geom_layer_type is not None:
             geom_featmap = self.geom_proc_layers(geom_featmap)
         pix = geom_featmap if pose_featmap is None else pose_featmap + geom_featmap
         feat_res = geom_featmap.shape[2]
         uv_res = int(uv_loc.shape[1] ** 0.5)
+        b, C = pix.shape[0], pix.shape[1]
+        HW = uv_loc.shape[1]
         if feat_res != uv_res:
-            pix = F.grid_sample(pix, uv_to_grid(uv_loc, uv_res), mode="bilinear", align_corners=False)
-        b, C, H, W = pix.shape
-        x = torch.cat([pix.reshape(b, C, H * W).transpose(1, 2), uv_loc], dim=2)     # [b, HW, C+2]
-        r, s, c = self.decoder.forward_points(x.reshape(b * H * W, C + uv_loc.shape[-1]))
-        r, s, c = (t.reshape(b, H * W, -1) for t in (r, s, c))
+            mats = self._separable_bilinear(uv_loc, feat_res, uv_res) if pix.is_cuda else None
+            if mats is not None:
+                # the query grid is separable (the reference's texel-centre grid): bilinear
+                # up-sampling = two small dense GEMMs that write the point-major layout directly
+                # (no scatter-add backward, no transposes) — same weights as grid_sample
+                Wr, Wc = mats
+                featP = pix.permute(0, 2, 3, 1)                               # [b, R, R, C]
+                t1 = torch.matmul(Wc, featP)                                  # [b, R(p), S(j), C]
+                pts = torch.matmul(Wr, t1.reshape(b, feat_res, uv_res * C))   # [b, S(i), S(j)*C]
+                pts = pts.reshape(b, HW, C)
+            else:
+                pix = F.grid_sample(pix, uv_to_grid(uv_loc, uv_res), mode="bilinear", align_corners=False)
+                pts = pix.reshape(b, C, HW).transpose(1, 2)
+        else:
+            pts = pix.reshape(b, C, HW).transpose(1, 2)
+        x = torch.cat([pts, uv_loc], dim=2)                                   # [b, HW, C+2]
+        r, s, c = self.decoder.forward_points(x.reshape(b * HW, C + uv_loc.shape[-1]))
+        r, s, c = (t.reshape(b, HW, -1) for t in (r, s, c))
         if shared:
             r, s, c = (t.expand(B, -1, -1) for t in (r, s, c))
         return r, s, c

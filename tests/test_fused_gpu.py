@@ -95,6 +95,52 @@ def test_fused_ssim_matches_reference_formulation(shape):
     assert float((ag.grad.cpu() - ac.grad).abs().max()) <= 2e-4 * scale
 
 
+@pytest.mark.parametrize("feat,S", [(16, 32), (32, 96), (128, 512)])
+def test_separable_bilinear_matmul_equals_grid_sample(feat, S):
+    """The two-GEMM up-sampling used on the GPU vs F.grid_sample at the reference's query grid."""
+    from gaussianavatar_amd.network import POP_no_unet, uv_to_grid
+    torch.manual_seed(3)
+    net = POP_no_unet(c_geom=8, hsize=16).cuda()
+    idx = torch.stack(torch.meshgrid(torch.arange(S), torch.arange(S), indexing="ij"), -1).reshape(-1, 2).float() / (S - 1)
+    uv = idx[None].cuda()
+    mats = net._separable_bilinear(uv, feat, S)
+    assert mats is not None
+    pix = torch.randn(1, 8, feat, feat, device="cuda")
+    ref = F.grid_sample(pix, uv_to_grid(uv, S), mode="bilinear", align_corners=False)
+    ref = ref.reshape(1, 8, S * S).transpose(1, 2)
+    Wr, Wc = mats
+    t1 = torch.matmul(Wc, pix.permute(0, 2, 3, 1))
+    pts = torch.matmul(Wr, t1.reshape(1, feat, S * 8)).reshape(1, S * S, 8)
+    torch.testing.assert_close(pts, ref, rtol=1e-4, atol=1e-5)
+    # a non-separable query set must fall back to grid_sample
+    uv2 = uv.clone()
+    uv2[0, 5, 0] += 0.01
+    assert net._separable_bilinear(uv2, feat, S) is None
+
+
+def test_whole_net_gpu_equals_cpu():
+    import copy
+    from gaussianavatar_amd.network import POP_no_unet
+    torch.manual_seed(0)
+    net = POP_no_unet(c_geom=8, hsize=16).train()
+    geo = torch.randn(1, 8, 16, 16, requires_grad=True)
+    S = 32
+    idx = torch.stack(torch.meshgrid(torch.arange(S), torch.arange(S), indexing="ij"), -1).reshape(-1, 2).float() / (S - 1)
+    net_g = copy.deepcopy(net).cuda()
+    geo_g = geo.detach().cuda().requires_grad_(True)
+    outs = net.forward_points(None, geo.expand(2, -1, -1, -1), idx[None].expand(2, -1, -1))
+    outs_g = net_g.forward_points(None, geo_g.expand(2, -1, -1, -1), idx.cuda()[None].expand(2, -1, -1))
+    w = [torch.randn_like(o) for o in outs]
+    sum((o * wi).sum() for o, wi in zip(outs, w)).backward()
+    sum((o * wi.cuda()).sum() for o, wi in zip(outs_g, w)).backward()
+    for a, b in zip(outs, outs_g):
+        torch.testing.assert_close(a, b.cpu(), rtol=1e-3, atol=1e-4)
+    gmax = max(float(p.grad.abs().max()) for p in net.parameters())
+    assert float((geo.grad - geo_g.grad.cpu()).abs().max()) <= 2e-3 * max(1.0, float(geo.grad.abs().max()))
+    for (n, p), (_, q) in zip(net.named_parameters(), net_g.named_parameters()):
+        assert float((p.grad - q.grad.cpu()).abs().max()) <= 2e-3 * max(1.0, gmax), n
+
+
 def test_decoder_gpu_fused_equals_cpu_torch():
     """The whole decoder (fused kernels on the GPU) against the same module on the CPU."""
     import copy
