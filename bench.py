@@ -198,7 +198,8 @@ def main():
                    "mean_tile_pairs_per_frame": mean_pairs, "final_loss": final_loss},
     }
     if prof:
-        alg = algorithmic_bytes(N, mean_pairs, H * W)
+        # one launch of every rasterizer kernel processes all B frames of the rank's batch
+        alg = {k: v * B for k, v in algorithmic_bytes(N, mean_pairs, H * W).items()}
         kern = {}
         for name, (ms, n) in prof.items():
             if n:
@@ -216,7 +217,7 @@ def main():
         dom = max(table, key=lambda k: table[k]["avg_us"])
         out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": table[dom]["GBps"],
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": table[dom]["frac_of_8TBps"],
-                           "traffic": None, "avg_us": table[dom]["avg_us"],
+                           "traffic": None, "avg_us": table[dom]["avg_us"], "frames_per_launch": B,
                            "algorithmic_bytes_per_launch": table[dom]["algorithmic_bytes"]}
         fwd_us = sum(table[k]["avg_us"] for k in ("preprocess", "binning", "render_fwd") if k in table)
         bwd_us = sum(table[k]["avg_us"] for k in ("render_bwd", "preprocess_bwd") if k in table)

@@ -33,6 +33,13 @@ class GsrSettings(ctypes.Structure):
     ]
 
 
+class GsrBatch(ctypes.Structure):
+    """struct GsrBatch (include/gsr.h): element strides between frames, 0 = shared."""
+    _fields_ = [("frames", c_int32), ("means3D_stride", c_int64), ("colors_stride", c_int64),
+                ("opacities_stride", c_int64), ("scales_stride", c_int64), ("rotations_stride", c_int64),
+                ("cov3D_stride", c_int64), ("viewmatrix_stride", c_int64), ("projmatrix_stride", c_int64)]
+
+
 _LAYOUT_FIELDS = ["total_bytes", "depth", "xy", "conic_opacity", "rgb", "cov3d", "rect",
                   "tiles_touched", "clamped", "tile_count", "tile_offset", "tile_cursor",
                   "pair_key", "point_list", "pair_tmp", "final_T", "n_contrib", "grad_acc", "status"]
@@ -57,7 +64,8 @@ _galbs = None
 
 GSR_SYMBOLS = ["gsr_workspace_bytes", "gsr_workspace_layout", "gsr_forward", "gsr_backward",
                "gsr_mark_visible", "gsr_read_status", "gsr_last_error", "gsr_abi_version",
-               "gsr_profile_enable", "gsr_profile_read", "gsr_profile_kernel_name"]
+               "gsr_profile_enable", "gsr_profile_read", "gsr_profile_kernel_name",
+               "gsr_forward_batch", "gsr_backward_batch"]
 GALBS_SYMBOLS = ["galbs_joint_saved_floats", "galbs_joint_transforms_fwd",
                  "galbs_joint_transforms_bwd", "galbs_skin_fwd", "galbs_skin_bwd",
                  "galbs_last_error", "galbs_abi_version"]
@@ -78,6 +86,13 @@ def gsr() -> ctypes.CDLL:
         lib.gsr_backward.restype = c_int
         lib.gsr_backward.argtypes = [ctypes.POINTER(GsrSettings), c_int32, P, P, P, c_int32, P, P, P, P,
                                      P, P, c_size_t, c_int64, P, P, P, P, P, P, P, P, P, P]
+        B_ = ctypes.POINTER(GsrBatch)
+        lib.gsr_forward_batch.restype = c_int
+        lib.gsr_forward_batch.argtypes = [ctypes.POINTER(GsrSettings), B_, c_int32, P, P, P, c_int32, P, P, P, P,
+                                          P, c_size_t, c_int64, P, P, P]
+        lib.gsr_backward_batch.restype = c_int
+        lib.gsr_backward_batch.argtypes = [ctypes.POINTER(GsrSettings), B_, c_int32, P, P, P, c_int32, P, P, P, P,
+                                           P, P, c_size_t, c_int64, P, P, P, P, P, P, P, P, P, P]
         lib.gsr_mark_visible.restype = c_int
         lib.gsr_mark_visible.argtypes = [c_int32, P, P, P, P, P]
         lib.gsr_read_status.restype = c_int

@@ -33,7 +33,7 @@ import torch.nn as nn
 from . import parallel
 from .lbs import SMPLBody, skin
 from .network import POP_no_unet, UnetNoCond5DS
-from .renderer import render_batch
+from .renderer import render_batch, render_frames  # noqa: F401
 from .synthetic import make_assets, make_frames
 
 
@@ -307,18 +307,16 @@ class AvatarModel:
         return res, point_res, pscale.expand(-1, -1, 3), pshs
 
     def _render_frames(self, batch_data, full_pred, colors, scales):
-        images = []
+        """The reference renders the frames one by one (avatar_model.py:332-365); here the whole
+        batch goes through one launch of every rasterizer kernel."""
         B = full_pred.shape[0]
-        for b in range(B):
-            images.append(render_batch(
-                points=full_pred[b], shs=None, colors_precomp=colors[b], rotations=self.fix_rotation,
-                scales=scales[b], opacity=self.fix_opacity,
-                FovX=batch_data["FovX"][b], FovY=batch_data["FovY"][b],
-                height=batch_data["height"][b], width=batch_data["width"][b], bg_color=self.background,
-                world_view_transform=batch_data["world_view_transform"][b],
-                full_proj_transform=batch_data["full_proj_transform"][b],
-                active_sh_degree=0, camera_center=batch_data["camera_center"][b]))
-        return torch.stack(images, dim=0)
+        return render_frames(
+            points=full_pred, colors_precomp=colors, rotations=self.fix_rotation, scales=scales,
+            opacity=self.fix_opacity, FovX=batch_data["FovX"], FovY=batch_data["FovY"],
+            height=batch_data["height"], width=batch_data["width"], bg_color=self.background,
+            world_view_transform=batch_data["world_view_transform"][:B],
+            full_proj_transform=batch_data["full_proj_transform"][:B],
+            camera_center=batch_data["camera_center"][:B])
 
     def _forward(self, batch_data, iteration, pose, transl, pose_featmap, warmup):
         B = pose.shape[0]

@@ -98,24 +98,31 @@ wgrad_kernel(int64_t M, int N, int K, const float* __restrict__ g, int64_t ldg,
   }
 }
 
+// Sum the per-workgroup partial tiles. 64 output elements per block, 4 threads per element
+// (each walks a quarter of the partials), combined through LDS.
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(int nblocks, int N, int K, const float* __restrict__ partial,
                     float* __restrict__ dW, float* __restrict__ db) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float s_part[4][64];
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
   const int total = N * K + N;
-  if (e >= total) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int b = 0;
-  for (; b + 3 < nblocks; b += 4) {
-    s0 += partial[(size_t)b * total + e];
-    s1 += partial[(size_t)(b + 1) * total + e];
-    s2 += partial[(size_t)(b + 2) * total + e];
-    s3 += partial[(size_t)(b + 3) * total + e];
+  float s0 = 0.f, s1 = 0.f;
+  if (e < total) {
+    int b = part;
+    for (; b + 4 < nblocks; b += 8) {
+      s0 += partial[(size_t)b * total + e];
+      s1 += partial[(size_t)(b + 4) * total + e];
+    }
+    if (b < nblocks) s0 += partial[(size_t)b * total + e];
   }
-  for (; b < nblocks; ++b) s0 += partial[(size_t)b * total + e];
-  const float s = (s0 + s1) + (s2 + s3);
-  if (e < N * K) dW[e] = s;
-  else if (db) db[e - N * K] = s;
+  s_part[part][lane] = s0 + s1;
+  __syncthreads();
+  if (part == 0 && e < total) {
+    const float s = (s_part[0][lane] + s_part[1][lane]) + (s_part[2][lane] + s_part[3][lane]);
+    if (e < N * K) dW[e] = s;
+    else if (db) db[e - N * K] = s;
+  }
 }
 
 int plan_blocks(int64_t M, int64_t* rows_per_block) {
@@ -182,7 +189,7 @@ int ganet_linear_wgrad(int64_t M, int32_t N, int32_t K, const float* g, int64_t 
   int rc = check_hip(hipGetLastError(), "wgrad_kernel");
   if (rc) return rc;
   const int total = N * K + N;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, nb, N, K,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, stream, nb, N, K,
                      partial, dW, db);
   return check_hip(hipGetLastError(), "wgrad_reduce_kernel");
 }

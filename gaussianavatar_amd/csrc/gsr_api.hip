@@ -195,11 +195,39 @@ int gsr_workspace_layout(int32_t P, int32_t W, int32_t H, int64_t max_pairs, Gsr
   return GSR_OK;
 }
 
-int gsr_forward(const GsrSettings* s, int32_t P, const float* means3D,
-                const float* colors_precomp, const float* shs, int32_t sh_coeffs,
-                const float* opacities, const float* scales, const float* rotations,
-                const float* cov3D_precomp, void* workspace, size_t workspace_bytes,
-                int64_t max_pairs, float* out_color, int32_t* out_radii, void* stream_) {
+static int make_batch(const GsrBatch* b, int32_t P, const GsrLayout& L, size_t workspace_bytes,
+                      Batch* out) {
+  if (!b || b->frames < 1 || b->frames > 65535) {
+    set_error("batch descriptor: frames must be in [1, 65535]");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  const int64_t strides[] = {b->means3D_stride, b->colors_stride, b->opacities_stride,
+                             b->scales_stride, b->rotations_stride, b->cov3D_stride,
+                             b->viewmatrix_stride, b->projmatrix_stride};
+  for (int64_t v : strides)
+    if (v < 0) { set_error("batch descriptor: negative stride"); return GSR_ERR_INVALID_ARGUMENT; }
+  if (b->frames > 1 && b->means3D_stride < (int64_t)P * 3) {
+    set_error("batch descriptor: means3D_stride must be >= 3*P (frames do not share positions)");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  if (workspace_bytes < (size_t)b->frames * L.total_bytes) {
+    set_error("workspace too small: have %zu bytes, need %d x %llu", workspace_bytes, b->frames,
+              (unsigned long long)L.total_bytes);
+    return GSR_ERR_WORKSPACE_TOO_SMALL;
+  }
+  out->frames = b->frames;
+  out->ws_stride = (size_t)L.total_bytes;
+  out->means = b->means3D_stride; out->colors = b->colors_stride; out->opacities = b->opacities_stride;
+  out->scales = b->scales_stride; out->rotations = b->rotations_stride; out->cov3d = b->cov3D_stride;
+  out->view = b->viewmatrix_stride; out->proj = b->projmatrix_stride;
+  return GSR_OK;
+}
+
+int gsr_forward_batch(const GsrSettings* s, const GsrBatch* batch, int32_t P, const float* means3D,
+                      const float* colors_precomp, const float* shs, int32_t sh_coeffs,
+                      const float* opacities, const float* scales, const float* rotations,
+                      const float* cov3D_precomp, void* workspace, size_t workspace_bytes,
+                      int64_t max_pairs, float* out_color, int32_t* out_radii, void* stream_) {
   (void)sh_coeffs;
   GsrLayout L;
   int rc = validate(s, P, means3D, colors_precomp, shs, opacities, scales, rotations,
@@ -209,25 +237,80 @@ int gsr_forward(const GsrSettings* s, int32_t P, const float* means3D,
     set_error("out_color / out_radii are NULL");
     return GSR_ERR_INVALID_ARGUMENT;
   }
+  Batch bt;
+  if ((rc = make_batch(batch, P, L, workspace_bytes, &bt))) return rc;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const Dims d = make_dims(P, s->image_width, s->image_height, max_pairs);
   const Workspace ws = resolve(workspace, L);
-  // tile_count .. tile_cursor are contiguous in the layout: one memset clears the histogram
-  if ((rc = check_hip(hipMemsetAsync(ws.tile_count, 0, L.tile_cursor - L.tile_count, stream),
-                      "memset tile_count")))
+  // tile_count .. tile_cursor are contiguous in the layout: one (2-D) memset clears the
+  // histogram of every frame, a second one the status words
+  if ((rc = check_hip(hipMemset2DAsync(ws.tile_count, bt.ws_stride, 0, L.tile_cursor - L.tile_count,
+                                       bt.frames, stream), "memset tile_count")))
     return rc;
-  if ((rc = check_hip(hipMemsetAsync(ws.status, 0, 8 * sizeof(int32_t), stream), "memset status")))
+  if ((rc = check_hip(hipMemset2DAsync(ws.status, bt.ws_stride, 0, 8 * sizeof(int32_t), bt.frames,
+                                       stream), "memset status")))
     return rc;
   if ((rc = check_hip(launch_preprocess(*s, d, means3D, colors_precomp, opacities, scales,
-                                        rotations, cov3D_precomp, ws, out_radii, stream),
+                                        rotations, cov3D_precomp, ws, out_radii, bt, stream),
                       "preprocess")))
     return rc;
   if ((rc = debug_sync(s, stream, "preprocess (sync)"))) return rc;
-  if ((rc = check_hip(launch_binning(d, ws, stream), "binning"))) return rc;
+  if ((rc = check_hip(launch_binning(d, ws, bt, stream), "binning"))) return rc;
   if ((rc = debug_sync(s, stream, "binning (sync)"))) return rc;
-  if ((rc = check_hip(launch_render_fwd(*s, d, ws, out_color, stream), "render_fwd"))) return rc;
+  if ((rc = check_hip(launch_render_fwd(*s, d, ws, out_color, bt, stream), "render_fwd"))) return rc;
   if ((rc = debug_sync(s, stream, "render_fwd (sync)"))) return rc;
   return GSR_OK;
+}
+
+int gsr_backward_batch(const GsrSettings* s, const GsrBatch* batch, int32_t P, const float* means3D,
+                       const float* colors_precomp, const float* shs, int32_t sh_coeffs,
+                       const float* opacities, const float* scales, const float* rotations,
+                       const float* cov3D_precomp, const int32_t* radii, void* workspace,
+                       size_t workspace_bytes, int64_t max_pairs, const float* dL_dout_color,
+                       float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors, float* dL_dsh,
+                       float* dL_dopacity, float* dL_dscales, float* dL_drotations,
+                       float* dL_dcov3D, void* stream_) {
+  (void)sh_coeffs; (void)dL_dsh;
+  GsrLayout L;
+  int rc = validate(s, P, means3D, colors_precomp, shs, opacities, scales, rotations,
+                    cov3D_precomp, workspace, workspace_bytes, max_pairs, &L);
+  if (rc) return rc;
+  if (!dL_dout_color || (P > 0 && !radii)) {
+    set_error("dL_dout_color / radii are NULL");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  Batch bt;
+  if ((rc = make_batch(batch, P, L, workspace_bytes, &bt))) return rc;
+  if (P == 0) return GSR_OK;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const Dims d = make_dims(P, s->image_width, s->image_height, max_pairs);
+  const Workspace ws = resolve(workspace, L);
+  if ((rc = check_hip(hipMemset2DAsync(ws.grad_acc, bt.ws_stride, 0,
+                                       (size_t)P * GSR_GRAD_STRIDE * sizeof(float), bt.frames, stream),
+                      "memset grad_acc")))
+    return rc;
+  if ((rc = check_hip(launch_render_bwd(*s, d, ws, dL_dout_color, bt, stream), "render_bwd")))
+    return rc;
+  if ((rc = debug_sync(s, stream, "render_bwd (sync)"))) return rc;
+  if ((rc = check_hip(launch_preprocess_bwd(*s, d, means3D, scales, rotations, radii, ws,
+                                            dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity,
+                                            dL_dscales, dL_drotations, dL_dcov3D, bt, stream),
+                      "preprocess_bwd")))
+    return rc;
+  if ((rc = debug_sync(s, stream, "preprocess_bwd (sync)"))) return rc;
+  return GSR_OK;
+}
+
+static const GsrBatch kSingleFrame = {1, 0, 0, 0, 0, 0, 0, 0, 0};
+
+int gsr_forward(const GsrSettings* s, int32_t P, const float* means3D,
+                const float* colors_precomp, const float* shs, int32_t sh_coeffs,
+                const float* opacities, const float* scales, const float* rotations,
+                const float* cov3D_precomp, void* workspace, size_t workspace_bytes,
+                int64_t max_pairs, float* out_color, int32_t* out_radii, void* stream_) {
+  return gsr_forward_batch(s, &kSingleFrame, P, means3D, colors_precomp, shs, sh_coeffs, opacities,
+                           scales, rotations, cov3D_precomp, workspace, workspace_bytes, max_pairs,
+                           out_color, out_radii, stream_);
 }
 
 int gsr_backward(const GsrSettings* s, int32_t P, const float* means3D,
@@ -238,32 +321,10 @@ int gsr_backward(const GsrSettings* s, int32_t P, const float* means3D,
                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors, float* dL_dsh,
                  float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
                  void* stream_) {
-  (void)sh_coeffs; (void)dL_dsh;
-  GsrLayout L;
-  int rc = validate(s, P, means3D, colors_precomp, shs, opacities, scales, rotations,
-                    cov3D_precomp, workspace, workspace_bytes, max_pairs, &L);
-  if (rc) return rc;
-  if (!dL_dout_color || (P > 0 && !radii)) {
-    set_error("dL_dout_color / radii are NULL");
-    return GSR_ERR_INVALID_ARGUMENT;
-  }
-  if (P == 0) return GSR_OK;
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const Dims d = make_dims(P, s->image_width, s->image_height, max_pairs);
-  const Workspace ws = resolve(workspace, L);
-  if ((rc = check_hip(hipMemsetAsync(ws.grad_acc, 0, (size_t)P * GSR_GRAD_STRIDE * sizeof(float),
-                                     stream), "memset grad_acc")))
-    return rc;
-  if ((rc = check_hip(launch_render_bwd(*s, d, ws, dL_dout_color, stream), "render_bwd")))
-    return rc;
-  if ((rc = debug_sync(s, stream, "render_bwd (sync)"))) return rc;
-  if ((rc = check_hip(launch_preprocess_bwd(*s, d, means3D, scales, rotations, radii, ws,
-                                            dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity,
-                                            dL_dscales, dL_drotations, dL_dcov3D, stream),
-                      "preprocess_bwd")))
-    return rc;
-  if ((rc = debug_sync(s, stream, "preprocess_bwd (sync)"))) return rc;
-  return GSR_OK;
+  return gsr_backward_batch(s, &kSingleFrame, P, means3D, colors_precomp, shs, sh_coeffs, opacities,
+                            scales, rotations, cov3D_precomp, radii, workspace, workspace_bytes,
+                            max_pairs, dL_dout_color, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dsh,
+                            dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D, stream_);
 }
 
 int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,

@@ -22,7 +22,14 @@ constexpr int MERGE_ITEMS = 8;        // outputs per thread per merge step
 __global__ void __launch_bounds__(SCAN_THREADS)
 tile_scan_kernel(int T, int64_t max_pairs, const uint32_t* __restrict__ tile_count,
                  uint32_t* __restrict__ tile_offset, uint32_t* __restrict__ tile_cursor,
-                 int32_t* __restrict__ status) {
+                 int32_t* __restrict__ status, size_t ws_stride) {
+  {
+    const size_t off = (size_t)blockIdx.y * ws_stride;   // batched launch: this frame's workspace
+    tile_count = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(tile_count) + off);
+    tile_offset = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(tile_offset) + off);
+    tile_cursor = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(tile_cursor) + off);
+    status = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(status) + off);
+  }
   __shared__ uint32_t s_wave[SCAN_THREADS / GSR_WAVE];
   __shared__ uint32_t s_max[SCAN_THREADS / GSR_WAVE];
   const int tid = threadIdx.x;
@@ -73,9 +80,16 @@ tile_scan_kernel(int T, int64_t max_pairs, const uint32_t* __restrict__ tile_cou
 __global__ void __launch_bounds__(256)
 scatter_kernel(int P, int gx, int64_t max_pairs, const int4* __restrict__ rect,
                const float* __restrict__ depth, uint32_t* __restrict__ tile_cursor,
-               uint64_t* __restrict__ pair_key) {
+               uint64_t* __restrict__ pair_key, size_t ws_stride) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
+  {
+    const size_t off = (size_t)blockIdx.y * ws_stride;
+    rect = reinterpret_cast<const int4*>(reinterpret_cast<const char*>(rect) + off);
+    depth = reinterpret_cast<const float*>(reinterpret_cast<const char*>(depth) + off);
+    tile_cursor = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(tile_cursor) + off);
+    pair_key = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(pair_key) + off);
+  }
   const int lane = threadIdx.x & (GSR_WAVE - 1);
   const int4 rc = rect[i];
   const uint64_t key = ((uint64_t)__float_as_uint(depth[i]) << 32) | (uint32_t)i;
@@ -160,8 +174,15 @@ __device__ __forceinline__ int merge_split(const uint64_t* A, int na, const uint
 __global__ void __launch_bounds__(SORT_THREADS)
 tile_sort_kernel(int64_t max_pairs, const uint32_t* __restrict__ tile_offset,
                  uint64_t* __restrict__ pair_key, uint64_t* __restrict__ pair_tmp,
-                 uint32_t* __restrict__ point_list) {
+                 uint32_t* __restrict__ point_list, size_t ws_stride) {
   __shared__ uint64_t s_key[SORT_CAP];
+  {
+    const size_t off = (size_t)blockIdx.y * ws_stride;
+    tile_offset = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(tile_offset) + off);
+    pair_key = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(pair_key) + off);
+    pair_tmp = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(pair_tmp) + off);
+    point_list = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(point_list) + off);
+  }
   const int tile = blockIdx.x;
   const int tid = threadIdx.x;
   const int64_t cap = max_pairs;
@@ -222,26 +243,26 @@ tile_sort_kernel(int64_t max_pairs, const uint32_t* __restrict__ tile_offset,
 
 }  // namespace
 
-hipError_t launch_binning(const Dims& d, const Workspace& ws, hipStream_t stream) {
+hipError_t launch_binning(const Dims& d, const Workspace& ws, const Batch& bt, hipStream_t stream) {
   {
     ProfScope prof_(K_SCAN, stream);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, d.T, d.max_pairs,
-                     ws.tile_count, ws.tile_offset, ws.tile_cursor, ws.status);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1, bt.frames), dim3(SCAN_THREADS), 0, stream, d.T, d.max_pairs,
+                     ws.tile_count, ws.tile_offset, ws.tile_cursor, ws.status, bt.ws_stride);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (d.P > 0) {
     {
       ProfScope prof_(K_SCATTER, stream);
-      hipLaunchKernelGGL(scatter_kernel, dim3((d.P + 255) / 256), dim3(256), 0, stream, d.P, d.gx,
-                       d.max_pairs, ws.rect, ws.depth, ws.tile_cursor, ws.pair_key);
+      hipLaunchKernelGGL(scatter_kernel, dim3((d.P + 255) / 256, bt.frames), dim3(256), 0, stream, d.P, d.gx,
+                       d.max_pairs, ws.rect, ws.depth, ws.tile_cursor, ws.pair_key, bt.ws_stride);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     {
       ProfScope prof_(K_SORT, stream);
-      hipLaunchKernelGGL(tile_sort_kernel, dim3(d.T), dim3(SORT_THREADS), 0, stream, d.max_pairs,
-                       ws.tile_offset, ws.pair_key, ws.pair_tmp, ws.point_list);
+      hipLaunchKernelGGL(tile_sort_kernel, dim3(d.T, bt.frames), dim3(SORT_THREADS), 0, stream, d.max_pairs,
+                       ws.tile_offset, ws.pair_key, ws.pair_tmp, ws.point_list, bt.ws_stride);
     }
     e = hipGetLastError();
   }

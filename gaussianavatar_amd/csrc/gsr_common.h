@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "gsr.h"
 
 #define GSR_TILE_PIX (GSR_TILE * GSR_TILE)   // 256 threads per tile = 4 wave64
@@ -64,6 +66,22 @@ struct Workspace {
   int32_t* status;
 };
 
+// Batched launches: blockIdx.y = frame. Element strides between frames (0 = shared by all
+// frames); outputs and gradients are contiguous [frames, ...].
+struct Batch {
+  int frames;
+  size_t ws_stride;   // bytes between per-frame workspaces
+  int64_t means, colors, opacities, scales, rotations, cov3d, view, proj;
+};
+
+__host__ __device__ inline Workspace frame_ws(Workspace w, size_t bytes) {
+  auto mv = [bytes](auto*& p) { p = reinterpret_cast<std::remove_reference_t<decltype(p)>>(reinterpret_cast<char*>(p) + bytes); };
+  mv(w.depth); mv(w.xy); mv(w.conic_opacity); mv(w.rgb); mv(w.cov3d); mv(w.rect); mv(w.tiles_touched);
+  mv(w.clamped); mv(w.tile_count); mv(w.tile_offset); mv(w.tile_cursor); mv(w.pair_key);
+  mv(w.point_list); mv(w.pair_tmp); mv(w.final_T); mv(w.n_contrib); mv(w.grad_acc); mv(w.status);
+  return w;
+}
+
 int compute_layout(int P, int W, int H, int64_t max_pairs, GsrLayout* out);
 Workspace resolve(void* base, const GsrLayout& L);
 void set_error(const char* fmt, ...);
@@ -73,18 +91,18 @@ hipError_t launch_preprocess(const GsrSettings& s, const Dims& d, const float* m
                              const float* colors_precomp, const float* opacities,
                              const float* scales, const float* rotations,
                              const float* cov3D_precomp, const Workspace& ws, int32_t* radii,
-                             hipStream_t stream);
-hipError_t launch_binning(const Dims& d, const Workspace& ws, hipStream_t stream);
+                             const Batch& bt, hipStream_t stream);
+hipError_t launch_binning(const Dims& d, const Workspace& ws, const Batch& bt, hipStream_t stream);
 hipError_t launch_render_fwd(const GsrSettings& s, const Dims& d, const Workspace& ws,
-                             float* out_color, hipStream_t stream);
+                             float* out_color, const Batch& bt, hipStream_t stream);
 hipError_t launch_render_bwd(const GsrSettings& s, const Dims& d, const Workspace& ws,
-                             const float* dL_dout, hipStream_t stream);
+                             const float* dL_dout, const Batch& bt, hipStream_t stream);
 hipError_t launch_preprocess_bwd(const GsrSettings& s, const Dims& d, const float* means3D,
                                  const float* scales, const float* rotations,
                                  const int32_t* radii, const Workspace& ws,
                                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors,
                                  float* dL_dopacity, float* dL_dscales, float* dL_drotations,
-                                 float* dL_dcov3D, hipStream_t stream);
+                                 float* dL_dcov3D, const Batch& bt, hipStream_t stream);
 // Opt-in per-kernel timing (gsr_profile_* in gsr.h).
 enum KernelId { K_PREPROCESS = 0, K_SCAN, K_SCATTER, K_SORT, K_RENDER_FWD, K_RENDER_BWD,
                 K_PREPROCESS_BWD, K_COUNT };

@@ -76,9 +76,18 @@ preprocess_kernel(int P, int W, int H, int gx, int gy, float tanfovx, float tanf
                   const float* __restrict__ colors, const float* __restrict__ opacities,
                   const float* __restrict__ scales, const float* __restrict__ rotations,
                   const float* __restrict__ cov3D_precomp, Workspace ws,
-                  int32_t* __restrict__ radii) {
+                  int32_t* __restrict__ radii, Batch bt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
+  {   // batched launch: select this frame's inputs, workspace and outputs
+    const int64_t f = blockIdx.y;
+    view += f * bt.view; proj += f * bt.proj; means3D += f * bt.means; colors += f * bt.colors;
+    opacities += f * bt.opacities;
+    if (scales) { scales += f * bt.scales; rotations += f * bt.rotations; }
+    if (cov3D_precomp) cov3D_precomp += f * bt.cov3d;
+    ws = frame_ws(ws, (size_t)f * bt.ws_stride);
+    radii += f * P;
+  }
   float V[16], PV[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) { V[k] = view[k]; PV[k] = proj[k]; }
@@ -193,9 +202,23 @@ preprocess_bwd_kernel(int P, int W, int H, float tanfovx, float tanfovy, float s
                       Workspace ws, float* __restrict__ dL_dmeans3D,
                       float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors,
                       float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales,
-                      float* __restrict__ dL_drotations, float* __restrict__ dL_dcov3D) {
+                      float* __restrict__ dL_drotations, float* __restrict__ dL_dcov3D, Batch bt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
+  {
+    const int64_t f = blockIdx.y;
+    view += f * bt.view; proj += f * bt.proj; means3D += f * bt.means;
+    if (scales) { scales += f * bt.scales; rotations += f * bt.rotations; }
+    ws = frame_ws(ws, (size_t)f * bt.ws_stride);
+    radii += f * P;
+    if (dL_dmeans3D) dL_dmeans3D += f * P * 3;
+    if (dL_dmeans2D) dL_dmeans2D += f * P * 3;
+    if (dL_dcolors) dL_dcolors += f * P * 3;
+    if (dL_dopacity) dL_dopacity += f * P;
+    if (dL_dscales) dL_dscales += f * P * 3;
+    if (dL_drotations) dL_drotations += f * P * 4;
+    if (dL_dcov3D) dL_dcov3D += f * P * 6;
+  }
   const bool live = radii[i] > 0;
   float g[GSR_GRAD_STRIDE];
 #pragma unroll
@@ -356,16 +379,16 @@ hipError_t launch_preprocess(const GsrSettings& s, const Dims& d, const float* m
                              const float* colors_precomp, const float* opacities,
                              const float* scales, const float* rotations,
                              const float* cov3D_precomp, const Workspace& ws, int32_t* radii,
-                             hipStream_t stream) {
+                             const Batch& bt, hipStream_t stream) {
   if (d.P == 0) return hipSuccess;
   const int block = 256;
   const int grid = (d.P + block - 1) / block;
   {
     ProfScope prof_(K_PREPROCESS, stream);
-    hipLaunchKernelGGL(preprocess_kernel, dim3(grid), dim3(block), 0, stream, d.P, d.W, d.H, d.gx,
+    hipLaunchKernelGGL(preprocess_kernel, dim3(grid, bt.frames), dim3(block), 0, stream, d.P, d.W, d.H, d.gx,
                      d.gy, s.tanfovx, s.tanfovy, s.scale_modifier, s.viewmatrix, s.projmatrix,
                      means3D, colors_precomp, opacities, scales, rotations, cov3D_precomp, ws,
-                     radii);
+                     radii, bt);
   }
   return hipGetLastError();
 }
@@ -375,16 +398,16 @@ hipError_t launch_preprocess_bwd(const GsrSettings& s, const Dims& d, const floa
                                  const int32_t* radii, const Workspace& ws,
                                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors,
                                  float* dL_dopacity, float* dL_dscales, float* dL_drotations,
-                                 float* dL_dcov3D, hipStream_t stream) {
+                                 float* dL_dcov3D, const Batch& bt, hipStream_t stream) {
   if (d.P == 0) return hipSuccess;
   const int block = 256;
   const int grid = (d.P + block - 1) / block;
   {
     ProfScope prof_(K_PREPROCESS_BWD, stream);
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(grid), dim3(block), 0, stream, d.P, d.W, d.H,
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(grid, bt.frames), dim3(block), 0, stream, d.P, d.W, d.H,
                      s.tanfovx, s.tanfovy, s.scale_modifier, s.viewmatrix, s.projmatrix,
                      means3D, scales, rotations, radii, ws, dL_dmeans3D, dL_dmeans2D,
-                     dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D);
+                     dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D, bt);
   }
   return hipGetLastError();
 }

@@ -107,8 +107,9 @@ class _PairCapacity:
         self.pool.append(host)
         self.seen[key] = max(self.seen.get(key, 0), needed)
         self.stamp[key] = time.monotonic()
-        self.pairs_sum += needed
-        self.calls += 1
+        frames = int(host[5]) if int(host[5]) > 0 else 1          # batched launches report totals
+        self.pairs_sum += int(host[4]) if int(host[5]) > 0 else needed
+        self.calls += frames
         return needed, overflow
 
     def poll(self, block: bool = False):
@@ -380,6 +381,143 @@ class _RasterizeGaussians(torch.autograd.Function):
                               _stream_ptr(dev))
         _native.gsr_check(rc)
         return d_means3D, d_means2D, None, d_colors, d_opac, d_scales, d_rots, d_cov, None, None
+
+
+def _frame_stride(t: torch.Tensor, frames: int, inner_shape) -> tuple:
+    """(tensor whose data pointer is frame 0, element stride between frames). A leading dimension
+    of size 1 or an expanded (stride 0) one means "shared by all frames"."""
+    inner = 1
+    for d in inner_shape:
+        inner *= d
+    if t.dim() == len(inner_shape):                         # no frame dimension at all
+        return _f32c(t, inner_shape), 0
+    if t.shape[0] == 1 or t.stride(0) == 0:
+        return _f32c(t[0], inner_shape), 0
+    assert t.shape[0] == frames, (t.shape, frames)
+    return _f32c(t, (frames,) + tuple(inner_shape)), inner
+
+
+class _RasterizeGaussiansBatch(torch.autograd.Function):
+    """All frames of a batch through ONE launch of every rasterizer kernel (gsr_forward_batch).
+    Inputs: means3D [B,P,3]; colors_precomp, scales [B,P,3] (or shared [P,3] / expanded views);
+    opacities [P,1] | [B,P,1]; rotations [P,4] | [B,P,4]; settings.viewmatrix / projmatrix
+    [B,4,4] (or shared [4,4]). Returns (color [B,3,H,W], radii [B,P])."""
+
+    @staticmethod
+    def forward(ctx, means3D, colors_precomp, opacities, scales, rotations, raster_settings, sync_check):
+        rs = raster_settings
+        if not means3D.is_cuda:
+            raise RuntimeError("GaussianRasterizer: tensors must live on a HIP device "
+                               "(there is no CPU fallback)")
+        lib = _native.gsr()
+        dev = means3D.device
+        B, P = means3D.shape[0], means3D.shape[1]
+        H, W = int(rs.image_height), int(rs.image_width)
+        means3D = _f32c(means3D, (B, P, 3))
+        col, s_col = _frame_stride(colors_precomp, B, (P, 3))
+        opa_flat = opacities.squeeze(-1) if (opacities.dim() >= 2 and opacities.shape[-1] == 1) else opacities
+        opa, s_opa = _frame_stride(opa_flat, B, (P,))
+        sca, s_sca = _frame_stride(scales, B, (P, 3))
+        rot, s_rot = _frame_stride(rotations, B, (P, 4))
+        view, s_view = _frame_stride(rs.viewmatrix.reshape(*rs.viewmatrix.shape[:-2], 16), B, (16,))
+        proj, s_proj = _frame_stride(rs.projmatrix.reshape(*rs.projmatrix.shape[:-2], 16), B, (16,))
+        bg = _f32c(rs.bg.to(dev), (3,))
+        campos = _f32c(rs.campos.to(dev).reshape(-1)[:3], (3,))
+        st = _native.GsrSettings(H, W, float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier),
+                                 int(rs.sh_degree), int(bool(rs.prefiltered)), int(bool(rs.debug)),
+                                 bg.data_ptr(), view.data_ptr(), proj.data_ptr(), campos.data_ptr())
+        bt = _native.GsrBatch(B, P * 3, s_col, s_opa, s_sca, s_rot, 0, s_view, s_proj)
+        _capacity.poll()
+        key = (P, W, H)
+        sync_check = bool(rs.debug) or bool(sync_check) or not _capacity.known(key)
+        max_pairs = _capacity.capacity(key)
+        L = _native.GsrLayout()
+        while True:
+            frame_bytes = lib.gsr_workspace_bytes(P, W, H, max_pairs)
+            workspace = torch.empty(B * frame_bytes, dtype=torch.uint8, device=dev)
+            color = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
+            radii = torch.empty((B, P), dtype=torch.int32, device=dev)
+            _native.gsr_check(lib.gsr_forward_batch(
+                ctypes.byref(st), ctypes.byref(bt), P, _ptr(means3D), _ptr(col), None, 0, _ptr(opa),
+                _ptr(sca), _ptr(rot), None, _ptr(workspace), workspace.numel(), max_pairs,
+                _ptr(color), _ptr(radii), _stream_ptr(dev)))
+            lib.gsr_workspace_layout(P, W, H, max_pairs, ctypes.byref(L))
+            status = workspace.view(B, frame_bytes)[:, L.status:L.status + 32].contiguous().view(torch.int32)
+            # frame with the most pairs decides (status words: [needed, overflow, ...])
+            # one record for the whole launch: [max pairs of a frame, any overflow, -, longest tile
+            # list, total pairs of all frames, frames, -, -]
+            worst = torch.stack([status[:, 0].max(), status[:, 1].max(), status[:, 2].sum(), status[:, 3].max(),
+                                 status[:, 0].sum(), torch.full((), B, dtype=torch.int32, device=dev),
+                                 status[:, 6].max(), status[:, 7].max()]).to(torch.int32)
+            _capacity.post(worst, max_pairs, key)
+            if not sync_check:
+                break
+            needed, overflow = _capacity.wait_last()
+            if not overflow:
+                break
+            max_pairs = _capacity.capacity(key)
+        ctx.raster_settings = rs
+        ctx.max_pairs = max_pairs
+        # (original shape, has a leading frame dimension) of every differentiable input
+        ctx.meta = (B, P, H, W, (s_col, s_opa, s_sca, s_rot, s_view, s_proj),
+                    (tuple(colors_precomp.shape), colors_precomp.dim() == 3),
+                    (tuple(opacities.shape), opa_flat.dim() == 2),
+                    (tuple(scales.shape), scales.dim() == 3),
+                    (tuple(rotations.shape), rotations.dim() == 3))
+        ctx.save_for_backward(means3D, col, opa, sca, rot, view, proj, bg, campos, radii, workspace)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_color, _grad_radii):
+        lib = _native.gsr()
+        rs = ctx.raster_settings
+        means3D, col, opa, sca, rot, view, proj, bg, campos, radii, workspace = ctx.saved_tensors
+        B, P, H, W, strides, col_shape, opa_shape, sca_shape, rot_shape = ctx.meta
+        s_col, s_opa, s_sca, s_rot, s_view, s_proj = strides
+        dev = means3D.device
+        _capacity.poll()
+        grad_color = _f32c(grad_color, (B, 3, H, W))
+        need = ctx.needs_input_grad
+
+        def out(flag, *shape):
+            return torch.empty(shape, dtype=torch.float32, device=dev) if flag else None
+
+        d_means = out(need[0], B, P, 3)
+        d_col = out(need[1], B, P, 3)
+        d_opa = out(need[2], B, P)
+        d_sca = out(need[3], B, P, 3)
+        d_rot = out(need[4], B, P, 4)
+        st = _native.GsrSettings(H, W, float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier),
+                                 int(rs.sh_degree), int(bool(rs.prefiltered)), int(bool(rs.debug)),
+                                 bg.data_ptr(), view.data_ptr(), proj.data_ptr(), campos.data_ptr())
+        bt = _native.GsrBatch(B, P * 3, s_col, s_opa, s_sca, s_rot, 0, s_view, s_proj)
+        _native.gsr_check(lib.gsr_backward_batch(
+            ctypes.byref(st), ctypes.byref(bt), P, _ptr(means3D), _ptr(col), None, 0, _ptr(opa), _ptr(sca),
+            _ptr(rot), None, _ptr(radii), _ptr(workspace), workspace.numel(), ctx.max_pairs,
+            _ptr(grad_color), _ptr(d_means), None, _ptr(d_col), None, _ptr(d_opa), _ptr(d_sca), _ptr(d_rot),
+            None, _stream_ptr(dev)))
+
+        def fold(g, info):
+            """Per-frame gradients [B, ...] back to the shape the caller passed: summed over frames
+            for inputs without a frame dimension or with a broadcast one of size 1."""
+            if g is None:
+                return None
+            shape, has_frame_dim = info
+            if not has_frame_dim or (shape[0] == 1 and B > 1):
+                g = g.sum(0)
+            return g.reshape(shape)
+
+        return (d_means, fold(d_col, col_shape), fold(d_opa, opa_shape), fold(d_sca, sca_shape),
+                fold(d_rot, rot_shape), None, None)
+
+
+def rasterize_gaussians_batch(means3D, colors_precomp, opacities, scales, rotations, raster_settings):
+    """Batched rasterization (see _RasterizeGaussiansBatch)."""
+    tensors = (means3D, colors_precomp, opacities, scales, rotations)
+    differentiable = torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
+    return _RasterizeGaussiansBatch.apply(means3D, colors_precomp, opacities, scales, rotations,
+                                          raster_settings, not differentiable)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,

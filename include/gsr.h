@@ -153,6 +153,49 @@ int gsr_backward(const GsrSettings* settings, int32_t P,
                  float* dL_dopacity, float* dL_dscales, float* dL_drotations,
                  float* dL_dcov3D, void* stream);
 
+/*
+ * Batched variants: `frames` frames that share P, image size, FoV and background are rendered by
+ * ONE launch of every kernel (grid.y = frame). The reference renders the frames of a batch one
+ * after the other (/root/reference/model/avatar_model.py:332-365); the per-tile work of one
+ * frame leaves most of the chip idle, so batching the frames is what fills it.
+ * Strides are in elements between consecutive frames; 0 = the array is shared by all frames
+ * (stage 1 shares colours, scales, opacities and rotations). settings->viewmatrix/projmatrix
+ * point at frame 0. The workspace is frames x gsr_workspace_bytes(...) (frame f at offset
+ * f * gsr_workspace_bytes); out_color [frames,3,H,W], radii [frames,P] and every gradient
+ * [frames,P,...] are contiguous.
+ */
+typedef struct GsrBatch {
+  int32_t frames;
+  int64_t means3D_stride;
+  int64_t colors_stride;
+  int64_t opacities_stride;
+  int64_t scales_stride;
+  int64_t rotations_stride;
+  int64_t cov3D_stride;
+  int64_t viewmatrix_stride;
+  int64_t projmatrix_stride;
+} GsrBatch;
+
+int gsr_forward_batch(const GsrSettings* settings, const GsrBatch* batch, int32_t P,
+                      const float* means3D, const float* colors_precomp,
+                      const float* shs, int32_t sh_coeffs,
+                      const float* opacities, const float* scales, const float* rotations,
+                      const float* cov3D_precomp,
+                      void* workspace, size_t workspace_bytes, int64_t max_pairs,
+                      float* out_color, int32_t* out_radii, void* stream);
+
+int gsr_backward_batch(const GsrSettings* settings, const GsrBatch* batch, int32_t P,
+                       const float* means3D, const float* colors_precomp,
+                       const float* shs, int32_t sh_coeffs,
+                       const float* opacities, const float* scales, const float* rotations,
+                       const float* cov3D_precomp,
+                       const int32_t* radii,
+                       void* workspace, size_t workspace_bytes, int64_t max_pairs,
+                       const float* dL_dout_color,
+                       float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors, float* dL_dsh,
+                       float* dL_dopacity, float* dL_dscales, float* dL_drotations,
+                       float* dL_dcov3D, void* stream);
+
 /* Replaces `_C.mark_visible`: out_visible[i] = 1 if Gaussian i passes the near-plane
  * test of the forward pass (view-space z > 0.2). out_visible is uint8 [P]. */
 int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,
