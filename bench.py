@@ -78,8 +78,20 @@ def cpu_baseline(N: int, B: int, budget_s: float = 12.0) -> dict:
         res = (torch.zeros(B, N, 3)).requires_grad_(True)
         O.cpu_baseline_step(pose, transl, J, parents, inv, pts, res, w, full_proj)
 
-    for _ in range(2):
+    # torch's intra-op threading degrades badly when every hardware thread of a large host is
+    # used for these small ops (256 threads: 9 s per iteration); take the best of a few counts
+    best = None
+    for nt in sorted({min(cores, c) for c in (8, 16, 32, 64)}):
+        torch.set_num_threads(nt)
         one()
+        t0 = time.perf_counter()
+        one()
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[1]:
+            best = (nt, dt)
+    threads = best[0]
+    torch.set_num_threads(threads)
+    one()
     t0 = time.perf_counter()
     n = 0
     while True:
@@ -88,10 +100,11 @@ def cpu_baseline(N: int, B: int, budget_s: float = 12.0) -> dict:
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 400:
             break
-    return {"value": n / el, "unit": "iters/s", "cores": cores, "kind": "port",
+    return {"value": n / el, "unit": "iters/s", "cores": threads, "kind": "port",
             "sample": f"{n} fwd+bwd iterations of LBS joint transforms + skinning + projection + "
                       f"L1-to-black (no rasterizer/net exists on the CPU side), B={B} frames, "
-                      f"N={N} points, {el:.1f} s wall; CPU: {_cpu_model()}"}
+                      f"N={N} points, {el:.1f} s wall, {threads} of {cores} host threads (best of 8/16/32/64); "
+                      f"CPU: {_cpu_model()}"}
 
 
 def _cpu_model() -> str:
@@ -108,8 +121,8 @@ def _cpu_model() -> str:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--points", type=int, default=200_000)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--frames-per-gpu", type=int, default=2)
@@ -215,9 +228,21 @@ def main():
                 table[gname] = {"avg_us": us, "algorithmic_bytes": alg[gname], "GBps": gbs,
                                 "frac_of_8TBps": gbs / HBM_PEAK_GBS}
         dom = max(table, key=lambda k: table[k]["avg_us"])
+        # HBM traffic per launch: PMC counters need their own rocprofv3 passes, so the value is
+        # the one measured for this same command and committed under profiles/ (null if absent or
+        # if the workload differs from the default one)
+        traffic, traffic_note = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath) and (N, H, B) == (200_000, 1024, 2):
+            t = json.load(open(tpath)).get(dom)
+            if t:
+                traffic = (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0
+                traffic_note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of this command, "
+                                "profiles/r01_pmc_render.txt; 2*FETCH+WRITE (gfx950 wide-read correction)")
         out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": table[dom]["GBps"],
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": table[dom]["frac_of_8TBps"],
-                           "traffic": None, "avg_us": table[dom]["avg_us"], "frames_per_launch": B,
+                           "traffic": traffic, "traffic_note": traffic_note,
+                           "avg_us": table[dom]["avg_us"], "frames_per_launch": B,
                            "algorithmic_bytes_per_launch": table[dom]["algorithmic_bytes"]}
         fwd_us = sum(table[k]["avg_us"] for k in ("preprocess", "binning", "render_fwd") if k in table)
         bwd_us = sum(table[k]["avg_us"] for k in ("render_bwd", "preprocess_bwd") if k in table)
