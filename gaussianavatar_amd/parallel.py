@@ -44,7 +44,9 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # GA_DIST_BACKEND=gloo lets the multi-rank code path be exercised on a box with
+            # fewer GPUs than ranks (development only; RCCL is the production backend)
+            backend = os.environ.get("GA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -12,10 +12,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared(header):
     src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b((?:gsr|galbs)_[a-z_0-9]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b((?:gsr|galbs|ganet)_[a-z_0-9]+)\s*\(", src)))
 
 
-@pytest.mark.parametrize("header,loader", [("gsr.h", "gsr"), ("galbs.h", "galbs")])
+@pytest.mark.parametrize("header,loader", [("gsr.h", "gsr"), ("galbs.h", "galbs"), ("ganet.h", "ganet")])
 def test_every_declared_symbol_is_exported(header, loader):
     from gaussianavatar_amd import _native
     lib = getattr(_native, loader)()
@@ -23,7 +23,7 @@ def test_every_declared_symbol_is_exported(header, loader):
     assert len(names) >= 7
     for n in names:
         assert hasattr(lib, n), n
-    listed = _native.GSR_SYMBOLS if loader == "gsr" else _native.GALBS_SYMBOLS
+    listed = {"gsr": _native.GSR_SYMBOLS, "galbs": _native.GALBS_SYMBOLS, "ganet": _native.GANET_SYMBOLS}[loader]
     assert set(names) == set(listed), set(names) ^ set(listed)
 
 
