@@ -153,7 +153,8 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_bn_workspace.restype = c_size_t
         lib.ganet_bn_workspace.argtypes = [c_int64, c_int32]
         lib.ganet_bn_act_fwd.restype = c_int
-        lib.ganet_bn_act_fwd.argtypes = [c_int64, c_int32, P, P, P, c_float, c_int32, P, P, P, P, c_size_t, P]
+        lib.ganet_bn_act_fwd.argtypes = [c_int64, c_int32, P, P, P, c_float, c_int32, P, P, P, P, P, c_float, P, P,
+                                         c_size_t, P]
         lib.ganet_bn_act_bwd.restype = c_int
         lib.ganet_bn_act_bwd.argtypes = [c_int64, c_int32, P, P, P, P, P, c_int32, P, P, P, P, P, c_size_t, P]
         lib.ganet_ssim_fwd.restype = c_int

@@ -113,7 +113,9 @@ bn_stats_kernel(int64_t M, int C, const float* __restrict__ x, float* __restrict
 // one wave per channel: lanes stride over the per-block partials, then a butterfly of Chan merges
 __global__ void __launch_bounds__(64)
 bn_stats_final_kernel(int nblocks, int C, float eps, const float* __restrict__ part,
-                      float* __restrict__ mean, float* __restrict__ rstd) {
+                      float* __restrict__ mean, float* __restrict__ rstd,
+                      float* __restrict__ running_mean, float* __restrict__ running_var,
+                      float momentum, long long* __restrict__ num_batches_tracked) {
   const int c = blockIdx.x;
   const int lane = threadIdx.x;
   float n = 0.f, mu = 0.f, m2 = 0.f;
@@ -129,6 +131,10 @@ bn_stats_final_kernel(int nblocks, int C, float eps, const float* __restrict__ p
   if (lane == 0) {
     mean[c] = mu;
     rstd[c] = rsqrtf(m2 / n + eps);       // biased variance, as F.batch_norm in training mode
+    // running statistics exactly as torch: unbiased variance, running = (1-m) running + m batch
+    if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mu;
+    if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (m2 / fmaxf(n - 1.0f, 1.0f));
+    if (num_batches_tracked && c == 0) num_batches_tracked[0] += 1;
   }
 }
 
@@ -303,8 +309,10 @@ size_t ganet_bn_workspace(int64_t M, int32_t C) {
 }
 
 int ganet_bn_act_fwd(int64_t M, int32_t C, const float* x, const float* gamma, const float* beta,
-                     float eps, int32_t act, float* y, float* mean, float* rstd, void* workspace,
-                     size_t workspace_bytes, void* stream_) {
+                     float eps, int32_t act, float* y, float* mean, float* rstd,
+                     float* running_mean, float* running_var, float momentum,
+                     int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes,
+                     void* stream_) {
   int rc = check_shape(M, C);
   if (rc) return rc;
   if (!x || !gamma || !beta || !y || !mean || !rstd || !workspace ||
@@ -317,7 +325,8 @@ int ganet_bn_act_fwd(int64_t M, int32_t C, const float* x, const float* gamma, c
   float* part = static_cast<float*>(workspace);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(p.nblocks), dim3(WG), 0, stream, M, C, x, part, p);
   hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(64), 0, stream, p.nblocks, C, eps, part,
-                     mean, rstd);
+                     mean, rstd, running_mean, running_var, momentum,
+                     reinterpret_cast<long long*>(num_batches_tracked));
   hipLaunchKernelGGL(bn_apply_kernel, dim3(elementwise_grid(M * C / 4)), dim3(WG), 0, stream, M, C, x,
                      gamma, beta, mean, rstd, act, y);
   return check_hip(hipGetLastError(), "ganet_bn_act_fwd");

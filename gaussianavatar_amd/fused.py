@@ -75,7 +75,7 @@ def bn_supported(C: int) -> bool:
 
 class _BnActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, act):
+    def forward(ctx, x, gamma, beta, eps, act, running_mean, running_var, momentum, num_batches_tracked):
         lib = _native.ganet()
         M, C = x.shape
         x = x.contiguous()
@@ -85,8 +85,9 @@ class _BnActFn(torch.autograd.Function):
         nbytes = lib.ganet_bn_workspace(M, C)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         _native.ganet_check(lib.ganet_bn_act_fwd(M, C, _ptr(x), _ptr(gamma), _ptr(beta), float(eps), int(act),
-                                                 _ptr(y), _ptr(mean), _ptr(rstd), _ptr(ws), nbytes,
-                                                 _stream(x.device)))
+                                                 _ptr(y), _ptr(mean), _ptr(rstd), _ptr(running_mean),
+                                                 _ptr(running_var), float(momentum), _ptr(num_batches_tracked),
+                                                 _ptr(ws), nbytes, _stream(x.device)))
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
         ctx.act = int(act)
         ctx.mark_non_differentiable(mean, rstd)
@@ -106,7 +107,7 @@ class _BnActFn(torch.autograd.Function):
         _native.ganet_check(lib.ganet_bn_act_bwd(M, C, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd),
                                                  ctx.act, _ptr(dy), _ptr(dx), _ptr(dgamma), _ptr(dbeta),
                                                  _ptr(ws), nbytes, _stream(x.device)))
-        return dx, dgamma, dbeta, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
 def batchnorm_act(x, bn: torch.nn.BatchNorm1d, act: str = "softplus"):
@@ -117,12 +118,15 @@ def batchnorm_act(x, bn: torch.nn.BatchNorm1d, act: str = "softplus"):
     if not fusable:
         y = bn(x)
         return F.softplus(y) if act == "softplus" else (F.relu(y) if act == "relu" else y)
-    y, mean, rstd = _BnActFn.apply(x, bn.weight, bn.bias, bn.eps, 1 if act == "softplus" else 0)
-    if bn.track_running_stats:
+    track = bn.track_running_stats and bn.momentum is not None
+    y, mean, rstd = _BnActFn.apply(x, bn.weight, bn.bias, bn.eps, 1 if act == "softplus" else 0,
+                                   bn.running_mean if track else None, bn.running_var if track else None,
+                                   bn.momentum if track else 0.0, bn.num_batches_tracked if track else None)
+    if bn.track_running_stats and not track:          # cumulative moving average (momentum=None): rare
         with torch.no_grad():
             n = x.shape[0]
             bn.num_batches_tracked += 1
-            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            mom = 1.0 / float(bn.num_batches_tracked)
             var_unbiased = (1.0 / (rstd * rstd) - bn.eps) * (n / max(n - 1, 1))
             bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
             bn.running_var.mul_(1 - mom).add_(var_unbiased, alpha=mom)

@@ -42,12 +42,16 @@ int ganet_linear_wgrad(int64_t M, int32_t N, int32_t K, const float* g, int64_t 
 /* ---- Training-mode BatchNorm over rows + activation, y = act(gamma * (x - mean) * rstd + beta).
  * x,y: [M,C] row-major contiguous, C <= 256. act: 0 = identity, 1 = softplus (beta=1,
  * threshold=20 as torch.nn.Softplus). Forward writes mean[C] and rstd[C] (biased variance,
- * eps as given) for the backward pass and for the running-statistics update.
+ * eps as given) for the backward pass; if running_mean / running_var / num_batches_tracked are
+ * non-NULL they are updated in place exactly as torch.nn.BatchNorm1d does in training mode
+ * (unbiased variance, running = (1 - momentum) * running + momentum * batch).
  * workspace: ganet_bn_workspace(M,C) bytes. */
 size_t ganet_bn_workspace(int64_t M, int32_t C);
 int ganet_bn_act_fwd(int64_t M, int32_t C, const float* x, const float* gamma, const float* beta,
-                     float eps, int32_t act, float* y, float* mean, float* rstd, void* workspace,
-                     size_t workspace_bytes, void* stream);
+                     float eps, int32_t act, float* y, float* mean, float* rstd,
+                     float* running_mean, float* running_var, float momentum,
+                     int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes,
+                     void* stream);
 /* Backward: dy [M,C] -> dx [M,C], dgamma[C], dbeta[C]. */
 int ganet_bn_act_bwd(int64_t M, int32_t C, const float* x, const float* gamma, const float* beta,
                      const float* mean, const float* rstd, int32_t act, const float* dy, float* dx,
