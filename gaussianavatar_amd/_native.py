@@ -37,7 +37,8 @@ class GsrBatch(ctypes.Structure):
     """struct GsrBatch (include/gsr.h): element strides between frames, 0 = shared."""
     _fields_ = [("frames", c_int32), ("means3D_stride", c_int64), ("colors_stride", c_int64),
                 ("opacities_stride", c_int64), ("scales_stride", c_int64), ("rotations_stride", c_int64),
-                ("cov3D_stride", c_int64), ("viewmatrix_stride", c_int64), ("projmatrix_stride", c_int64)]
+                ("cov3D_stride", c_int64), ("viewmatrix_stride", c_int64), ("projmatrix_stride", c_int64),
+                ("shs_stride", c_int64), ("campos_stride", c_int64)]
 
 
 _LAYOUT_FIELDS = ["total_bytes", "depth", "xy", "conic_opacity", "rgb", "cov3d", "rect",
@@ -105,7 +106,7 @@ def gsr() -> ctypes.CDLL:
         lib.gsr_profile_read.argtypes = [P, P, c_int]
         lib.gsr_profile_kernel_name.restype = c_char_p
         lib.gsr_profile_kernel_name.argtypes = [c_int]
-        if lib.gsr_abi_version() != 1:
+        if lib.gsr_abi_version() != 2:
             raise RuntimeError("libgsr_hip.so ABI version mismatch; rebuild")
         _gsr = lib
     return _gsr
@@ -138,6 +139,8 @@ def galbs() -> ctypes.CDLL:
 _ganet = None
 GANET_SYMBOLS = ["ganet_linear_wgrad_workspace", "ganet_linear_wgrad", "ganet_bn_workspace",
                  "ganet_bn_act_fwd", "ganet_bn_act_bwd", "ganet_ssim_fwd", "ganet_ssim_bwd",
+                 "ganet_mlp_stats_floats", "ganet_mlp_fwd", "ganet_mlp_stats",
+                 "ganet_wgrad_act_workspace", "ganet_wgrad_act",
                  "ganet_last_error", "ganet_abi_version"]
 
 
@@ -161,9 +164,21 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_ssim_fwd.argtypes = [c_int32, c_int32, c_int32, P, P, P, P, P]
         lib.ganet_ssim_bwd.restype = c_int
         lib.ganet_ssim_bwd.argtypes = [c_int32, c_int32, c_int32, P, P, P, P, P, P]
+        lib.ganet_mlp_stats_floats.restype = c_size_t
+        lib.ganet_mlp_stats_floats.argtypes = [c_int32]
+        lib.ganet_mlp_fwd.restype = c_int
+        lib.ganet_mlp_fwd.argtypes = [c_int64, c_int32, c_int32, c_int32, P, c_int64, P, c_int64, P, P, P, P, P,
+                                      c_int64, P, P]
+        lib.ganet_mlp_stats.restype = c_int
+        lib.ganet_mlp_stats.argtypes = [c_int64, c_int32, P, P, P, c_float, P, P, P, P, P, P, c_float, P, P]
+        lib.ganet_wgrad_act_workspace.restype = c_size_t
+        lib.ganet_wgrad_act_workspace.argtypes = [c_int64, c_int32, c_int32]
+        lib.ganet_wgrad_act.restype = c_int
+        lib.ganet_wgrad_act.argtypes = [c_int64, c_int32, c_int32, P, c_int64, P, c_int64, P, P, P, P, P,
+                                        c_size_t, P]
         lib.ganet_last_error.restype = c_char_p
         lib.ganet_abi_version.restype = c_int
-        if lib.ganet_abi_version() != 1:
+        if lib.ganet_abi_version() != 2:
             raise RuntimeError("libganet_hip.so ABI version mismatch; rebuild")
         _ganet = lib
     return _ganet

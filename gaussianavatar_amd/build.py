@@ -31,6 +31,7 @@ LIBS = {
         ("gsr_preprocess.hip", ["-ffp-contract=off"]),
         ("gsr_binning.hip", []),
         ("gsr_render.hip", []),
+        ("gsr_sh.hip", []),
     ],
     "libgalbs_hip.so": [
         ("galbs.hip", []),
@@ -39,6 +40,7 @@ LIBS = {
         ("ganet_bn.hip", []),
         ("ganet_wgrad.hip", []),
         ("ganet_ssim.hip", []),
+        ("ganet_mlp.hip", []),
     ],
 }
 

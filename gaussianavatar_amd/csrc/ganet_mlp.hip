@@ -1,0 +1,476 @@
+// ganet_mlp.hip — fused layers of the decoder MLP on fp32 MFMA ("tall-skinny" GEMMs).
+//
+//   Z[M,N] = [ X1 | softplus(scale . X2 + shift) ] [M, K1+K2] . W[N, K1+K2]^T + b
+//
+// M = 262,144 rows (UV texels), N <= 128, K1 + K2 <= 200: the Conv1d(k=1) -> BatchNorm1d -> Softplus
+// chain of /root/reference/model/modules.py:554-582 evaluated point-major. X2 is the PREVIOUS
+// layer's pre-activation; its BatchNorm (batch statistics folded to a per-column scale/shift) and
+// softplus are applied on the fly while the A operand is loaded, and the per-column sum / sum of
+// squares of the OUTPUT (what this layer's BatchNorm needs) come out of the epilogue. Normalised
+// activations are therefore never written to HBM, and neither a statistics pass nor a normalisation
+// pass over the [M,128] tensors exists any more. X1 is an un-activated operand (the decoder input,
+// and the DeepSDF-style skip of conv5 = cat[x, y4]).
+//
+// Mapping (v_mfma_f32_32x32x2_f32, exact fp32; a wave owns slabs of 32 rows x all N columns):
+//   * W stays in LDS for the whole kernel as [N][K+4] (the +4 makes ds_read_b128 conflict-free);
+//     one 512-thread workgroup per CU shares it (up to 104 KB of the 160 KB);
+//   * the A fragment of lane (row = lane & 31, h = lane >> 5) for k-block `b` is ONE 16-byte load
+//     X[row][8 b + 4 h .. +3]: the order of the reduction over k is free, so MFMA step t of the
+//     block pairs k = 8 b + t (h = 0) with k = 8 b + 4 + t (h = 1); the B fragment of that step is
+//     W[n][8 b + 4 h + t] — one ds_read_b128 per 32-column tile and k-block;
+//   * software pipeline without a second buffer: as soon as k-block b has been consumed its four
+//     registers are refilled with block b of the wave's NEXT slab, so every global load has a whole
+//     slab of MFMA work (~16k cycles) to land.
+//
+// The matching weight gradient (wgrad_act_kernel) recomputes the activation of X2 the same way:
+//   dW[n,k] = sum_m G[m,n] . softplus(scale_k X2[m,k] + shift_k),   db[n] = sum_m G[m,n]
+#include <cstdint>
+
+#include "ganet.h"
+#include "ganet_common.h"
+
+namespace ganet {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WG = 512;               // 8 waves, one workgroup per CU
+constexpr int WAVES = WG / 64;
+constexpr int SLAB = 32;              // rows per wave step
+constexpr int FWD_BLOCKS = 256;
+// llvm.amdgcn.sched.barrier mask: VALU | SALU | DS | transcendental may cross; MFMA and VMEM may not
+constexpr int kSchedMask = 0x2 | 0x4 | 0x80 | 0x100 | 0x200 | 0x400;
+
+// softplus(u) = log1p(exp(u)) (torch.nn.Softplus: beta 1, threshold 20); the series keeps full
+// relative precision where exp(u) vanishes against the 1 in 1 + e. Straight-line code on the
+// hardware exp2/log2 (no branches: this runs between MFMAs).
+__device__ __forceinline__ float softplus_f(float u) {
+  const float e = __builtin_amdgcn_exp2f(u * 1.4426950408889634f);
+  const float lg = __builtin_amdgcn_logf(1.0f + e) * 0.6931471805599453f;
+  const float ser = e * (1.0f - 0.5f * e);
+  const float sp = e < 1e-3f ? ser : lg;
+  return u > 20.0f ? u : sp;
+}
+
+template <int K1B, int K2B, int NT>
+__global__ void __attribute__((amdgpu_flat_work_group_size(WG, WG), amdgpu_waves_per_eu(2, 2)))
+mlp_fwd_kernel(int64_t M, int N, const float* __restrict__ x1, int64_t ld1,
+               const float* __restrict__ x2, int64_t ld2, const float* __restrict__ in_scale,
+               const float* __restrict__ in_shift, const float* __restrict__ W,
+               const float* __restrict__ bias, float* __restrict__ z, int64_t ldz,
+               float* __restrict__ col_part) {
+  constexpr int KB = K1B + K2B;         // k-blocks of 8
+  constexpr int K = 8 * KB;
+  constexpr int LDW4 = K / 4 + 1;       // row stride of W in LDS, in float4
+  constexpr int NP = NT * 32;
+  extern __shared__ float4 s_mem[];     // W [NP][LDW4] | scale [2*K2B] | shift [2*K2B]   (float4 units)
+  float4* s_w = s_mem;
+  float4* s_sc = s_mem + NP * LDW4;
+  float4* s_sh = s_sc + 2 * K2B;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: slab loop on SGPRs
+  const int lane = threadIdx.x & 63;
+  const int h = lane >> 5, col = lane & 31;
+
+  for (int i = threadIdx.x; i < NP * (K / 4); i += WG) {
+    const int n = i / (K / 4), k4 = i - n * (K / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < N) v = *reinterpret_cast<const float4*>(W + (size_t)n * K + 4 * k4);
+    s_w[n * LDW4 + k4] = v;
+  }
+  for (int i = threadIdx.x; i < 2 * K2B; i += WG) {
+    s_sc[i] = *reinterpret_cast<const float4*>(in_scale + 4 * i);
+    s_sh[i] = *reinterpret_cast<const float4*>(in_shift + 4 * i);
+  }
+  __syncthreads();
+
+  float csum[NT], csq[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { csum[t] = 0.f; csq[t] = 0.f; }
+
+  const int64_t nslab = (M + SLAB - 1) / SLAB;
+  const int64_t wave_global = (int64_t)blockIdx.x * WAVES + wave;
+  const int64_t wave_stride = (int64_t)gridDim.x * WAVES;
+
+  // A-operand pipeline: a ring of D k-blocks (float4 per lane each). Block i of the wave's block
+  // sequence (slab after slab) sits in slot i % D; as soon as it has been consumed the slot is
+  // refilled with block i + D (same slab, or the wave's next slab), so every global load has
+  // D x 16 MFMAs (>= 5k cycles) to land and the ring costs 4 D registers instead of 4 KB.
+  constexpr int D = (KB % 8 == 0) ? 8 : ((KB % 5 == 0) ? 5 : KB);
+  static_assert(KB % D == 0, "ring depth must divide the number of k-blocks");
+  const float *p1c = nullptr, *p2c = nullptr, *p1n = nullptr, *p2n = nullptr;
+  auto point_at = [&](int64_t slab, const float*& q1, const float*& q2) {
+    const int64_t row = min(slab * SLAB + col, M - 1);
+    if (K1B > 0) q1 = x1 + row * ld1 + 4 * h;
+    if (K2B > 0) q2 = x2 + row * ld2 + 4 * h;
+  };
+  auto load_block = [&](const float* q1, const float* q2, int b) -> float4 {
+    return b < K1B ? *reinterpret_cast<const float4*>(q1 + 8 * b)
+                   : *reinterpret_cast<const float4*>(q2 + 8 * (b - K1B));
+  };
+  float4 a[D];
+  point_at(min(wave_global, nslab - 1), p1c, p2c);
+#pragma unroll
+  for (int b = 0; b < D; ++b) a[b] = load_block(p1c, p2c, b);
+  float bias_r[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bias_r[t] = (bias && t * 32 + col < N) ? bias[t * 32 + col] : 0.f;
+
+  for (int64_t slab = wave_global; slab < nslab; slab += wave_stride) {
+    point_at(min(slab + wave_stride, nslab - 1), p1n, p2n);   // branch-free prefetch target
+    // W's fragment is the same for every slab; it must stay in LDS (the offset is made opaque:
+    // the compiler would otherwise hoist all KB x NT ds_read_b128 out of this loop and spill)
+    int woff = col * LDW4 + h;
+    int soff = h;
+    asm volatile("" : "+v"(woff), "+v"(soff));
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+    for (int b = 0; b < KB; ++b) {
+      const int slot = b % D;
+      float av0 = a[slot].x, av1 = a[slot].y, av2 = a[slot].z, av3 = a[slot].w;
+      if (b >= K1B) {
+        const float4 sc = s_sc[soff + 2 * (b - K1B)];
+        const float4 sh = s_sh[soff + 2 * (b - K1B)];
+        av0 = softplus_f(fmaf(sc.x, av0, sh.x));
+        av1 = softplus_f(fmaf(sc.y, av1, sh.y));
+        av2 = softplus_f(fmaf(sc.z, av2, sh.z));
+        av3 = softplus_f(fmaf(sc.w, av3, sh.w));
+        // the raw values are dead now: refill the slot (activated blocks). The two scheduling
+        // barriers let VALU / LDS / scalar work flow across but pin the load between this block's
+        // and the previous block's MFMAs — left alone, the scheduler sinks the refills to just
+        // before their use and exposes the full HBM latency.
+        __builtin_amdgcn_sched_barrier(kSchedMask);
+        a[slot] = (b + D < KB) ? load_block(p1c, p2c, b + D) : load_block(p1n, p2n, b + D - KB);
+        __builtin_amdgcn_sched_barrier(kSchedMask);
+      }
+      float4 bw[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bw[t] = s_w[woff + t * 32 * LDW4 + 2 * b];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bw[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bw[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av2, bw[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av3, bw[t].w, acc[t], 0, 0, 0);
+      // identity blocks feed the MFMAs straight from the slot: refill once they have been issued
+      if (b < K1B) {
+        __builtin_amdgcn_sched_barrier(kSchedMask);
+        a[slot] = (b + D < KB) ? load_block(p1c, p2c, b + D) : load_block(p1n, p2n, b + D - KB);
+        __builtin_amdgcn_sched_barrier(kSchedMask);
+      }
+    }
+    p1c = p1n; p2c = p2n;
+    // epilogue: + bias, store, column statistics. C/D layout of the 32x32 MFMA: column = lane & 31,
+    // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int64_t row0 = slab * SLAB;
+    if (row0 + SLAB <= M && N == NP) {
+      float* zr = z + (row0 + 4 * h) * ldz + col;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float bn_ = bias_r[t];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[t][r] + bn_;
+          zr[((r & 3) + 8 * (r >> 2)) * ldz + t * 32] = v;
+          csum[t] += v;
+          csq[t] = fmaf(v, v, csq[t]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int n = t * 32 + col;
+        const float bn_ = bias_r[t];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < M && n < N) {
+            const float v = acc[t][r] + bn_;
+            z[row * ldz + n] = v;
+            csum[t] += v;
+            csq[t] = fmaf(v, v, csq[t]);
+          }
+        }
+      }
+    }
+  }
+  if (col_part) {
+    // per-wave partial column sums -> [gridDim.x * WAVES][2][NP]
+    float* o = col_part + (size_t)wave_global * 2 * NP;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float s = csum[t] + __shfl_xor(csum[t], 32);
+      const float q = csq[t] + __shfl_xor(csq[t], 32);
+      if (h == 0) { o[t * 32 + col] = s; o[NP + t * 32 + col] = q; }
+    }
+  }
+}
+
+// One wave per column: sum the per-wave partials in double, then mean / rstd, the folded
+// scale = gamma * rstd and shift = beta - mean * scale the next layer's prologue applies, and the
+// running statistics exactly as F.batch_norm(training=True) updates them.
+__global__ void __launch_bounds__(64)
+mlp_stats_kernel(int nparts, int NP, int64_t M, const float* __restrict__ col_part,
+                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                 float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                 float* __restrict__ scale_out, float* __restrict__ shift_out,
+                 float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+                 long long* __restrict__ num_batches_tracked) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  double s = 0.0, q = 0.0;
+  for (int p = lane; p < nparts; p += 64) {
+    s += (double)col_part[(size_t)p * 2 * NP + n];
+    q += (double)col_part[(size_t)p * 2 * NP + NP + n];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+  if (lane == 0) {
+    const double mean = s / (double)M;
+    double var = q / (double)M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[n] * rstd;
+    mean_out[n] = (float)mean;
+    rstd_out[n] = rstd;
+    scale_out[n] = sc;
+    shift_out[n] = beta[n] - (float)mean * sc;
+    if (running_mean) {
+      const double unbiased = var * ((double)M / (double)(M > 1 ? M - 1 : 1));
+      running_mean[n] = (1.0f - momentum) * running_mean[n] + momentum * (float)mean;
+      running_var[n] = (1.0f - momentum) * running_var[n] + momentum * (float)unbiased;
+    }
+    if (n == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient with the activation of the x operand recomputed on the fly. Wave w owns k-tile w
+// (32 columns of x, activated once) and all NTW n-tiles of g; both operands are read straight from
+// HBM in MFMA fragment layout (two coalesced 128-byte segments per operand and step), the reduction
+// over M is split across workgroups and summed by wgrad_act_reduce_kernel.
+constexpr int WG_W = 256;
+constexpr int UNROLL = 4;
+
+template <int NTW>
+__global__ void __launch_bounds__(WG_W)
+wgrad_act_kernel(int64_t M, int N, int K, const float* __restrict__ g, int64_t ldg,
+                 const float* __restrict__ x, int64_t ldx, const float* __restrict__ in_scale,
+                 const float* __restrict__ in_shift, float* __restrict__ partial,
+                 int64_t rows_per_block) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int half = lane >> 5, col = lane & 31;
+  const int KT = (K + 31) / 32;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(r0 + rows_per_block, M);
+  float* out = partial + (size_t)blockIdx.x * ((size_t)N * K + N);
+  if (wave >= KT) return;
+  const int kcol = wave * 32 + col;
+  const bool kok = kcol < K;
+  const float sc = kok ? in_scale[kcol] : 0.f, sh = kok ? in_shift[kcol] : 0.f;
+
+  f32x16 acc[NTW];
+  float bias[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    bias[j] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  }
+  for (int64_t m = r0; m < r1; m += 2 * UNROLL) {
+    float a[UNROLL][NTW], b[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t row = min(m + 2 * u + half, r1 - 1);      // clamped: loads stay branch-free
+      b[u] = x[row * ldx + (kok ? kcol : 0)];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) a[u][j] = g[row * ldg + min(j * 32 + col, N - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const bool rok = m + 2 * u + half < r1;
+      const float bv = (rok && kok) ? softplus_f(fmaf(sc, b[u], sh)) : 0.f;
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const float av = (rok && j * 32 + col < N) ? a[u][j] : 0.f;
+        bias[j] += av;
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (n < N && kok) out[(size_t)n * K + kcol] = acc[j][r];
+    }
+    const float bs = bias[j] + __shfl_xor(bias[j], 32);
+    if (wave == 0 && half == 0 && j * 32 + col < N) out[(size_t)N * K + j * 32 + col] = bs;
+  }
+}
+
+// 64 outputs per block, 4 partial walkers per output, combined through LDS (deterministic)
+__global__ void __launch_bounds__(256)
+wgrad_act_reduce_kernel(int nblocks, int N, int K, const float* __restrict__ partial,
+                        float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ float s_part[4][64];
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
+  const int total = N * K + N;
+  float s0 = 0.f, s1 = 0.f;
+  if (e < total) {
+    int b = part;
+    for (; b + 4 < nblocks; b += 8) {
+      s0 += partial[(size_t)b * total + e];
+      s1 += partial[(size_t)(b + 4) * total + e];
+    }
+    if (b < nblocks) s0 += partial[(size_t)b * total + e];
+  }
+  s_part[part][lane] = s0 + s1;
+  __syncthreads();
+  if (part == 0 && e < total) {
+    const float s = (s_part[0][lane] + s_part[1][lane]) + (s_part[2][lane] + s_part[3][lane]);
+    if (e < N * K) dW[e] = s;
+    else if (db) db[e - N * K] = s;
+  }
+}
+
+int plan_wgrad(int64_t M, int64_t* rows_per_block) {
+  const int max_blocks = 512;
+  int64_t rpb = (M + max_blocks - 1) / max_blocks;
+  rpb = ((rpb + 2 * UNROLL - 1) / (2 * UNROLL)) * (2 * UNROLL);
+  if (rpb < 2 * UNROLL) rpb = 2 * UNROLL;
+  *rows_per_block = rpb;
+  return (int)((M + rpb - 1) / rpb);
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+}  // namespace ganet
+
+using namespace ganet;
+
+extern "C" {
+
+size_t ganet_mlp_stats_floats(int32_t N) {
+  if (N <= 0 || N > 128) return 0;
+  return (size_t)FWD_BLOCKS * WAVES * 2 * (size_t)(((N + 31) / 32) * 32);
+}
+
+int ganet_mlp_fwd(int64_t M, int32_t N, int32_t K1, int32_t K2, const float* x1, int64_t ld1,
+                  const float* x2, int64_t ld2, const float* in_scale, const float* in_shift,
+                  const float* W, const float* bias, float* z, int64_t ldz, float* col_part,
+                  void* stream_) {
+  const bool bad_x1 = K1 > 0 && (!x1 || (ld1 % 4) != 0 || ld1 < K1 || !aligned16(x1));
+  const bool bad_x2 = K2 > 0 && (!x2 || (ld2 % 4) != 0 || ld2 < K2 || !aligned16(x2) || !in_scale ||
+                                 !in_shift || !aligned16(in_scale) || !aligned16(in_shift));
+  if (M <= 0 || N <= 0 || N > 128 || K1 < 0 || K2 < 0 || (K1 % 8) || (K2 % 8) || K1 + K2 == 0 ||
+      bad_x1 || bad_x2 || !W || !aligned16(W) || !z || ldz < N) {
+    set_error("ganet_mlp_fwd: invalid arguments (M=%lld N=%d K1=%d K2=%d; K1, K2 multiples of 8, "
+              "row strides multiples of 4, 16-byte aligned operands)", (long long)M, N, K1, K2);
+    return 1;
+  }
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int nt = (N + 31) / 32;
+  const dim3 grid(FWD_BLOCKS), block(WG);
+#define LAUNCH(A, B, T)                                                                            \
+  do {                                                                                             \
+    constexpr int Kc = 8 * ((A) + (B));                                                            \
+    const size_t lds = ((size_t)(T) * 32 * (Kc / 4 + 1) + 4 * (B)) * sizeof(float4);               \
+    static bool attr_set = false;                                                                  \
+    if (!attr_set) {                                                                               \
+      if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<A, B, T>),    \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),     \
+                    "hipFuncSetAttribute")) return 3;                                             \
+      attr_set = true;                                                                             \
+    }                                                                                              \
+    hipLaunchKernelGGL((mlp_fwd_kernel<A, B, T>), grid, block, lds, stream, M, N, x1, ld1, x2, ld2, \
+                       in_scale, in_shift, W, bias, z, ldz, col_part);                             \
+  } while (0)
+  // the decoder's shapes: input layer (K1 = 72 = 66 padded), hidden layers (K2 = 128), the skip
+  // layer (72 + 128) and the 3/1/3-column output heads (one 32-column tile)
+  if (K1 == 72 && K2 == 0 && nt == 4) LAUNCH(9, 0, 4);
+  else if (K1 == 0 && K2 == 128 && nt == 4) LAUNCH(0, 16, 4);
+  else if (K1 == 72 && K2 == 128 && nt == 4) LAUNCH(9, 16, 4);
+  else if (K1 == 0 && K2 == 128 && nt == 1) LAUNCH(0, 16, 1);
+  else {
+    set_error("ganet_mlp_fwd: unsupported shape N=%d K1=%d K2=%d", N, K1, K2);
+    return 4;
+  }
+#undef LAUNCH
+  return check_hip(hipGetLastError(), "mlp_fwd_kernel");
+}
+
+int ganet_mlp_stats(int64_t M, int32_t N, const float* col_part, const float* gamma,
+                    const float* beta, float eps, float* mean, float* rstd, float* scale,
+                    float* shift, float* running_mean, float* running_var, float momentum,
+                    int64_t* num_batches_tracked, void* stream_) {
+  if (M <= 0 || N <= 0 || N > 128 || !col_part || !gamma || !beta || !mean || !rstd || !scale ||
+      !shift || ((running_mean == nullptr) != (running_var == nullptr))) {
+    set_error("ganet_mlp_stats: invalid arguments");
+    return 1;
+  }
+  const int np = ((N + 31) / 32) * 32;
+  hipLaunchKernelGGL(mlp_stats_kernel, dim3(N), dim3(64), 0, static_cast<hipStream_t>(stream_),
+                     FWD_BLOCKS * WAVES, np, M, col_part, gamma, beta, eps, mean, rstd, scale, shift,
+                     running_mean, running_var, momentum,
+                     reinterpret_cast<long long*>(num_batches_tracked));
+  return check_hip(hipGetLastError(), "mlp_stats_kernel");
+}
+
+size_t ganet_wgrad_act_workspace(int64_t M, int32_t N, int32_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  int64_t rpb;
+  const int nb = plan_wgrad(M, &rpb);
+  return (size_t)nb * ((size_t)N * K + N) * sizeof(float);
+}
+
+int ganet_wgrad_act(int64_t M, int32_t N, int32_t K, const float* g, int64_t ldg, const float* x,
+                    int64_t ldx, const float* in_scale, const float* in_shift, float* dW, float* db,
+                    void* workspace, size_t workspace_bytes, void* stream_) {
+  if (M <= 0 || N <= 0 || K <= 0 || !g || !x || !in_scale || !in_shift || !dW || ldg < N || ldx < K) {
+    set_error("ganet_wgrad_act: invalid arguments");
+    return 1;
+  }
+  if (N > 128 || K > 128) {
+    set_error("ganet_wgrad_act: unsupported shape N=%d K=%d (N, K <= 128)", N, K);
+    return 4;
+  }
+  int64_t rpb;
+  const int nb = plan_wgrad(M, &rpb);
+  const size_t need = (size_t)nb * ((size_t)N * K + N) * sizeof(float);
+  if (!workspace || workspace_bytes < need) {
+    set_error("ganet_wgrad_act: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return 2;
+  }
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  float* partial = static_cast<float*>(workspace);
+  const dim3 grid(nb), block(WG_W);
+  const int nt = (N + 31) / 32;
+#define LAUNCH(T) \
+  hipLaunchKernelGGL((wgrad_act_kernel<T>), grid, block, 0, stream, M, N, K, g, ldg, x, ldx, in_scale, \
+                     in_shift, partial, rpb)
+  switch (nt) {
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 3: LAUNCH(3); break;
+    default: LAUNCH(4); break;
+  }
+#undef LAUNCH
+  int rc = check_hip(hipGetLastError(), "wgrad_act_kernel");
+  if (rc) return rc;
+  const int total = N * K + N;
+  hipLaunchKernelGGL(wgrad_act_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, stream, nb, N, K,
+                     partial, dW, db);
+  return check_hip(hipGetLastError(), "wgrad_act_reduce_kernel");
+}
+
+}  // extern "C"

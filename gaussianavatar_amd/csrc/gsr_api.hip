@@ -121,9 +121,10 @@ static int debug_sync(const GsrSettings* s, hipStream_t stream, const char* what
 }
 
 static int validate(const GsrSettings* s, int32_t P, const float* means3D,
-                    const float* colors_precomp, const float* shs, const float* opacities,
-                    const float* scales, const float* rotations, const float* cov3D_precomp,
-                    void* workspace, size_t workspace_bytes, int64_t max_pairs, GsrLayout* L) {
+                    const float* colors_precomp, const float* shs, int32_t sh_coeffs,
+                    const float* opacities, const float* scales, const float* rotations,
+                    const float* cov3D_precomp, void* workspace, size_t workspace_bytes,
+                    int64_t max_pairs, GsrLayout* L) {
   if (!s) { set_error("settings is NULL"); return GSR_ERR_INVALID_ARGUMENT; }
   if (P < 0 || s->image_width <= 0 || s->image_height <= 0) {
     set_error("bad sizes: P=%d W=%d H=%d", P, s->image_width, s->image_height);
@@ -155,9 +156,16 @@ static int validate(const GsrSettings* s, int32_t P, const float* means3D,
     return GSR_ERR_INVALID_ARGUMENT;
   }
   if (shs) {
-    set_error("spherical-harmonics colours are not implemented yet; pass colors_precomp "
-              "(the reference always does: /root/reference/model/avatar_model.py:350)");
-    return GSR_ERR_UNSUPPORTED;
+    const int deg = s->sh_degree;
+    if (deg < 0 || deg > 3 || sh_coeffs < (deg + 1) * (deg + 1)) {
+      set_error("SH colours: sh_degree=%d needs 0 <= degree <= 3 and sh_coeffs >= (degree+1)^2 "
+                "(got %d)", deg, sh_coeffs);
+      return GSR_ERR_INVALID_ARGUMENT;
+    }
+    if (!s->campos) {
+      set_error("SH colours need settings->campos");
+      return GSR_ERR_INVALID_ARGUMENT;
+    }
   }
   if (P > 0 && (!means3D || !opacities)) {
     set_error("means3D / opacities are NULL");
@@ -213,7 +221,8 @@ static int make_batch(const GsrBatch* b, int32_t P, const GsrLayout& L, size_t w
   }
   const int64_t strides[] = {b->means3D_stride, b->colors_stride, b->opacities_stride,
                              b->scales_stride, b->rotations_stride, b->cov3D_stride,
-                             b->viewmatrix_stride, b->projmatrix_stride};
+                             b->viewmatrix_stride, b->projmatrix_stride, b->shs_stride,
+                             b->campos_stride};
   for (int64_t v : strides)
     if (v < 0) { set_error("batch descriptor: negative stride"); return GSR_ERR_INVALID_ARGUMENT; }
   if (b->frames > 1 && b->means3D_stride < (int64_t)P * 3) {
@@ -230,6 +239,7 @@ static int make_batch(const GsrBatch* b, int32_t P, const GsrLayout& L, size_t w
   out->means = b->means3D_stride; out->colors = b->colors_stride; out->opacities = b->opacities_stride;
   out->scales = b->scales_stride; out->rotations = b->rotations_stride; out->cov3d = b->cov3D_stride;
   out->view = b->viewmatrix_stride; out->proj = b->projmatrix_stride;
+  out->shs = b->shs_stride; out->campos = b->campos_stride;
   return GSR_OK;
 }
 
@@ -238,9 +248,8 @@ int gsr_forward_batch(const GsrSettings* s, const GsrBatch* batch, int32_t P, co
                       const float* opacities, const float* scales, const float* rotations,
                       const float* cov3D_precomp, void* workspace, size_t workspace_bytes,
                       int64_t max_pairs, float* out_color, int32_t* out_radii, void* stream_) {
-  (void)sh_coeffs;
   GsrLayout L;
-  int rc = validate(s, P, means3D, colors_precomp, shs, opacities, scales, rotations,
+  int rc = validate(s, P, means3D, colors_precomp, shs, sh_coeffs, opacities, scales, rotations,
                     cov3D_precomp, workspace, workspace_bytes, max_pairs, &L);
   if (rc) return rc;
   if (!out_color || (P > 0 && !out_radii)) {
@@ -264,6 +273,9 @@ int gsr_forward_batch(const GsrSettings* s, const GsrBatch* batch, int32_t P, co
                                         rotations, cov3D_precomp, ws, out_radii, bt, stream),
                       "preprocess")))
     return rc;
+  if (shs && (rc = check_hip(launch_sh_color(*s, d, means3D, shs, sh_coeffs, ws, bt, stream),
+                             "sh_color")))
+    return rc;
   if ((rc = debug_sync(s, stream, "preprocess (sync)"))) return rc;
   if ((rc = check_hip(launch_binning(d, ws, bt, stream), "binning"))) return rc;
   if ((rc = debug_sync(s, stream, "binning (sync)"))) return rc;
@@ -280,9 +292,8 @@ int gsr_backward_batch(const GsrSettings* s, const GsrBatch* batch, int32_t P, c
                        float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors, float* dL_dsh,
                        float* dL_dopacity, float* dL_dscales, float* dL_drotations,
                        float* dL_dcov3D, void* stream_) {
-  (void)sh_coeffs; (void)dL_dsh;
   GsrLayout L;
-  int rc = validate(s, P, means3D, colors_precomp, shs, opacities, scales, rotations,
+  int rc = validate(s, P, means3D, colors_precomp, shs, sh_coeffs, opacities, scales, rotations,
                     cov3D_precomp, workspace, workspace_bytes, max_pairs, &L);
   if (rc) return rc;
   if (!dL_dout_color || (P > 0 && !radii)) {
@@ -307,11 +318,15 @@ int gsr_backward_batch(const GsrSettings* s, const GsrBatch* batch, int32_t P, c
                                             dL_dscales, dL_drotations, dL_dcov3D, bt, stream),
                       "preprocess_bwd")))
     return rc;
+  if (shs && (dL_dsh || dL_dmeans3D) &&
+      (rc = check_hip(launch_sh_bwd(*s, d, means3D, shs, sh_coeffs, ws, dL_dsh, dL_dmeans3D, bt,
+                                    stream), "sh_bwd")))
+    return rc;
   if ((rc = debug_sync(s, stream, "preprocess_bwd (sync)"))) return rc;
   return GSR_OK;
 }
 
-static const GsrBatch kSingleFrame = {1, 0, 0, 0, 0, 0, 0, 0, 0};
+static const GsrBatch kSingleFrame = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 int gsr_forward(const GsrSettings* s, int32_t P, const float* means3D,
                 const float* colors_precomp, const float* shs, int32_t sh_coeffs,

@@ -71,7 +71,7 @@ struct Workspace {
 struct Batch {
   int frames;
   size_t ws_stride;   // bytes between per-frame workspaces
-  int64_t means, colors, opacities, scales, rotations, cov3d, view, proj;
+  int64_t means, colors, opacities, scales, rotations, cov3d, view, proj, shs, campos;
 };
 
 __host__ __device__ inline Workspace frame_ws(Workspace w, size_t bytes) {
@@ -103,6 +103,13 @@ hipError_t launch_preprocess_bwd(const GsrSettings& s, const Dims& d, const floa
                                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors,
                                  float* dL_dopacity, float* dL_dscales, float* dL_drotations,
                                  float* dL_dcov3D, const Batch& bt, hipStream_t stream);
+// SH colour path (gsr_sh.hip): runs after K1 / after K7 when `shs` is given.
+hipError_t launch_sh_color(const GsrSettings& s, const Dims& d, const float* means3D,
+                           const float* shs, int sh_coeffs, const Workspace& ws, const Batch& bt,
+                           hipStream_t stream);
+hipError_t launch_sh_bwd(const GsrSettings& s, const Dims& d, const float* means3D, const float* shs,
+                         int sh_coeffs, const Workspace& ws, float* dL_dsh, float* dL_dmeans3D,
+                         const Batch& bt, hipStream_t stream);
 // Opt-in per-kernel timing (gsr_profile_* in gsr.h).
 enum KernelId { K_PREPROCESS = 0, K_SCAN, K_SCATTER, K_SORT, K_RENDER_FWD, K_RENDER_BWD,
                 K_PREPROCESS_BWD, K_COUNT };

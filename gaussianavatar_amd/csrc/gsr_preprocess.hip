@@ -81,7 +81,8 @@ preprocess_kernel(int P, int W, int H, int gx, int gy, float tanfovx, float tanf
   if (i >= P) return;
   {   // batched launch: select this frame's inputs, workspace and outputs
     const int64_t f = blockIdx.y;
-    view += f * bt.view; proj += f * bt.proj; means3D += f * bt.means; colors += f * bt.colors;
+    view += f * bt.view; proj += f * bt.proj; means3D += f * bt.means;
+    if (colors) colors += f * bt.colors;
     opacities += f * bt.opacities;
     if (scales) { scales += f * bt.scales; rotations += f * bt.rotations; }
     if (cov3D_precomp) cov3D_precomp += f * bt.cov3d;
@@ -125,7 +126,8 @@ preprocess_kernel(int P, int W, int H, int gx, int gy, float tanfovx, float tanf
   }
 #pragma unroll
   for (int k = 0; k < 6; ++k) ws.cov3d[6 * i + k] = c6[k];
-  ws.rgb[i] = make_float4(colors[3 * i], colors[3 * i + 1], colors[3 * i + 2], 0.f);
+  // with SH input the colour is filled in by sh_color_kernel (gsr_sh.hip) right after this kernel
+  if (colors) ws.rgb[i] = make_float4(colors[3 * i], colors[3 * i + 1], colors[3 * i + 2], 0.f);
 
   const float tx = vm(V, 0, 0) * px + vm(V, 0, 1) * py + vm(V, 0, 2) * pz + vm(V, 0, 3);
   const float ty = vm(V, 1, 0) * px + vm(V, 1, 1) * py + vm(V, 1, 2) * pz + vm(V, 1, 3);

@@ -166,3 +166,224 @@ class _SsimFn(torch.autograd.Function):
 def ssim_mean(img1, img2):
     """Mean SSIM (window 11, sigma 1.5) of img1 vs img2 ([..., H, W]); differentiable w.r.t. img1."""
     return _SsimFn.apply(img1, img2)
+
+
+# ------------------------------------------------------------------------------------------------
+# Whole-decoder autograd function on the fused layer kernels (ganet_mlp.hip): no normalised
+# activation is ever stored, BatchNorm statistics come out of the producing GEMM's epilogue.
+
+_TRUNK = (("conv1", "bn1"), ("conv2", "bn2"), ("conv3", "bn3"), ("conv4", "bn4"), ("conv5", "bn5"))
+_HEAD_TAGS = ("", "N", "SH")
+_K1_PAD = 72          # decoder input (64 geometry features + 2 uv = 66 columns) padded to 8-float blocks
+
+
+def decoder_supported(dec, x) -> bool:
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and not dec.use_relu
+            and dec.hsize == 128 and dec.in_size <= _K1_PAD and x.shape[1] == dec.in_size
+            and all(getattr(dec, bn).training == dec.training and getattr(dec, bn).affine
+                    and getattr(dec, bn).momentum is not None for _, bn in _decoder_bn_layers())
+            and (dec.training or not torch.is_grad_enabled()))
+
+
+def _decoder_bn_layers():
+    out = list(_TRUNK)
+    for t in _HEAD_TAGS:
+        out += [(f"conv6{t}", f"bn6{t}"), (f"conv7{t}", f"bn7{t}")]
+    return out
+
+
+def _mlp_fwd(lib, M, N, x1, x2, scale, shift, W, bias, col_part, dev):
+    z = torch.empty((M, N), dtype=torch.float32, device=dev)
+    K1 = 0 if x1 is None else x1.shape[1]
+    K2 = 0 if x2 is None else x2.shape[1]
+    _native.ganet_check(lib.ganet_mlp_fwd(
+        M, N, K1, K2, _ptr(x1), 0 if x1 is None else x1.stride(0), _ptr(x2), 0 if x2 is None else x2.stride(0),
+        _ptr(scale), _ptr(shift), _ptr(W), _ptr(bias), _ptr(z), z.stride(0), _ptr(col_part), _stream(dev)))
+    return z
+
+
+class _DecoderFn(torch.autograd.Function):
+    """(x [M,in], flat parameter list) -> (residual [M,3], scale logits [M,1], colour logits [M,3]).
+    Parameter order: for every (conv, bn) of _decoder_bn_layers(): conv.weight, conv.bias,
+    bn.weight, bn.bias; then conv8{tag}.weight, conv8{tag}.bias per head."""
+
+    @staticmethod
+    def forward(ctx, x, dec, *params):
+        lib = _native.ganet()
+        dev = x.device
+        M, cin = x.shape
+        layers = _decoder_bn_layers()
+        nl = len(layers)
+        conv_w = [params[4 * i].squeeze(-1) for i in range(nl)]
+        conv_b = [params[4 * i + 1] for i in range(nl)]
+        gammas = [params[4 * i + 2] for i in range(nl)]
+        betas = [params[4 * i + 3] for i in range(nl)]
+        out_w = [params[4 * nl + 2 * j].squeeze(-1) for j in range(3)]
+        out_b = [params[4 * nl + 2 * j + 1] for j in range(3)]
+        training = dec.training
+        xp = torch.zeros((M, _K1_PAD), dtype=torch.float32, device=dev)
+        xp[:, :cin] = x
+        pad_w = lambda w: torch.cat([w, w.new_zeros(w.shape[0], _K1_PAD - cin)], 1).contiguous()
+        col_part = torch.empty(lib.ganet_mlp_stats_floats(128), dtype=torch.float32, device=dev) if training else None
+
+        zs, stats = [], []            # per BN layer: pre-activation, (mean, rstd, scale, shift)
+
+        def bn_stats(i, z):
+            bn = getattr(dec, layers[i][1])
+            if training:
+                mean, rstd, sc, sh = (torch.empty(128, dtype=torch.float32, device=dev) for _ in range(4))
+                track = bn.track_running_stats
+                _native.ganet_check(lib.ganet_mlp_stats(
+                    M, 128, _ptr(col_part), _ptr(gammas[i]), _ptr(betas[i]), float(bn.eps), _ptr(mean), _ptr(rstd),
+                    _ptr(sc), _ptr(sh), _ptr(bn.running_mean if track else None),
+                    _ptr(bn.running_var if track else None), float(bn.momentum),
+                    _ptr(bn.num_batches_tracked if track else None), _stream(dev)))
+            else:
+                mean = bn.running_mean
+                rstd = torch.rsqrt(bn.running_var + bn.eps)
+                sc = (gammas[i] * rstd).contiguous()
+                sh = (betas[i] - mean * sc).contiguous()
+            return mean, rstd, sc, sh
+
+        def hidden(i, x1, W, src):
+            """layer i: z = [x1 | act(src)] W^T + b, then its BatchNorm statistics."""
+            x2 = sc = sh = None
+            if src is not None:
+                x2, (_, _, sc, sh) = zs[src], stats[src]
+            z = _mlp_fwd(lib, M, 128, x1, x2, sc, sh, W, conv_b[i], col_part, dev)
+            zs.append(z)
+            stats.append(bn_stats(i, z))
+
+        w1p = pad_w(conv_w[0])
+        hidden(0, xp, w1p, None)
+        for i in (1, 2, 3):
+            hidden(i, None, conv_w[i].contiguous(), i - 1)
+        w5 = conv_w[4]
+        w5p = torch.cat([pad_w(w5[:, :cin]), w5[:, cin:]], 1).contiguous()      # [128, 72 + 128]
+        hidden(4, xp, w5p, 3)
+        outs = []
+        for j in range(3):
+            i6, i7 = 5 + 2 * j, 6 + 2 * j
+            hidden(i6, None, conv_w[i6].contiguous(), 4)
+            hidden(i7, None, conv_w[i7].contiguous(), i6)
+            _, _, sc, sh = stats[i7]
+            outs.append(_mlp_fwd(lib, M, out_w[j].shape[0], None, zs[i7], sc, sh, out_w[j].contiguous(),
+                                 out_b[j], None, dev))
+        ctx.dec = dec
+        ctx.cin = cin
+        ctx.nl = nl
+        flat_stats = [t for st in stats for t in st]
+        ctx.save_for_backward(xp, *zs, *flat_stats, *conv_w, *gammas, *betas, *out_w)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *d_outs):
+        lib = _native.ganet()
+        nl, cin = ctx.nl, ctx.cin
+        sv = ctx.saved_tensors
+        xp = sv[0]
+        zs = sv[1:1 + nl]
+        fs = sv[1 + nl:1 + 5 * nl]
+        stats = [fs[4 * i:4 * i + 4] for i in range(nl)]
+        conv_w = sv[1 + 5 * nl:1 + 6 * nl]
+        gammas = sv[1 + 6 * nl:1 + 7 * nl]
+        betas = sv[1 + 7 * nl:1 + 8 * nl]
+        out_w = sv[1 + 8 * nl:1 + 8 * nl + 3]
+        dev = xp.device
+        M = xp.shape[0]
+        g_conv_w, g_conv_b, g_gamma, g_beta = [None] * nl, [None] * nl, [None] * nl, [None] * nl
+        g_out_w, g_out_b = [None] * 3, [None] * 3
+        bn_ws_bytes = lib.ganet_bn_workspace(M, 128)
+        bn_ws = torch.empty(bn_ws_bytes, dtype=torch.uint8, device=dev)
+        wg_bytes = max(lib.ganet_wgrad_act_workspace(M, 128, 128), lib.ganet_linear_wgrad_workspace(M, 128, _K1_PAD))
+        wg_ws = torch.empty(wg_bytes, dtype=torch.uint8, device=dev)
+
+        def wgrad_act(g, src):
+            """dW [N,128], db [N] of a layer whose input is act(bn(zs[src]))."""
+            N = g.shape[1]
+            dW = torch.empty((N, 128), dtype=torch.float32, device=dev)
+            db = torch.empty(N, dtype=torch.float32, device=dev)
+            _, _, sc, sh = stats[src]
+            _native.ganet_check(lib.ganet_wgrad_act(M, N, 128, _ptr(g), g.stride(0), _ptr(zs[src]), zs[src].stride(0),
+                                                    _ptr(sc), _ptr(sh), _ptr(dW), _ptr(db), _ptr(wg_ws), wg_bytes,
+                                                    _stream(dev)))
+            return dW, db
+
+        def wgrad_x(g):
+            """dW [128, cin] of the un-activated decoder-input operand."""
+            dW = torch.empty((128, _K1_PAD), dtype=torch.float32, device=dev)
+            db = torch.empty(128, dtype=torch.float32, device=dev)
+            _native.ganet_check(lib.ganet_linear_wgrad(M, 128, _K1_PAD, _ptr(g), g.stride(0), _ptr(xp), xp.stride(0),
+                                                       _ptr(dW), _ptr(db), _ptr(wg_ws), wg_bytes, _stream(dev)))
+            return dW[:, :cin], db
+
+        def bn_bwd(i, dy):
+            """grad w.r.t. act(bn(z_i)) -> grad w.r.t. z_i (+ d gamma, d beta)."""
+            mean, rstd, _, _ = stats[i]
+            dz = torch.empty_like(dy)
+            dg = torch.empty(128, dtype=torch.float32, device=dev)
+            db = torch.empty(128, dtype=torch.float32, device=dev)
+            _native.ganet_check(lib.ganet_bn_act_bwd(M, 128, _ptr(zs[i]), _ptr(gammas[i]), _ptr(betas[i]), _ptr(mean),
+                                                     _ptr(rstd), 1, _ptr(dy), _ptr(dz), _ptr(dg), _ptr(db),
+                                                     _ptr(bn_ws), bn_ws_bytes, _stream(dev)))
+            g_gamma[i], g_beta[i] = dg, db
+            return dz
+
+        dy5 = None
+        for j in range(3):
+            i6, i7 = 5 + 2 * j, 6 + 2 * j
+            g = d_outs[j]
+            if g is None:
+                continue
+            g = g.contiguous()
+            g_out_w[j], g_out_b[j] = wgrad_act(g, i7)
+            g_out_w[j] = g_out_w[j].unsqueeze(-1)
+            dz7 = bn_bwd(i7, g @ out_w[j])
+            dW, db = wgrad_act(dz7, i6)
+            g_conv_w[i7], g_conv_b[i7] = dW.unsqueeze(-1), db
+            dz6 = bn_bwd(i6, dz7 @ conv_w[i7])
+            del dz7
+            dW, db = wgrad_act(dz6, 4)
+            g_conv_w[i6], g_conv_b[i6] = dW.unsqueeze(-1), db
+            dy5 = dz6 @ conv_w[i6] if dy5 is None else dy5.addmm_(dz6, conv_w[i6])
+            del dz6
+        dx = None
+        if dy5 is not None:
+            dz = bn_bwd(4, dy5)
+            del dy5
+            dWy, db = wgrad_act(dz, 3)
+            dWx, _ = wgrad_x(dz)
+            g_conv_w[4], g_conv_b[4] = torch.cat([dWx, dWy], 1).unsqueeze(-1), db
+            w5 = conv_w[4]
+            if ctx.needs_input_grad[0]:
+                dx = dz @ w5[:, :cin]
+            dy = dz @ w5[:, cin:]
+            for i in (3, 2, 1):
+                dz = bn_bwd(i, dy)
+                dW, db = wgrad_act(dz, i - 1)
+                g_conv_w[i], g_conv_b[i] = dW.unsqueeze(-1), db
+                dy = dz @ conv_w[i]
+            dz = bn_bwd(0, dy)
+            dW, db = wgrad_x(dz)
+            g_conv_w[0], g_conv_b[0] = dW.contiguous().unsqueeze(-1), db
+            if ctx.needs_input_grad[0]:
+                dx = dx.addmm_(dz, conv_w[0])
+        grads = []
+        for i in range(nl):
+            grads += [g_conv_w[i], g_conv_b[i], g_gamma[i], g_beta[i]]
+        for j in range(3):
+            grads += [g_out_w[j], g_out_b[j]]
+        return (dx, None) + tuple(grads)
+
+
+def decoder_mlp(dec, x):
+    """ShapeDecoder.forward_points on the fused kernels: x [M, in_size] -> (residual [M,3],
+    scale logits [M,1], colour logits [M,3]) — the sigmoids of the two heads stay with the caller."""
+    params = []
+    for conv, bn in _decoder_bn_layers():
+        c, b = getattr(dec, conv), getattr(dec, bn)
+        params += [c.weight, c.bias, b.weight, b.bias]
+    for t in _HEAD_TAGS:
+        c = getattr(dec, f"conv8{t}")
+        params += [c.weight, c.bias]
+    return _DecoderFn.apply(x, dec, *params)

@@ -93,6 +93,11 @@ class ShapeDecoder(nn.Module):
 
     def forward_points(self, x):
         """x [M, in_size] -> (residual [M,3], scale [M,1], colour [M,3])."""
+        if fused.decoder_supported(self, x):
+            # whole decoder on the fused MFMA layer kernels (activation-on-load, statistics in the
+            # epilogue); the per-layer formulation below is the CPU / unsupported-shape path
+            r, s, c = fused.decoder_mlp(self, x)
+            return r, torch.sigmoid(s), torch.sigmoid(c)
         x1 = self._layer(x, "conv1", "bn1")
         x2 = self._layer(x1, "conv2", "bn2")
         x3 = self._layer(x2, "conv3", "bn3")

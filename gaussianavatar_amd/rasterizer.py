@@ -251,7 +251,7 @@ def workspace_views(workspace: torch.Tensor, P: int, W: int, H: int, max_pairs: 
 
 
 def _forward_once(rs, means3D, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                  max_pairs):
+                  max_pairs, shs=None):
     lib = _native.gsr()
     dev = means3D.device
     P = means3D.shape[0]
@@ -264,8 +264,8 @@ def _forward_once(rs, means3D, colors_precomp, opacities, scales, rotations, cov
     radii = torch.empty((P,), dtype=torch.int32, device=dev)
     keep = []
     st = _settings_struct(rs, keep)
-    rc = lib.gsr_forward(ctypes.byref(st), P, _ptr(means3D), _ptr(colors_precomp), None, 0,
-                         _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
+    rc = lib.gsr_forward(ctypes.byref(st), P, _ptr(means3D), _ptr(colors_precomp), _ptr(shs),
+                         0 if shs is None else int(shs.shape[1]), _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
                          _ptr(workspace), nbytes, max_pairs, _ptr(color), _ptr(radii),
                          _stream_ptr(dev))
     _native.gsr_check(rc)
@@ -308,12 +308,16 @@ class _RasterizeGaussians(torch.autograd.Function):
         if not means3D.is_cuda:
             raise RuntimeError("GaussianRasterizer: tensors must live on a HIP device "
                                "(there is no CPU fallback)")
-        if sh is not None and sh.numel() > 0:
-            raise NotImplementedError(
-                "spherical-harmonics colours are not implemented yet; pass colors_precomp")
         P = means3D.shape[0]
         means3D = _f32c(means3D, (P, 3))
-        colors_precomp = _f32c(colors_precomp, (P, 3))
+        if sh is not None and sh.numel() == 0:
+            sh = None
+        if colors_precomp is not None and colors_precomp.numel() == 0 and sh is not None:
+            colors_precomp = None
+        if sh is not None:                      # [P, M, 3], M >= (sh_degree+1)^2
+            sh = _f32c(sh, (P, sh.shape[-2], 3))
+        else:
+            colors_precomp = _f32c(colors_precomp, (P, 3))
         opacities = _f32c(opacities, (P,))
         scales = _f32c(scales, (P, 3)) if scales is not None else None
         rotations = _f32c(rotations, (P, 4)) if rotations is not None else None
@@ -325,7 +329,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         max_pairs = _capacity.capacity(key)
         while True:
             color, radii, workspace, status = _forward_once(
-                rs, means3D, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, max_pairs)
+                rs, means3D, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, max_pairs, sh)
             _capacity.post(status, max_pairs, key)
             if not sync_check:
                 break
@@ -337,7 +341,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = rs
         ctx.max_pairs = max_pairs
         ctx.has_sr = scales is not None
-        ctx.save_for_backward(means3D, colors_precomp, opacities,
+        ctx.has_sh = sh is not None
+        ctx.save_for_backward(means3D, sh if sh is not None else colors_precomp, opacities,
                               scales if scales is not None else torch.empty(0, device=means3D.device),
                               rotations if rotations is not None else torch.empty(0, device=means3D.device),
                               cov3Ds_precomp if cov3Ds_precomp is not None else torch.empty(0, device=means3D.device),
@@ -366,21 +371,25 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         d_means3D = out(need[0], P, 3)
         d_means2D = out(need[1], P, 3)
-        d_colors = out(need[3], P, 3)
+        sh = None
+        if ctx.has_sh:
+            sh, colors_precomp = colors_precomp, None
+        d_sh = out(need[2] and ctx.has_sh, P, sh.shape[1] if ctx.has_sh else 0, 3)
+        d_colors = out(need[3] and not ctx.has_sh, P, 3)
         d_opac = out(need[4], P, 1)
         d_scales = out(need[5] and ctx.has_sr, P, 3)
         d_rots = out(need[6] and ctx.has_sr, P, 4)
         d_cov = out(need[7] and not ctx.has_sr, P, 6)
         keep = []
         st = _settings_struct(rs, keep)
-        rc = lib.gsr_backward(ctypes.byref(st), P, _ptr(means3D), _ptr(colors_precomp), None, 0,
-                              _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3D),
+        rc = lib.gsr_backward(ctypes.byref(st), P, _ptr(means3D), _ptr(colors_precomp), _ptr(sh),
+                              int(sh.shape[1]) if ctx.has_sh else 0, _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3D),
                               _ptr(radii), _ptr(workspace), workspace.numel(), ctx.max_pairs,
                               _ptr(grad_color), _ptr(d_means3D), _ptr(d_means2D), _ptr(d_colors),
-                              None, _ptr(d_opac), _ptr(d_scales), _ptr(d_rots), _ptr(d_cov),
+                              _ptr(d_sh), _ptr(d_opac), _ptr(d_scales), _ptr(d_rots), _ptr(d_cov),
                               _stream_ptr(dev))
         _native.gsr_check(rc)
-        return d_means3D, d_means2D, None, d_colors, d_opac, d_scales, d_rots, d_cov, None, None
+        return d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rots, d_cov, None, None
 
 
 def _frame_stride(t: torch.Tensor, frames: int, inner_shape) -> tuple:
@@ -426,7 +435,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         st = _native.GsrSettings(H, W, float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier),
                                  int(rs.sh_degree), int(bool(rs.prefiltered)), int(bool(rs.debug)),
                                  bg.data_ptr(), view.data_ptr(), proj.data_ptr(), campos.data_ptr())
-        bt = _native.GsrBatch(B, P * 3, s_col, s_opa, s_sca, s_rot, 0, s_view, s_proj)
+        bt = _native.GsrBatch(B, P * 3, s_col, s_opa, s_sca, s_rot, 0, s_view, s_proj, 0, 0)
         _capacity.poll()
         key = (P, W, H)
         sync_check = bool(rs.debug) or bool(sync_check) or not _capacity.known(key)
@@ -491,7 +500,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         st = _native.GsrSettings(H, W, float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier),
                                  int(rs.sh_degree), int(bool(rs.prefiltered)), int(bool(rs.debug)),
                                  bg.data_ptr(), view.data_ptr(), proj.data_ptr(), campos.data_ptr())
-        bt = _native.GsrBatch(B, P * 3, s_col, s_opa, s_sca, s_rot, 0, s_view, s_proj)
+        bt = _native.GsrBatch(B, P * 3, s_col, s_opa, s_sca, s_rot, 0, s_view, s_proj, 0, 0)
         _native.gsr_check(lib.gsr_backward_batch(
             ctypes.byref(st), ctypes.byref(bt), P, _ptr(means3D), _ptr(col), None, 0, _ptr(opa), _ptr(sca),
             _ptr(rot), None, _ptr(radii), _ptr(workspace), workspace.numel(), ctx.max_pairs,

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GANET_ABI_VERSION 1
+#define GANET_ABI_VERSION 2
 
 /* ---- dW[N,K] = sum_m g[m,n] x[m,k] ; db[N] = sum_m g[m,n] (db may be NULL).
  * g: [M,N] row-major with leading dimension ldg, x: [M,K] with ldx. Supported: N <= 128,
@@ -67,6 +67,36 @@ int ganet_ssim_fwd(int32_t planes, int32_t H, int32_t W, const float* img1, cons
                    float* ssim_sum, float* partials, void* stream);
 int ganet_ssim_bwd(int32_t planes, int32_t H, int32_t W, const float* img1, const float* img2,
                    const float* partials, const float* scale_dev, float* dimg1, void* stream);
+
+/* ---- fused decoder-MLP layers (ganet_mlp.hip): tall-skinny fp32-MFMA GEMMs whose A operand is
+ * activated on load and whose epilogue produces the BatchNorm statistics of the output ----------
+ *
+ *   z[M,N] = [ x1 | softplus(in_scale . x2 + in_shift) ] [M,K1+K2] . W[N,K1+K2]^T + bias
+ *
+ * x2 is the previous layer's PRE-activation; in_scale = gamma*rstd and in_shift = beta - mean*in_scale
+ * fold its BatchNorm, so Conv1d(k=1) -> BatchNorm1d -> Softplus of
+ * /root/reference/model/modules.py:554-582 runs point-major without ever storing a normalised
+ * activation. x1 (K1 columns, may be 0) is an un-activated operand (the decoder input / the skip
+ * connection into conv5). K1 and K2 are multiples of 8, row strides multiples of 4 floats, operands
+ * 16-byte aligned; supported shapes: (K1,K2,N) = (72,0,128) (0,128,128) (72,128,128) (0,128,<=32).
+ * col_part (optional, ganet_mlp_stats_floats(N) floats) receives per-wave partial column sums and
+ * sums of squares of z; ganet_mlp_stats reduces them to mean/rstd, the folded scale/shift for the
+ * NEXT layer's prologue, and updates the running statistics like F.batch_norm(training=True).
+ * ganet_wgrad_act is the matching weight gradient: dW[n,k] = sum_m g[m,n] softplus(in_scale_k
+ * x[m,k] + in_shift_k), db[n] = sum_m g[m,n] (N, K <= 128). */
+size_t ganet_mlp_stats_floats(int32_t N);
+int ganet_mlp_fwd(int64_t M, int32_t N, int32_t K1, int32_t K2, const float* x1, int64_t ld1,
+                  const float* x2, int64_t ld2, const float* in_scale, const float* in_shift,
+                  const float* W, const float* bias, float* z, int64_t ldz, float* col_part,
+                  void* stream);
+int ganet_mlp_stats(int64_t M, int32_t N, const float* col_part, const float* gamma,
+                    const float* beta, float eps, float* mean, float* rstd, float* scale,
+                    float* shift, float* running_mean, float* running_var, float momentum,
+                    int64_t* num_batches_tracked, void* stream);
+size_t ganet_wgrad_act_workspace(int64_t M, int32_t N, int32_t K);
+int ganet_wgrad_act(int64_t M, int32_t N, int32_t K, const float* g, int64_t ldg, const float* x,
+                    int64_t ldx, const float* in_scale, const float* in_shift, float* dW, float* db,
+                    void* workspace, size_t workspace_bytes, void* stream);
 
 const char* ganet_last_error(void);
 int ganet_abi_version(void);

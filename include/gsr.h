@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 1
+#define GSR_ABI_VERSION 2
 #define GSR_TILE 16              /* tile edge in pixels (BLOCK_X = BLOCK_Y = 16)       */
 #define GSR_NUM_CHANNELS 3
 
@@ -174,6 +174,8 @@ typedef struct GsrBatch {
   int64_t cov3D_stride;
   int64_t viewmatrix_stride;
   int64_t projmatrix_stride;
+  int64_t shs_stride;        /* only read when shs != NULL                                     */
+  int64_t campos_stride;     /* only read when shs != NULL                                     */
 } GsrBatch;
 
 int gsr_forward_batch(const GsrSettings* settings, const GsrBatch* batch, int32_t P,

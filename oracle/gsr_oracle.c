@@ -490,3 +490,130 @@ void gsro_preprocess_backward(int P, const real* means3D, const real* scales, co
     }
   }
 }
+
+/*
+ * A.1 step 9 / A.5(f) — view-dependent colour from real spherical harmonics (only used when the
+ * caller passes `shs` instead of `colors_precomp`; the reference never does —
+ * /root/reference/model/avatar_model.py:350-351 — but the rasterizer API offers it,
+ * gaussian_renderer/__init__.py:40-47). Published 3DGS convention: real SH basis up to degree
+ * 3 with the Condon–Shortley signs folded into the constants, evaluated in the direction
+ * normalize(mean - campos), then +0.5 and clamped at 0 (flag kept per channel for backward).
+ *   shs [P,M,3] (M >= (deg+1)^2), colors [P,3], clamped [P,3] (uint8)
+ */
+static const real SH0 = R(0.28209479177387814);
+static const real SH1 = R(0.4886025119029199);
+static const real SH2[5] = {R(1.0925484305920792), R(-1.0925484305920792), R(0.31539156525252005),
+                            R(-1.0925484305920792), R(0.5462742152960396)};
+static const real SH3[7] = {R(-0.5900435899266435), R(2.890611442640554), R(-0.4570457994644658),
+                            R(0.3731763325901154),  R(-0.4570457994644658), R(1.445305721320277),
+                            R(-0.5900435899266435)};
+
+void gsro_sh_forward(int P, int M, int deg, const real* means3D, const real* campos,
+                     const real* shs, real* colors, uint8_t* clamped) {
+  for (int i = 0; i < P; ++i) {
+    const real* sh = shs + (size_t)i * M * 3;
+    real dx = means3D[3 * i] - campos[0], dy = means3D[3 * i + 1] - campos[1],
+         dz = means3D[3 * i + 2] - campos[2];
+    const real len = SQRT(dx * dx + dy * dy + dz * dz);
+    const real x = dx / len, y = dy / len, z = dz / len;
+    for (int c = 0; c < 3; ++c) {
+      real v = SH0 * sh[0 * 3 + c];
+      if (deg > 0) {
+        v = v - SH1 * y * sh[1 * 3 + c] + SH1 * z * sh[2 * 3 + c] - SH1 * x * sh[3 * 3 + c];
+        if (deg > 1) {
+          const real xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+          v = v + SH2[0] * xy * sh[4 * 3 + c] + SH2[1] * yz * sh[5 * 3 + c] +
+              SH2[2] * (R(2.0) * zz - xx - yy) * sh[6 * 3 + c] + SH2[3] * xz * sh[7 * 3 + c] +
+              SH2[4] * (xx - yy) * sh[8 * 3 + c];
+          if (deg > 2) {
+            v = v + SH3[0] * y * (R(3.0) * xx - yy) * sh[9 * 3 + c] +
+                SH3[1] * xy * z * sh[10 * 3 + c] +
+                SH3[2] * y * (R(4.0) * zz - xx - yy) * sh[11 * 3 + c] +
+                SH3[3] * z * (R(2.0) * zz - R(3.0) * xx - R(3.0) * yy) * sh[12 * 3 + c] +
+                SH3[4] * x * (R(4.0) * zz - xx - yy) * sh[13 * 3 + c] +
+                SH3[5] * z * (xx - yy) * sh[14 * 3 + c] +
+                SH3[6] * x * (xx - R(3.0) * yy) * sh[15 * 3 + c];
+          }
+        }
+      }
+      v += R(0.5);
+      clamped[3 * i + c] = v < 0;
+      colors[3 * i + c] = v < 0 ? 0 : v;
+    }
+  }
+}
+
+/* Backward of the above: dL_dsh [P,M,3] fully overwritten (zeros beyond the active degree);
+ * the view-direction term is ADDED to dL_dmeans3D [P,3]. */
+void gsro_sh_backward(int P, int M, int deg, const real* means3D, const real* campos,
+                      const real* shs, const uint8_t* clamped, const real* dL_dcolors,
+                      real* dL_dsh, real* dL_dmeans3D) {
+  for (int i = 0; i < P; ++i) {
+    const real* sh = shs + (size_t)i * M * 3;
+    real* dsh = dL_dsh + (size_t)i * M * 3;
+    for (int k = 0; k < M * 3; ++k) dsh[k] = 0;
+    const real dx = means3D[3 * i] - campos[0], dy = means3D[3 * i + 1] - campos[1],
+               dz = means3D[3 * i + 2] - campos[2];
+    const real sum2 = dx * dx + dy * dy + dz * dz;
+    const real len = SQRT(sum2);
+    const real x = dx / len, y = dy / len, z = dz / len;
+    real gdir[3] = {0, 0, 0}; /* dL/d(x,y,z) of the unit direction */
+    for (int c = 0; c < 3; ++c) {
+      const real g = clamped[3 * i + c] ? 0 : dL_dcolors[3 * i + c];
+      real gx = 0, gy = 0, gz = 0;
+      dsh[0 * 3 + c] = SH0 * g;
+      if (deg > 0) {
+        dsh[1 * 3 + c] = -SH1 * y * g;
+        dsh[2 * 3 + c] = SH1 * z * g;
+        dsh[3 * 3 + c] = -SH1 * x * g;
+        gx = -SH1 * sh[3 * 3 + c];
+        gy = -SH1 * sh[1 * 3 + c];
+        gz = SH1 * sh[2 * 3 + c];
+        if (deg > 1) {
+          const real xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+          dsh[4 * 3 + c] = SH2[0] * xy * g;
+          dsh[5 * 3 + c] = SH2[1] * yz * g;
+          dsh[6 * 3 + c] = SH2[2] * (R(2.0) * zz - xx - yy) * g;
+          dsh[7 * 3 + c] = SH2[3] * xz * g;
+          dsh[8 * 3 + c] = SH2[4] * (xx - yy) * g;
+          gx += SH2[0] * y * sh[4 * 3 + c] + SH2[2] * R(2.0) * -x * sh[6 * 3 + c] +
+                SH2[3] * z * sh[7 * 3 + c] + SH2[4] * R(2.0) * x * sh[8 * 3 + c];
+          gy += SH2[0] * x * sh[4 * 3 + c] + SH2[1] * z * sh[5 * 3 + c] +
+                SH2[2] * R(2.0) * -y * sh[6 * 3 + c] + SH2[4] * R(2.0) * -y * sh[8 * 3 + c];
+          gz += SH2[1] * y * sh[5 * 3 + c] + SH2[2] * R(4.0) * z * sh[6 * 3 + c] +
+                SH2[3] * x * sh[7 * 3 + c];
+          if (deg > 2) {
+            dsh[9 * 3 + c] = SH3[0] * y * (R(3.0) * xx - yy) * g;
+            dsh[10 * 3 + c] = SH3[1] * xy * z * g;
+            dsh[11 * 3 + c] = SH3[2] * y * (R(4.0) * zz - xx - yy) * g;
+            dsh[12 * 3 + c] = SH3[3] * z * (R(2.0) * zz - R(3.0) * xx - R(3.0) * yy) * g;
+            dsh[13 * 3 + c] = SH3[4] * x * (R(4.0) * zz - xx - yy) * g;
+            dsh[14 * 3 + c] = SH3[5] * z * (xx - yy) * g;
+            dsh[15 * 3 + c] = SH3[6] * x * (xx - R(3.0) * yy) * g;
+            gx += SH3[0] * sh[9 * 3 + c] * R(6.0) * xy + SH3[1] * sh[10 * 3 + c] * yz +
+                  SH3[2] * sh[11 * 3 + c] * -R(2.0) * xy + SH3[3] * sh[12 * 3 + c] * -R(6.0) * xz +
+                  SH3[4] * sh[13 * 3 + c] * (R(4.0) * zz - R(3.0) * xx - yy) +
+                  SH3[5] * sh[14 * 3 + c] * R(2.0) * xz +
+                  SH3[6] * sh[15 * 3 + c] * (R(3.0) * xx - R(3.0) * yy);
+            gy += SH3[0] * sh[9 * 3 + c] * (R(3.0) * xx - R(3.0) * yy) +
+                  SH3[1] * sh[10 * 3 + c] * xz +
+                  SH3[2] * sh[11 * 3 + c] * (R(4.0) * zz - xx - R(3.0) * yy) +
+                  SH3[3] * sh[12 * 3 + c] * -R(6.0) * yz + SH3[4] * sh[13 * 3 + c] * -R(2.0) * xy +
+                  SH3[5] * sh[14 * 3 + c] * -R(2.0) * yz + SH3[6] * sh[15 * 3 + c] * -R(6.0) * xy;
+            gz += SH3[1] * sh[10 * 3 + c] * xy + SH3[2] * sh[11 * 3 + c] * R(8.0) * yz +
+                  SH3[3] * sh[12 * 3 + c] * (R(6.0) * zz - R(3.0) * xx - R(3.0) * yy) +
+                  SH3[4] * sh[13 * 3 + c] * R(8.0) * xz + SH3[5] * sh[14 * 3 + c] * (xx - yy);
+          }
+        }
+      }
+      gdir[0] += gx * g;
+      gdir[1] += gy * g;
+      gdir[2] += gz * g;
+    }
+    /* through dir = d / |d| */
+    const real inv32 = R(1.0) / SQRT(sum2 * sum2 * sum2);
+    dL_dmeans3D[3 * i + 0] += ((sum2 - dx * dx) * gdir[0] - dy * dx * gdir[1] - dz * dx * gdir[2]) * inv32;
+    dL_dmeans3D[3 * i + 1] += (-dx * dy * gdir[0] + (sum2 - dy * dy) * gdir[1] - dz * dy * gdir[2]) * inv32;
+    dL_dmeans3D[3 * i + 2] += (-dx * dz * gdir[0] - dy * dz * gdir[1] + (sum2 - dz * dz) * gdir[2]) * inv32;
+  }
+}

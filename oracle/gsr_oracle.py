@@ -72,10 +72,47 @@ class RasterOracle:
             a = a.reshape(shape)
         return a
 
+    def sh_colors(self, means3D, shs, sh_degree, campos):
+        """View-dependent colours from SH coefficients shs [P,M,3] -> (colors [P,3], clamped [P,3])."""
+        P = int(np.asarray(means3D).shape[0])
+        shs = self._arr(shs)
+        M = int(shs.shape[1])
+        assert shs.shape == (P, M, 3) and M >= (int(sh_degree) + 1) ** 2
+        means3D = self._arr(means3D, (P, 3))
+        campos = self._arr(campos, (3,))
+        colors = np.zeros((P, 3), self.dtype)
+        clamped = np.zeros((P, 3), np.uint8)
+        self.lib.gsro_sh_forward(P, M, int(sh_degree), _p(means3D), _p(campos), _p(shs), _p(colors),
+                                 _p(clamped))
+        return colors, clamped
+
+    def sh_backward(self, means3D, shs, sh_degree, campos, clamped, dL_dcolors):
+        """-> (dL_dsh [P,M,3], view-direction term of dL_dmeans3D [P,3])."""
+        P = int(np.asarray(means3D).shape[0])
+        shs = self._arr(shs)
+        M = int(shs.shape[1])
+        means3D = self._arr(means3D, (P, 3))
+        campos = self._arr(campos, (3,))
+        clamped = np.ascontiguousarray(clamped, dtype=np.uint8)
+        g = self._arr(dL_dcolors, (P, 3))
+        dsh = np.zeros((P, M, 3), self.dtype)
+        dmean = np.zeros((P, 3), self.dtype)
+        self.lib.gsro_sh_backward(P, M, int(sh_degree), _p(means3D), _p(campos), _p(shs), _p(clamped),
+                                  _p(g), _p(dsh), _p(dmean))
+        return dsh, dmean
+
     def forward(self, means3D, colors, opacities, scales=None, rotations=None, cov3D_precomp=None,
-                *, viewmatrix, projmatrix, bg, W, H, tanfovx, tanfovy, scale_modifier=1.0):
+                *, viewmatrix, projmatrix, bg, W, H, tanfovx, tanfovy, scale_modifier=1.0,
+                shs=None, sh_degree=0, campos=None):
         P = int(np.asarray(means3D).shape[0])
         means3D = self._arr(means3D, (P, 3))
+        sh_state = None
+        if shs is not None:
+            assert colors is None, "exactly one of colors / shs"
+            shs = self._arr(shs)
+            campos = self._arr(campos, (3,))
+            colors, clamped = self.sh_colors(means3D, shs, sh_degree, campos)
+            sh_state = dict(shs=shs, sh_degree=int(sh_degree), campos=campos, clamped=clamped)
         colors = self._arr(colors, (P, 3))
         opacities = self._arr(opacities, (P,))
         scales = self._arr(scales, (P, 3)) if scales is not None else None
@@ -90,7 +127,7 @@ class RasterOracle:
                        _p(bg), _p(view), _p(proj))
         st = dict(P=P, W=int(W), H=int(H), cam=cam, _keep=(bg, view, proj), bg=bg,
                   means3D=means3D, colors=colors, opacities=opacities, scales=scales,
-                  rotations=rotations, cov3D_precomp=cov3D_precomp)
+                  rotations=rotations, cov3D_precomp=cov3D_precomp, sh=sh_state)
         f = self.dtype
         st["depth"] = np.zeros(P, f)
         st["xy"] = np.zeros((P, 2), f)
@@ -144,6 +181,13 @@ class RasterOracle:
                                           ctypes.byref(st["cam"]), _p(out["dmean2D"]),
                                           _p(out["dconic"]), _p(out["dmeans3D"]),
                                           _p(out["dcov3D"]), _p(out["dscales"]), _p(out["drots"]))
+        if st.get("sh") is not None:
+            sh = st["sh"]
+            M = int(sh["shs"].shape[1])
+            out["dsh"] = np.zeros((P, M, 3), f)
+            self.lib.gsro_sh_backward(P, M, sh["sh_degree"], _p(st["means3D"]), _p(sh["campos"]),
+                                      _p(sh["shs"]), _p(sh["clamped"]), _p(out["dcolors"]),
+                                      _p(out["dsh"]), _p(out["dmeans3D"]))
         # API shape of the means2D gradient: [P,3] with a zero z column
         out["dmeans2D"] = np.concatenate([out["dmean2D"], np.zeros((P, 1), f)], axis=1)
         return out

@@ -165,3 +165,30 @@ def rasterize(means3D, colors, opacities, scales, rotations, *, viewmatrix, proj
                xy=torch.stack([px, py], 1).detach(), depth=tz.detach(),
                conic=torch.stack([A, B, C], 1).detach(), visible=vis)
     return color, aux
+
+
+# Real SH basis of the published 3DGS convention (Condon–Shortley signs folded in), as a list of
+# monomial expressions: sh_colors() below is the autograd restatement of oracle/gsr_oracle.c's
+# gsro_sh_forward / gsro_sh_backward.
+def _sh_basis(x, y, z):
+    xx, yy, zz = x * x, y * y, z * z
+    one = torch.ones_like(x)
+    return [
+        0.28209479177387814 * one,
+        -0.4886025119029199 * y, 0.4886025119029199 * z, -0.4886025119029199 * x,
+        1.0925484305920792 * x * y, -1.0925484305920792 * y * z,
+        0.31539156525252005 * (2 * zz - xx - yy), -1.0925484305920792 * x * z,
+        0.5462742152960396 * (xx - yy),
+        -0.5900435899266435 * y * (3 * xx - yy), 2.890611442640554 * x * y * z,
+        -0.4570457994644658 * y * (4 * zz - xx - yy), 0.3731763325901154 * z * (2 * zz - 3 * xx - 3 * yy),
+        -0.4570457994644658 * x * (4 * zz - xx - yy), 1.445305721320277 * z * (xx - yy),
+        -0.5900435899266435 * x * (xx - 3 * yy)]
+
+
+def sh_colors(means3D, shs, sh_degree, campos):
+    """colors [P,3] = max(0, sum_k basis_k(normalize(mean - campos)) * shs[:, k] + 0.5)."""
+    d = means3D - campos.to(means3D.dtype).reshape(1, 3)
+    d = d / d.norm(dim=1, keepdim=True)
+    basis = torch.stack(_sh_basis(d[:, 0], d[:, 1], d[:, 2])[:(sh_degree + 1) ** 2], dim=1)   # [P,K]
+    raw = (basis.unsqueeze(-1) * shs[:, :basis.shape[1]]).sum(1) + 0.5
+    return torch.clamp_min(raw, 0.0)

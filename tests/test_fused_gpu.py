@@ -159,3 +159,124 @@ def test_decoder_gpu_fused_equals_cpu_torch():
     gmax = max(float(p.grad.abs().max()) for p in dec.parameters())
     for (n, p), (_, q) in zip(dec.named_parameters(), dec_g.named_parameters()):
         assert float((p.grad - q.grad.cpu()).abs().max()) <= 2e-3 * max(1.0, gmax), n
+
+
+def _softplus_bn(z, sc, sh):
+    return F.softplus(z.double() * sc.double() + sh.double())
+
+
+@pytest.mark.parametrize("M,K1,K2,N", [(262144, 0, 128, 128), (40000, 72, 0, 128), (33333, 72, 128, 128),
+                                       (70001, 0, 128, 3), (4100, 0, 128, 1), (31, 0, 128, 128)])
+def test_mlp_fwd_layer_matches_torch(M, K1, K2, N):
+    """ganet_mlp_fwd: activation-on-load GEMM + column statistics, incl. ragged M (tail slab),
+    the skip layer's two operands and the narrow output heads."""
+    from gaussianavatar_amd import _native, fused
+    lib = _native.ganet()
+    torch.manual_seed(M % 89)
+    dev = "cuda"
+    x1 = torch.randn(M, K1, device=dev) if K1 else None
+    x2 = (torch.randn(M, K2, device=dev) * 2 + torch.linspace(-4, 4, K2, device=dev)) if K2 else None
+    sc = torch.empty(K2, device=dev).uniform_(0.3, 2.0) if K2 else None
+    sh = torch.empty(K2, device=dev).uniform_(-25, 25) if K2 else None          # both softplus tails
+    W = torch.randn(N, K1 + K2, device=dev) * 0.1
+    b = torch.randn(N, device=dev)
+    part = torch.zeros(lib.ganet_mlp_stats_floats(N), device=dev)
+    z = fused._mlp_fwd(lib, M, N, x1, x2, sc, sh, W, b, part, dev)
+    cols = []
+    if K1:
+        cols.append(x1.double())
+    if K2:
+        cols.append(_softplus_bn(x2, sc, sh))
+    ref = torch.cat(cols, 1) @ W.double().t() + b.double()
+    tol = 2e-5 * float(ref.abs().max()) + 1e-5
+    assert float((z.double() - ref).abs().max()) <= tol
+    NP = ((N + 31) // 32) * 32
+    p = part.reshape(-1, 2, NP).double().sum(0)
+    assert float((p[0, :N] - ref.sum(0)).abs().max()) <= 1e-4 * float(ref.abs().sum(0).max()) + 1e-3
+    assert float((p[1, :N] - (ref ** 2).sum(0)).abs().max()) <= 1e-4 * float((ref ** 2).sum(0).max()) + 1e-3
+    # statistics -> folded scale/shift and running statistics, as F.batch_norm(training=True)
+    if N == 128:
+        bn = torch.nn.BatchNorm1d(N).to(dev).train()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 2.0)
+            bn.bias.uniform_(-1, 1)
+        mean, rstd, s2, h2 = (torch.empty(N, device=dev) for _ in range(4))
+        rm, rv, nbt = bn.running_mean.clone(), bn.running_var.clone(), bn.num_batches_tracked.clone()
+        _native.ganet_check(lib.ganet_mlp_stats(M, N, fused._ptr(part), fused._ptr(bn.weight), fused._ptr(bn.bias),
+                                                bn.eps, fused._ptr(mean), fused._ptr(rstd), fused._ptr(s2),
+                                                fused._ptr(h2), fused._ptr(rm), fused._ptr(rv), bn.momentum,
+                                                fused._ptr(nbt), fused._stream(torch.device(dev))))
+        y_ref = bn(z)
+        torch.testing.assert_close(z * s2 + h2, y_ref, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(rm, bn.running_mean, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(rv, bn.running_var, rtol=1e-4, atol=1e-6)
+        assert int(nbt) == int(bn.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("M,N", [(262144, 128), (50001, 128), (70001, 3), (4097, 1)])
+def test_wgrad_act_matches_torch(M, N):
+    from gaussianavatar_amd import _native, fused
+    lib = _native.ganet()
+    torch.manual_seed(N + M % 13)
+    dev = "cuda"
+    x = torch.randn(M, 128, device=dev) * 2
+    sc = torch.empty(128, device=dev).uniform_(0.3, 2.0)
+    sh = torch.empty(128, device=dev).uniform_(-3, 3)
+    g = torch.randn(M, N, device=dev)
+    dW = torch.empty(N, 128, device=dev)
+    db = torch.empty(N, device=dev)
+    nbytes = lib.ganet_wgrad_act_workspace(M, N, 128)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _native.ganet_check(lib.ganet_wgrad_act(M, N, 128, fused._ptr(g), g.stride(0), fused._ptr(x), x.stride(0),
+                                            fused._ptr(sc), fused._ptr(sh), fused._ptr(dW), fused._ptr(db),
+                                            fused._ptr(ws), nbytes, fused._stream(torch.device(dev))))
+    ref = g.double().t() @ _softplus_bn(x, sc, sh)
+    assert float((dW.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-4
+    rb = g.double().sum(0)
+    assert float((db.double() - rb).abs().max()) <= 2e-5 * float(rb.abs().max()) + 1e-4
+
+
+@pytest.mark.parametrize("M", [20000, 4099])
+def test_fused_decoder_equals_per_layer_formulation(M, monkeypatch):
+    """The whole-decoder function on the fused layer kernels (reference widths: 66 -> 128 x 5 -> three
+    heads) against the per-layer formulation (vendor GEMM + fused BN kernels) on the same device:
+    outputs, every parameter gradient, the input gradient and the BatchNorm running statistics."""
+    import copy
+    from gaussianavatar_amd import fused
+    from gaussianavatar_amd.network import ShapeDecoder
+    torch.manual_seed(1)
+    dec_a = ShapeDecoder(66, 128).cuda().train()
+    with torch.no_grad():
+        for m in dec_a.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.5, 0.5)
+    dec_b = copy.deepcopy(dec_a)
+    x_a = torch.randn(M, 66, device="cuda", requires_grad=True)
+    x_b = x_a.detach().clone().requires_grad_(True)
+    w = [torch.randn(M, k, device="cuda") for k in (3, 1, 3)]
+    assert fused.decoder_supported(dec_a, x_a)
+    outs_a = dec_a.forward_points(x_a)
+    sum((o * wi).sum() for o, wi in zip(outs_a, w)).backward()
+    monkeypatch.setattr(fused, "decoder_supported", lambda dec, x: False)
+    outs_b = dec_b.forward_points(x_b)
+    sum((o * wi).sum() for o, wi in zip(outs_b, w)).backward()
+    for a, b in zip(outs_a, outs_b):
+        torch.testing.assert_close(a, b, rtol=1e-3, atol=2e-4)
+    gmax = max(float(p.grad.abs().max()) for p in dec_b.parameters())
+    for (n, p), (_, q) in zip(dec_a.named_parameters(), dec_b.named_parameters()):
+        assert p.grad is not None, n
+        assert float((p.grad - q.grad).abs().max()) <= 2e-3 * max(1.0, gmax), (n, float((p.grad - q.grad).abs().max()), gmax)
+    assert float((x_a.grad - x_b.grad).abs().max()) <= 2e-3 * max(1e-3, float(x_b.grad.abs().max()))
+    for (n, p), (_, q) in zip(dec_a.named_buffers(), dec_b.named_buffers()):
+        torch.testing.assert_close(p.float(), q.float(), rtol=1e-4, atol=1e-5, msg=n)
+    # evaluation mode (running statistics) runs on the same kernels
+    dec_a.eval(); dec_b.eval()
+    with torch.no_grad():
+        monkeypatch.undo()
+        assert fused.decoder_supported(dec_a, x_a.detach())
+        e_a = dec_a.forward_points(x_a.detach())
+        monkeypatch.setattr(fused, "decoder_supported", lambda dec, x: False)
+        e_b = dec_b.forward_points(x_b.detach())
+    for a, b in zip(e_a, e_b):
+        torch.testing.assert_close(a, b, rtol=1e-3, atol=2e-4)

@@ -189,3 +189,28 @@ def test_raster_oracle_regression_vectors(raster_oracle):
         b = raster_oracle.backward(st, g[f"{name}_g"])
         for k in ("dmeans3D", "dcolors", "dopacity", "dscales", "drots"):
             np.testing.assert_allclose(b[k], g[f"{name}_{k}"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_sh_oracle_matches_autograd_restatement(raster_oracle_f64, deg):
+    """SH colour path (API completeness; the reference itself always passes colors_precomp):
+    analytic C backward vs autograd of the independent torch formulation, float64."""
+    import torch
+    from oracle import raster_torch
+    rng = np.random.default_rng(deg)
+    P, M = 300, 16
+    means = rng.normal(0, 1, (P, 3))
+    campos = np.array([0.1, 0.3, 2.5])
+    shs = rng.normal(0, 2.0, (P, M, 3))
+    col, clamped = raster_oracle_f64.sh_colors(means, shs, deg, campos)
+    assert 0.05 < clamped.mean() < 0.6          # both branches of the clamp are exercised
+    mt = torch.tensor(means, dtype=torch.float64, requires_grad=True)
+    st = torch.tensor(shs, dtype=torch.float64, requires_grad=True)
+    ct = raster_torch.sh_colors(mt, st, deg, torch.tensor(campos))
+    np.testing.assert_allclose(col, ct.detach().numpy(), rtol=1e-12, atol=1e-12)
+    g = rng.normal(0, 1, (P, 3))
+    ct.backward(torch.tensor(g))
+    dsh, dmean = raster_oracle_f64.sh_backward(means, shs, deg, campos, clamped, g)
+    np.testing.assert_allclose(dsh, st.grad.numpy(), rtol=1e-10, atol=1e-12)
+    mg = mt.grad.numpy() if mt.grad is not None else np.zeros((P, 3))   # degree 0 is view-independent
+    np.testing.assert_allclose(dmean, mg, rtol=1e-9, atol=1e-11)
