@@ -140,7 +140,8 @@ _ganet = None
 GANET_SYMBOLS = ["ganet_linear_wgrad_workspace", "ganet_linear_wgrad", "ganet_bn_workspace",
                  "ganet_bn_act_fwd", "ganet_bn_act_bwd", "ganet_ssim_fwd", "ganet_ssim_bwd",
                  "ganet_mlp_stats_floats", "ganet_mlp_fwd", "ganet_mlp_stats",
-                 "ganet_wgrad_act_workspace", "ganet_wgrad_act",
+                 "ganet_wgrad_act_workspace", "ganet_wgrad_act", "ganet_mlp_bwd_data_parts",
+                 "ganet_mlp_head_bwd_parts", "ganet_mlp_bwd_data", "ganet_mlp_head_bwd", "ganet_mlp_bwd_stats",
                  "ganet_last_error", "ganet_abi_version"]
 
 
@@ -174,8 +175,17 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_wgrad_act_workspace.restype = c_size_t
         lib.ganet_wgrad_act_workspace.argtypes = [c_int64, c_int32, c_int32]
         lib.ganet_wgrad_act.restype = c_int
-        lib.ganet_wgrad_act.argtypes = [c_int64, c_int32, c_int32, P, c_int64, P, c_int64, P, P, P, P, P,
-                                        c_size_t, P]
+        lib.ganet_wgrad_act.argtypes = [c_int64, c_int32, c_int32, P, c_int64, P, c_int64, P, P, c_int64, P, P, P,
+                                        P, P, c_size_t, P]
+        lib.ganet_mlp_bwd_data_parts.restype = c_int32
+        lib.ganet_mlp_head_bwd_parts.restype = c_int32
+        lib.ganet_mlp_bwd_data.restype = c_int
+        lib.ganet_mlp_bwd_data.argtypes = [c_int64, c_int32, P, c_int64, P, c_int64, P, P, P, c_int64, c_int32, P,
+                                           c_int64, P, P, P, P]
+        lib.ganet_mlp_head_bwd.restype = c_int
+        lib.ganet_mlp_head_bwd.argtypes = [c_int64, c_int32, P, P, P, c_int64, P, P, P, c_int64, P, P]
+        lib.ganet_mlp_bwd_stats.restype = c_int
+        lib.ganet_mlp_bwd_stats.argtypes = [c_int64, c_int32, P, P, P, P, P, P, P, P]
         lib.ganet_last_error.restype = c_char_p
         lib.ganet_abi_version.restype = c_int
         if lib.ganet_abi_version() != 2:

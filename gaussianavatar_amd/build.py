@@ -41,6 +41,7 @@ LIBS = {
         ("ganet_wgrad.hip", []),
         ("ganet_ssim.hip", []),
         ("ganet_mlp.hip", []),
+        ("ganet_mlp_bwd.hip", []),
     ],
 }
 

@@ -28,31 +28,16 @@
 
 #include "ganet.h"
 #include "ganet_common.h"
+#include "ganet_mlp_common.h"
 
 namespace ganet {
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
 constexpr int WG = 512;               // 8 waves, one workgroup per CU
 constexpr int WAVES = WG / 64;
 constexpr int SLAB = 32;              // rows per wave step
 constexpr int FWD_BLOCKS = 256;
-// llvm.amdgcn.sched.barrier mask: VALU | SALU | DS | transcendental may cross; MFMA and VMEM may not
-constexpr int kSchedMask = 0x2 | 0x4 | 0x80 | 0x100 | 0x200 | 0x400;
-
-// softplus(u) = log1p(exp(u)) (torch.nn.Softplus: beta 1, threshold 20); the series keeps full
-// relative precision where exp(u) vanishes against the 1 in 1 + e. Straight-line code on the
-// hardware exp2/log2 (no branches: this runs between MFMAs).
-__device__ __forceinline__ float softplus_f(float u) {
-  const float e = __builtin_amdgcn_exp2f(u * 1.4426950408889634f);
-  const float lg = __builtin_amdgcn_logf(1.0f + e) * 0.6931471805599453f;
-  const float ser = e * (1.0f - 0.5f * e);
-  const float sp = e < 1e-3f ? ser : lg;
-  return u > 20.0f ? u : sp;
-}
-
 template <int K1B, int K2B, int NT>
 __global__ void __attribute__((amdgpu_flat_work_group_size(WG, WG), amdgpu_waves_per_eu(2, 2)))
 mlp_fwd_kernel(int64_t M, int N, const float* __restrict__ x1, int64_t ld1,
@@ -212,27 +197,32 @@ mlp_fwd_kernel(int64_t M, int N, const float* __restrict__ x1, int64_t ld1,
   }
 }
 
-// One wave per column: sum the per-wave partials in double, then mean / rstd, the folded
+// One workgroup per column: sum the per-wave partials in double, then mean / rstd, the folded
 // scale = gamma * rstd and shift = beta - mean * scale the next layer's prologue applies, and the
 // running statistics exactly as F.batch_norm(training=True) updates them.
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 mlp_stats_kernel(int nparts, int NP, int64_t M, const float* __restrict__ col_part,
                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                  float* __restrict__ mean_out, float* __restrict__ rstd_out,
                  float* __restrict__ scale_out, float* __restrict__ shift_out,
                  float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
                  long long* __restrict__ num_batches_tracked) {
-  const int n = blockIdx.x, lane = threadIdx.x;
+  __shared__ double s_s[256], s_q[256];
+  const int n = blockIdx.x;
   double s = 0.0, q = 0.0;
-  for (int p = lane; p < nparts; p += 64) {
+  for (int p = threadIdx.x; p < nparts; p += 256) {
     s += (double)col_part[(size_t)p * 2 * NP + n];
     q += (double)col_part[(size_t)p * 2 * NP + NP + n];
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-  if (lane == 0) {
-    const double mean = s / (double)M;
-    double var = q / (double)M - mean * mean;
+  s_s[threadIdx.x] = s; s_q[threadIdx.x] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { s_s[threadIdx.x] += s_s[threadIdx.x + o]; s_q[threadIdx.x] += s_q[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double mean = s_s[0] / (double)M;
+    double var = s_q[0] / (double)M - mean * mean;
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float sc = gamma[n] * rstd;
@@ -250,69 +240,159 @@ mlp_stats_kernel(int nparts, int NP, int64_t M, const float* __restrict__ col_pa
 }
 
 // ---------------------------------------------------------------------------------------------
-// Weight gradient with the activation of the x operand recomputed on the fly. Wave w owns k-tile w
-// (32 columns of x, activated once) and all NTW n-tiles of g; both operands are read straight from
-// HBM in MFMA fragment layout (two coalesced 128-byte segments per operand and step), the reduction
-// over M is split across workgroups and summed by wgrad_act_reduce_kernel.
+// Weight gradient with the activation of the x operand recomputed on the fly.
+//
+//   dW[n,k] = sum_m g[m,n] . act(x[m,k]),  db[n] = sum_m g[m,n]      (reduction over M = 262,144)
+//
+// ONE wave accumulates the whole dW tile (up to 128 x 128 = 16 MFMA accumulators = 256 registers,
+// which the compiler places in AGPRs) over its own range of rows: one reduction step (two rows)
+// costs NTW + KTW dword loads per lane for NTW x KTW MFMAs — every g and x element is loaded exactly
+// once chip-wide, in MFMA fragment layout straight from HBM (two coalesced 128-byte segments per
+// operand tile and step), and x is activated once. One wave per SIMD (512 registers), 4 per
+// workgroup; latency is covered by a register double buffer of 2 x UNROLL steps. The four waves of
+// a workgroup combine their tiles through LDS (deterministic order), the per-workgroup partials
+// are summed by wgrad_act_reduce_kernel.
 constexpr int WG_W = 256;
 constexpr int UNROLL = 4;
+constexpr int WGRAD_MAX_BLOCKS = 256;
 
-template <int NTW>
-__global__ void __launch_bounds__(WG_W)
+template <int NTW, int KTW, bool ACT, bool GPRO>
+__global__ void __attribute__((amdgpu_flat_work_group_size(WG_W, WG_W), amdgpu_waves_per_eu(1, 1)))
 wgrad_act_kernel(int64_t M, int N, int K, const float* __restrict__ g, int64_t ldg,
+                 const float* __restrict__ gz, int64_t ldgz, const float* __restrict__ gcoef,
                  const float* __restrict__ x, int64_t ldx, const float* __restrict__ in_scale,
                  const float* __restrict__ in_shift, float* __restrict__ partial,
-                 int64_t rows_per_block) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+                 int64_t rows_per_wave) {
+  constexpr int NP = NTW * 32, KP = KTW * 32;
+  extern __shared__ float s_tile[];            // 2 x [NP][KP] + 2 x [NP] (bias)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   const int half = lane >> 5, col = lane & 31;
-  const int KT = (K + 31) / 32;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-  const int64_t r1 = min(r0 + rows_per_block, M);
-  float* out = partial + (size_t)blockIdx.x * ((size_t)N * K + N);
-  if (wave >= KT) return;
-  const int kcol = wave * 32 + col;
-  const bool kok = kcol < K;
-  const float sc = kok ? in_scale[kcol] : 0.f, sh = kok ? in_shift[kcol] : 0.f;
+  const int64_t r0 = ((int64_t)blockIdx.x * (WG_W / 64) + wave) * rows_per_wave;
+  const int64_t r1 = min(r0 + rows_per_wave, M);
 
-  f32x16 acc[NTW];
+  int ncol[NTW], kcol[KTW];
+  float sc[KTW], sh[KTW];
+  float cA[NTW], cq[NTW], cp[NTW];            // GPRO: g operand = cA * g + cq * gz + cp per column
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    ncol[j] = min(j * 32 + col, N - 1);
+    cA[j] = GPRO ? gcoef[ncol[j]] : 1.f;
+    cq[j] = GPRO ? gcoef[N + ncol[j]] : 0.f;
+    cp[j] = GPRO ? gcoef[2 * N + ncol[j]] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < KTW; ++i) {
+    kcol[i] = min(i * 32 + col, K - 1);
+    sc[i] = ACT ? in_scale[kcol[i]] : 1.f;
+    sh[i] = ACT ? in_shift[kcol[i]] : 0.f;
+  }
+  f32x16 acc[NTW][KTW];
   float bias[NTW];
 #pragma unroll
   for (int j = 0; j < NTW; ++j) {
     bias[j] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int i = 0; i < KTW; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
   }
-  for (int64_t m = r0; m < r1; m += 2 * UNROLL) {
-    float a[UNROLL][NTW], b[UNROLL];
+
+  struct Group { float a[UNROLL][NTW]; float c[UNROLL][GPRO ? NTW : 1]; float b[UNROLL][KTW]; };
+  auto load = [&](Group& q, int64_t m) {
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      const int64_t row = min(m + 2 * u + half, r1 - 1);      // clamped: loads stay branch-free
-      b[u] = x[row * ldx + (kok ? kcol : 0)];
+      const int64_t row = min(m + 2 * u + half, M - 1);        // clamped: loads stay branch-free
+      const float* gr = g + row * ldg;
+      const float* xr = x + row * ldx;
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) a[u][j] = g[row * ldg + min(j * 32 + col, N - 1)];
+      for (int j = 0; j < NTW; ++j) q.a[u][j] = gr[ncol[j]];
+      if (GPRO) {
+        const float* zr = gz + row * ldgz;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) q.c[u][j] = zr[ncol[j]];
+      }
+#pragma unroll
+      for (int i = 0; i < KTW; ++i) q.b[u][i] = xr[kcol[i]];
     }
+  };
+  auto compute = [&](const Group& q, int64_t m) {
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      const bool rok = m + 2 * u + half < r1;
-      const float bv = (rok && kok) ? softplus_f(fmaf(sc, b[u], sh)) : 0.f;
+      const bool rok = m + 2 * u + half < r1;                  // rows beyond the range contribute 0
+      float av[NTW], bv[KTW];
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
-        const float av = (rok && j * 32 + col < N) ? a[u][j] : 0.f;
-        bias[j] += av;
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+        const float gv = GPRO ? fmaf(cA[j], q.a[u][j], fmaf(cq[j], q.c[u][j], cp[j])) : q.a[u][j];
+        av[j] = rok ? gv : 0.f;
+        bias[j] += av[j];
       }
+#pragma unroll
+      for (int i = 0; i < KTW; ++i) bv[i] = ACT ? softplus_f(fmaf(sc[i], q.b[u][i], sh[i])) : q.b[u][i];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int i = 0; i < KTW; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[i], acc[j][i], 0, 0, 0);
+    }
+  };
+
+  if (r0 < r1) {
+    Group qa, qb;
+    load(qa, r0);
+    for (int64_t m = r0; m < r1; m += 4 * UNROLL) {
+      // full scheduling barriers: the next group's loads are issued before this group's MFMAs,
+      // and nothing of the next group (its softplus would wait for loads that were only just
+      // issued) is hoisted into this one
+      load(qb, m + 2 * UNROLL);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(qa, m);
+      __builtin_amdgcn_sched_barrier(0);
+      load(qa, m + 4 * UNROLL);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(qb, m + 2 * UNROLL);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
+
+  // combine the four waves' tiles: waves 0/1 store into two LDS tiles, waves 2/3 add on top
+  // (same lane -> same address, so plain read-modify-write), then all threads write tile0 + tile1
+  float* tile = s_tile + (size_t)(wave & 1) * (NP * KP + NP);
+  auto lds_index = [&](int j, int i, int r) {
+    return (j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * KP + i * 32 + col;
+  };
 #pragma unroll
-  for (int j = 0; j < NTW; ++j) {
+  for (int j = 0; j < NTW; ++j) bias[j] += __shfl_xor(bias[j], 32);
+  if (wave < 2) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int n = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (n < N && kok) out[(size_t)n * K + kcol] = acc[j][r];
+    for (int j = 0; j < NTW; ++j) {
+#pragma unroll
+      for (int i = 0; i < KTW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tile[lds_index(j, i, r)] = acc[j][i][r];
+      if (half == 0) tile[NP * KP + j * 32 + col] = bias[j];
     }
-    const float bs = bias[j] + __shfl_xor(bias[j], 32);
-    if (wave == 0 && half == 0 && j * 32 + col < N) out[(size_t)N * K + j * 32 + col] = bs;
   }
+  __syncthreads();
+  if (wave >= 2) {
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+#pragma unroll
+      for (int i = 0; i < KTW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tile[lds_index(j, i, r)] += acc[j][i][r];
+      if (half == 0) tile[NP * KP + j * 32 + col] += bias[j];
+    }
+  }
+  __syncthreads();
+  float* out = partial + (size_t)blockIdx.x * ((size_t)N * K + N);
+  const float* t0 = s_tile;
+  const float* t1 = s_tile + (NP * KP + NP);
+  for (int e = threadIdx.x; e < N * K; e += WG_W) {
+    const int n = e / K, k = e - n * K;
+    out[e] = t0[n * KP + k] + t1[n * KP + k];
+  }
+  for (int n = threadIdx.x; n < N; n += WG_W) out[(size_t)N * K + n] = t0[NP * KP + n] + t1[NP * KP + n];
 }
 
 // 64 outputs per block, 4 partial walkers per output, combined through LDS (deterministic)
@@ -341,16 +421,14 @@ wgrad_act_reduce_kernel(int nblocks, int N, int K, const float* __restrict__ par
   }
 }
 
-int plan_wgrad(int64_t M, int64_t* rows_per_block) {
-  const int max_blocks = 512;
-  int64_t rpb = (M + max_blocks - 1) / max_blocks;
-  rpb = ((rpb + 2 * UNROLL - 1) / (2 * UNROLL)) * (2 * UNROLL);
-  if (rpb < 2 * UNROLL) rpb = 2 * UNROLL;
-  *rows_per_block = rpb;
-  return (int)((M + rpb - 1) / rpb);
+int plan_wgrad(int64_t M, int64_t* rows_per_wave) {
+  const int waves = WG_W / 64;
+  int64_t rpw = (M + (int64_t)WGRAD_MAX_BLOCKS * waves - 1) / ((int64_t)WGRAD_MAX_BLOCKS * waves);
+  rpw = ((rpw + 4 * UNROLL - 1) / (4 * UNROLL)) * (4 * UNROLL);
+  if (rpw < 4 * UNROLL) rpw = 4 * UNROLL;
+  *rows_per_wave = rpw;
+  return (int)((M + rpw * waves - 1) / (rpw * waves));
 }
-
-bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
 
@@ -419,7 +497,7 @@ int ganet_mlp_stats(int64_t M, int32_t N, const float* col_part, const float* ga
     return 1;
   }
   const int np = ((N + 31) / 32) * 32;
-  hipLaunchKernelGGL(mlp_stats_kernel, dim3(N), dim3(64), 0, static_cast<hipStream_t>(stream_),
+  hipLaunchKernelGGL(mlp_stats_kernel, dim3(N), dim3(256), 0, static_cast<hipStream_t>(stream_),
                      FWD_BLOCKS * WAVES, np, M, col_part, gamma, beta, eps, mean, rstd, scale, shift,
                      running_mean, running_var, momentum,
                      reinterpret_cast<long long*>(num_batches_tracked));
@@ -433,10 +511,12 @@ size_t ganet_wgrad_act_workspace(int64_t M, int32_t N, int32_t K) {
   return (size_t)nb * ((size_t)N * K + N) * sizeof(float);
 }
 
-int ganet_wgrad_act(int64_t M, int32_t N, int32_t K, const float* g, int64_t ldg, const float* x,
-                    int64_t ldx, const float* in_scale, const float* in_shift, float* dW, float* db,
+int ganet_wgrad_act(int64_t M, int32_t N, int32_t K, const float* g, int64_t ldg, const float* gz,
+                    int64_t ldgz, const float* gcoef, const float* x, int64_t ldx,
+                    const float* in_scale, const float* in_shift, float* dW, float* db,
                     void* workspace, size_t workspace_bytes, void* stream_) {
-  if (M <= 0 || N <= 0 || K <= 0 || !g || !x || !in_scale || !in_shift || !dW || ldg < N || ldx < K) {
+  if (M <= 0 || N <= 0 || K <= 0 || !g || !x || ((in_scale == nullptr) != (in_shift == nullptr)) ||
+      ((gz == nullptr) != (gcoef == nullptr)) || (gz && ldgz < N) || !dW || ldg < N || ldx < K) {
     set_error("ganet_wgrad_act: invalid arguments");
     return 1;
   }
@@ -444,8 +524,8 @@ int ganet_wgrad_act(int64_t M, int32_t N, int32_t K, const float* g, int64_t ldg
     set_error("ganet_wgrad_act: unsupported shape N=%d K=%d (N, K <= 128)", N, K);
     return 4;
   }
-  int64_t rpb;
-  const int nb = plan_wgrad(M, &rpb);
+  int64_t rpw;
+  const int nb = plan_wgrad(M, &rpw);
   const size_t need = (size_t)nb * ((size_t)N * K + N) * sizeof(float);
   if (!workspace || workspace_bytes < need) {
     set_error("ganet_wgrad_act: workspace too small (%zu < %zu)", workspace_bytes, need);
@@ -454,15 +534,33 @@ int ganet_wgrad_act(int64_t M, int32_t N, int32_t K, const float* g, int64_t ldg
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   float* partial = static_cast<float*>(workspace);
   const dim3 grid(nb), block(WG_W);
-  const int nt = (N + 31) / 32;
-#define LAUNCH(T) \
-  hipLaunchKernelGGL((wgrad_act_kernel<T>), grid, block, 0, stream, M, N, K, g, ldg, x, ldx, in_scale, \
-                     in_shift, partial, rpb)
-  switch (nt) {
-    case 1: LAUNCH(1); break;
-    case 2: LAUNCH(2); break;
-    case 3: LAUNCH(3); break;
-    default: LAUNCH(4); break;
+  const int nt = N > 32 ? 4 : 1, kt = K > 96 ? 4 : 3;
+  const bool act = in_scale != nullptr, gpro = gz != nullptr;
+#define LAUNCH(T, KT_, A, G)                                                                       \
+  do {                                                                                             \
+    const size_t lds = 2 * ((size_t)(T) * 32 * (KT_) * 32 + (T) * 32) * sizeof(float);             \
+    static bool attr_set = false;                                                                  \
+    if (!attr_set) {                                                                               \
+      if (check_hip(hipFuncSetAttribute(                                                           \
+                        reinterpret_cast<const void*>(wgrad_act_kernel<T, KT_, A, G>),             \
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),                     \
+                    "hipFuncSetAttribute")) return 3;                                              \
+      attr_set = true;                                                                             \
+    }                                                                                              \
+    hipLaunchKernelGGL((wgrad_act_kernel<T, KT_, A, G>), grid, block, lds, stream, M, N, K, g, ldg, \
+                       gz, ldgz, gcoef, x, ldx, in_scale, in_shift, partial, rpw);                 \
+  } while (0)
+  // instantiated: the decoder's cases (+ the raw-g variants used by tests / generic callers)
+  if (nt == 4 && kt == 4 && act && gpro) LAUNCH(4, 4, true, true);
+  else if (nt == 4 && kt == 4 && act) LAUNCH(4, 4, true, false);
+  else if (nt == 4 && kt == 3 && !act && gpro) LAUNCH(4, 3, false, true);
+  else if (nt == 4 && kt == 3 && !act) LAUNCH(4, 3, false, false);
+  else if (nt == 1 && kt == 4 && act && !gpro) LAUNCH(1, 4, true, false);
+  else if (nt == 1 && kt == 3 && !act && !gpro) LAUNCH(1, 3, false, false);
+  else {
+    set_error("ganet_wgrad_act: unsupported combination N=%d K=%d act=%d gpro=%d", N, K, (int)act,
+              (int)gpro);
+    return 4;
   }
 #undef LAUNCH
   int rc = check_hip(hipGetLastError(), "wgrad_act_kernel");

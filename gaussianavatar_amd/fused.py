@@ -278,96 +278,117 @@ class _DecoderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *d_outs):
+        """No dL/dy or dz tensor is materialised: every hidden layer i keeps G_i = dL/dy_i . softplus'(u_i)
+        (written by the producing kernel's epilogue) and the per-column coefficients (A, q, p) with
+        dz_i = A G_i + q z_i + p; the data-gradient and weight-gradient kernels assemble dz_i on load
+        (include/ganet.h, ganet_mlp_bwd.hip)."""
         lib = _native.ganet()
         nl, cin = ctx.nl, ctx.cin
         sv = ctx.saved_tensors
         xp = sv[0]
         zs = sv[1:1 + nl]
         fs = sv[1 + nl:1 + 5 * nl]
-        stats = [fs[4 * i:4 * i + 4] for i in range(nl)]
+        stats = [fs[4 * i:4 * i + 4] for i in range(nl)]          # mean, rstd, scale, shift
         conv_w = sv[1 + 5 * nl:1 + 6 * nl]
-        gammas = sv[1 + 6 * nl:1 + 7 * nl]
-        betas = sv[1 + 7 * nl:1 + 8 * nl]
         out_w = sv[1 + 8 * nl:1 + 8 * nl + 3]
         dev = xp.device
         M = xp.shape[0]
+        st = _stream(dev)
         g_conv_w, g_conv_b, g_gamma, g_beta = [None] * nl, [None] * nl, [None] * nl, [None] * nl
         g_out_w, g_out_b = [None] * 3, [None] * 3
-        bn_ws_bytes = lib.ganet_bn_workspace(M, 128)
-        bn_ws = torch.empty(bn_ws_bytes, dtype=torch.uint8, device=dev)
-        wg_bytes = max(lib.ganet_wgrad_act_workspace(M, 128, 128), lib.ganet_linear_wgrad_workspace(M, 128, _K1_PAD))
+        wg_bytes = lib.ganet_wgrad_act_workspace(M, 128, 128)
         wg_ws = torch.empty(wg_bytes, dtype=torch.uint8, device=dev)
+        n_data, n_head = lib.ganet_mlp_bwd_data_parts(), lib.ganet_mlp_head_bwd_parts()
+        col_part = torch.empty(max(n_data, n_head) * 256, dtype=torch.float32, device=dev)
+        f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
 
-        def wgrad_act(g, src):
-            """dW [N,128], db [N] of a layer whose input is act(bn(zs[src]))."""
-            N = g.shape[1]
-            dW = torch.empty((N, 128), dtype=torch.float32, device=dev)
-            db = torch.empty(N, dtype=torch.float32, device=dev)
-            _, _, sc, sh = stats[src]
-            _native.ganet_check(lib.ganet_wgrad_act(M, N, 128, _ptr(g), g.stride(0), _ptr(zs[src]), zs[src].stride(0),
-                                                    _ptr(sc), _ptr(sh), _ptr(dW), _ptr(db), _ptr(wg_ws), wg_bytes,
-                                                    _stream(dev)))
+        def wgrad(g, gi, src, K=128):
+            """dW [N,K], db [N]. g operand: raw tensor (gi None) or layer gi's (G, z, coef) triple;
+            x operand: act(bn(zs[src])), or the padded decoder input when src is None."""
+            if gi is None:
+                gt, gz, coef, N = g, None, None, g.shape[1]
+            else:
+                gt, gz, coef, N = Gs[gi], zs[gi], coefs[gi], 128
+            x = xp if src is None else zs[src]
+            sc, sh = (None, None) if src is None else stats[src][2:]
+            dW, db = f32(N, K), f32(N)
+            _native.ganet_check(lib.ganet_wgrad_act(
+                M, N, K, _ptr(gt), gt.stride(0), _ptr(gz), 0 if gz is None else gz.stride(0), _ptr(coef),
+                _ptr(x), x.stride(0), _ptr(sc), _ptr(sh), _ptr(dW), _ptr(db), _ptr(wg_ws), wg_bytes, st))
             return dW, db
 
-        def wgrad_x(g):
-            """dW [128, cin] of the un-activated decoder-input operand."""
-            dW = torch.empty((128, _K1_PAD), dtype=torch.float32, device=dev)
-            db = torch.empty(128, dtype=torch.float32, device=dev)
-            _native.ganet_check(lib.ganet_linear_wgrad(M, 128, _K1_PAD, _ptr(g), g.stride(0), _ptr(xp), xp.stride(0),
-                                                       _ptr(dW), _ptr(db), _ptr(wg_ws), wg_bytes, _stream(dev)))
-            return dW[:, :cin], db
+        def finish(i, nparts):
+            """column sums of (G_i, G_i z_i) -> coefficients of layer i, d gamma_i, d beta_i."""
+            mean, rstd, sc, _ = stats[i]
+            coef, dg, dbt = f32(3 * 128), f32(128), f32(128)
+            _native.ganet_check(lib.ganet_mlp_bwd_stats(M, nparts, _ptr(col_part), _ptr(mean), _ptr(rstd), _ptr(sc),
+                                                        _ptr(coef), _ptr(dg), _ptr(dbt), st))
+            coefs[i], g_gamma[i], g_beta[i] = coef, dg, dbt
 
-        def bn_bwd(i, dy):
-            """grad w.r.t. act(bn(z_i)) -> grad w.r.t. z_i (+ d gamma, d beta)."""
-            mean, rstd, _, _ = stats[i]
-            dz = torch.empty_like(dy)
-            dg = torch.empty(128, dtype=torch.float32, device=dev)
-            db = torch.empty(128, dtype=torch.float32, device=dev)
-            _native.ganet_check(lib.ganet_bn_act_bwd(M, 128, _ptr(zs[i]), _ptr(gammas[i]), _ptr(betas[i]), _ptr(mean),
-                                                     _ptr(rstd), 1, _ptr(dy), _ptr(dz), _ptr(dg), _ptr(db),
-                                                     _ptr(bn_ws), bn_ws_bytes, _stream(dev)))
-            g_gamma[i], g_beta[i] = dg, db
-            return dz
+        def data_grad(gi, Wt, out, accumulate, src):
+            """out (+)= dz_gi . W ; with src: out = G_src (and its column sums in col_part)."""
+            O = Wt.shape[0]
+            sz = None if src is None else zs[src]
+            sc, sh = (None, None) if src is None else stats[src][2:]
+            _native.ganet_check(lib.ganet_mlp_bwd_data(
+                M, O, _ptr(Gs[gi]), Gs[gi].stride(0), _ptr(zs[gi]), zs[gi].stride(0), _ptr(coefs[gi]), _ptr(Wt),
+                _ptr(out), out.stride(0), int(accumulate), _ptr(sz), 0 if sz is None else sz.stride(0),
+                _ptr(sc), _ptr(sh), _ptr(col_part) if src is not None else None, st))
 
-        dy5 = None
-        for j in range(3):
+        Gs, coefs = [None] * nl, [None] * nl
+        heads = [j for j in range(3) if d_outs[j] is not None]
+        G5 = f32(M, 128) if heads else None
+        for pos, j in enumerate(heads):
             i6, i7 = 5 + 2 * j, 6 + 2 * j
-            g = d_outs[j]
-            if g is None:
-                continue
-            g = g.contiguous()
-            g_out_w[j], g_out_b[j] = wgrad_act(g, i7)
-            g_out_w[j] = g_out_w[j].unsqueeze(-1)
-            dz7 = bn_bwd(i7, g @ out_w[j])
-            dW, db = wgrad_act(dz7, i6)
+            g = d_outs[j].contiguous()
+            dW, db = wgrad(g, None, i7)
+            g_out_w[j], g_out_b[j] = dW.unsqueeze(-1), db
+            Gs[i7] = f32(M, 128)
+            _, _, sc7, sh7 = stats[i7]
+            _native.ganet_check(lib.ganet_mlp_head_bwd(M, g.shape[1], _ptr(g), _ptr(out_w[j].contiguous()), _ptr(zs[i7]),
+                                                       zs[i7].stride(0), _ptr(sc7), _ptr(sh7), _ptr(Gs[i7]),
+                                                       Gs[i7].stride(0), _ptr(col_part), st))
+            finish(i7, n_head)
+            dW, db = wgrad(None, i7, i6)
             g_conv_w[i7], g_conv_b[i7] = dW.unsqueeze(-1), db
-            dz6 = bn_bwd(i6, dz7 @ conv_w[i7])
-            del dz7
-            dW, db = wgrad_act(dz6, 4)
+            Gs[i6] = f32(M, 128)
+            data_grad(i7, conv_w[i7].t().contiguous(), Gs[i6], False, i6)
+            Gs[i7] = None
+            finish(i6, n_data)
+            dW, db = wgrad(None, i6, 4)
             g_conv_w[i6], g_conv_b[i6] = dW.unsqueeze(-1), db
-            dy5 = dz6 @ conv_w[i6] if dy5 is None else dy5.addmm_(dz6, conv_w[i6])
-            del dz6
+            last = pos == len(heads) - 1
+            data_grad(i6, conv_w[i6].t().contiguous(), G5, pos > 0, 4 if last else None)
+            Gs[i6] = None
         dx = None
-        if dy5 is not None:
-            dz = bn_bwd(4, dy5)
-            del dy5
-            dWy, db = wgrad_act(dz, 3)
-            dWx, _ = wgrad_x(dz)
-            g_conv_w[4], g_conv_b[4] = torch.cat([dWx, dWy], 1).unsqueeze(-1), db
+        if heads:
+            Gs[4] = G5
+            finish(4, n_data)
             w5 = conv_w[4]
-            if ctx.needs_input_grad[0]:
-                dx = dz @ w5[:, :cin]
-            dy = dz @ w5[:, cin:]
+            pad_rows = lambda wt: torch.cat([wt, wt.new_zeros(_K1_PAD - cin, wt.shape[1])], 0).contiguous()
+            dWy, db = wgrad(None, 4, 3)
+            dWx, _ = wgrad(None, 4, None, _K1_PAD)
+            g_conv_w[4], g_conv_b[4] = torch.cat([dWx[:, :cin], dWy], 1).unsqueeze(-1), db
+            need_dx = ctx.needs_input_grad[0]
+            if need_dx:
+                dxp = f32(M, _K1_PAD)
+                data_grad(4, pad_rows(w5[:, :cin].t()), dxp, False, None)
+            Gs[3] = f32(M, 128)
+            data_grad(4, w5[:, cin:].t().contiguous(), Gs[3], False, 3)
+            Gs[4] = None
             for i in (3, 2, 1):
-                dz = bn_bwd(i, dy)
-                dW, db = wgrad_act(dz, i - 1)
+                finish(i, n_data)
+                dW, db = wgrad(None, i, i - 1)
                 g_conv_w[i], g_conv_b[i] = dW.unsqueeze(-1), db
-                dy = dz @ conv_w[i]
-            dz = bn_bwd(0, dy)
-            dW, db = wgrad_x(dz)
-            g_conv_w[0], g_conv_b[0] = dW.contiguous().unsqueeze(-1), db
-            if ctx.needs_input_grad[0]:
-                dx = dx.addmm_(dz, conv_w[0])
+                Gs[i - 1] = f32(M, 128)
+                data_grad(i, conv_w[i].t().contiguous(), Gs[i - 1], False, i - 1)
+                Gs[i] = None
+            finish(0, n_data)
+            dW, db = wgrad(None, 0, None, _K1_PAD)
+            g_conv_w[0], g_conv_b[0] = dW[:, :cin].contiguous().unsqueeze(-1), db
+            if need_dx:
+                data_grad(0, pad_rows(conv_w[0].t()), dxp, True, None)
+                dx = dxp[:, :cin]
         grads = []
         for i in range(nl):
             grads += [g_conv_w[i], g_conv_b[i], g_gamma[i], g_beta[i]]

@@ -94,9 +94,38 @@ int ganet_mlp_stats(int64_t M, int32_t N, const float* col_part, const float* ga
                     float* shift, float* running_mean, float* running_var, float momentum,
                     int64_t* num_batches_tracked, void* stream);
 size_t ganet_wgrad_act_workspace(int64_t M, int32_t N, int32_t K);
-int ganet_wgrad_act(int64_t M, int32_t N, int32_t K, const float* g, int64_t ldg, const float* x,
-                    int64_t ldx, const float* in_scale, const float* in_shift, float* dW, float* db,
+/* gz/gcoef (both or neither): the g operand is assembled on load as gcoef[0][n] g + gcoef[1][n] gz +
+ * gcoef[2][n] — the BatchNorm backward of the layer folded to per-column coefficients (see
+ * ganet_mlp_bwd_stats). in_scale/in_shift NULL: x is used as it is (decoder input operand). */
+int ganet_wgrad_act(int64_t M, int32_t N, int32_t K, const float* g, int64_t ldg, const float* gz,
+                    int64_t ldgz, const float* gcoef, const float* x, int64_t ldx,
+                    const float* in_scale, const float* in_shift, float* dW, float* db,
                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- input-gradient side with the BatchNorm + softplus backward folded in (ganet_mlp_bwd.hip) ----
+ * For a hidden layer with stored pre-activation z, u = scale z + shift, y = softplus(u):
+ *   G  = dL/dy . softplus'(u);   dz = A G + q z + p   (per-column A, q, p from the sums of G and G z).
+ * ganet_mlp_bwd_data:  out[M,O] (+)= (A g + q gz + p)[M,128] . Wt[O,128]^T   (Wt = W^T of the layer,
+ *   O = 128 or <= 96); with src_z != NULL the result is multiplied by softplus'(src_scale src_z +
+ *   src_shift) — i.e. out = G of the SOURCE layer — and col_part ([ganet_mlp_bwd_data_parts()][2][128])
+ *   receives the partial column sums of out and out . src_z.
+ * ganet_mlp_head_bwd:  the same for the narrow output heads (g [M,N8], N8 <= 4, W8 [N8,128]):
+ *   G[M,128] = (g W8) softplus'(scale z + shift), partial sums [ganet_mlp_head_bwd_parts()][2][128].
+ * ganet_mlp_bwd_stats: partial sums -> coef [3][128] = (A, q, p), d gamma, d beta.
+ * Together they replace the autograd backward of Conv1d(k=1) -> BatchNorm1d -> Softplus
+ * (/root/reference/model/modules.py:554-582) without materialising dz or dL/dy. */
+int32_t ganet_mlp_bwd_data_parts(void);
+int32_t ganet_mlp_head_bwd_parts(void);
+int ganet_mlp_bwd_data(int64_t M, int32_t O, const float* g, int64_t ldg, const float* gz, int64_t ldgz,
+                       const float* gcoef, const float* Wt, float* out, int64_t ldo, int32_t accumulate,
+                       const float* src_z, int64_t ld_src, const float* src_scale,
+                       const float* src_shift, float* col_part, void* stream);
+int ganet_mlp_head_bwd(int64_t M, int32_t N8, const float* g, const float* W8, const float* z,
+                       int64_t ldz, const float* scale, const float* shift, float* G, int64_t ldG,
+                       float* col_part, void* stream);
+int ganet_mlp_bwd_stats(int64_t M, int32_t nparts, const float* col_part, const float* mean,
+                        const float* rstd, const float* scale, float* coef, float* dgamma,
+                        float* dbeta, void* stream);
 
 const char* ganet_last_error(void);
 int ganet_abi_version(void);

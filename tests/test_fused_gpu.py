@@ -213,24 +213,34 @@ def test_mlp_fwd_layer_matches_torch(M, K1, K2, N):
         assert int(nbt) == int(bn.num_batches_tracked) == 1
 
 
-@pytest.mark.parametrize("M,N", [(262144, 128), (50001, 128), (70001, 3), (4097, 1)])
-def test_wgrad_act_matches_torch(M, N):
+@pytest.mark.parametrize("M,N,K,act", [(262144, 128, 128, True), (50001, 128, 128, True), (70001, 3, 128, True),
+                                         (4097, 1, 128, True), (40000, 128, 72, False), (15, 128, 128, True),
+                                         (3000, 20, 70, False)])
+def test_wgrad_act_matches_torch(M, N, K, act):
     from gaussianavatar_amd import _native, fused
     lib = _native.ganet()
     torch.manual_seed(N + M % 13)
     dev = "cuda"
-    x = torch.randn(M, 128, device=dev) * 2
-    sc = torch.empty(128, device=dev).uniform_(0.3, 2.0)
-    sh = torch.empty(128, device=dev).uniform_(-3, 3)
+    x = torch.randn(M, K, device=dev) * 2
+    sc = torch.empty(K, device=dev).uniform_(0.3, 2.0) if act else None
+    sh = torch.empty(K, device=dev).uniform_(-3, 3) if act else None
     g = torch.randn(M, N, device=dev)
-    dW = torch.empty(N, 128, device=dev)
+    dW = torch.empty(N, K, device=dev)
     db = torch.empty(N, device=dev)
-    nbytes = lib.ganet_wgrad_act_workspace(M, N, 128)
+    nbytes = lib.ganet_wgrad_act_workspace(M, N, K)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    _native.ganet_check(lib.ganet_wgrad_act(M, N, 128, fused._ptr(g), g.stride(0), fused._ptr(x), x.stride(0),
-                                            fused._ptr(sc), fused._ptr(sh), fused._ptr(dW), fused._ptr(db),
+    gz = coef = None
+    gd = g.double()
+    if N == 128:          # g operand assembled on load: coef[0] g + coef[1] gz + coef[2]
+        gz = torch.randn(M, N, device=dev)
+        coef = torch.randn(3, N, device=dev)
+        gd = coef[0].double() * g.double() + coef[1].double() * gz.double() + coef[2].double()
+    _native.ganet_check(lib.ganet_wgrad_act(M, N, K, fused._ptr(g), g.stride(0), fused._ptr(gz),
+                                            0 if gz is None else gz.stride(0), fused._ptr(coef), fused._ptr(x),
+                                            x.stride(0), fused._ptr(sc), fused._ptr(sh), fused._ptr(dW), fused._ptr(db),
                                             fused._ptr(ws), nbytes, fused._stream(torch.device(dev))))
-    ref = g.double().t() @ _softplus_bn(x, sc, sh)
+    g = gd
+    ref = g.double().t() @ (_softplus_bn(x, sc, sh) if act else x.double())
     assert float((dW.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-4
     rb = g.double().sum(0)
     assert float((db.double() - rb).abs().max()) <= 2e-5 * float(rb.abs().max()) + 1e-4
@@ -280,3 +290,82 @@ def test_fused_decoder_equals_per_layer_formulation(M, monkeypatch):
         e_b = dec_b.forward_points(x_b.detach())
     for a, b in zip(e_a, e_b):
         torch.testing.assert_close(a, b, rtol=1e-3, atol=2e-4)
+
+
+@pytest.mark.parametrize("M,O,accumulate,sig", [(262144, 128, False, True), (33001, 128, True, True),
+                                                (20000, 128, False, False), (20011, 128, True, False),
+                                                (40000, 72, False, False), (4099, 72, True, False), (17, 128, False, True)])
+def test_mlp_bwd_data_matches_torch(M, O, accumulate, sig):
+    """ganet_mlp_bwd_data: dz assembled on load from (G, z, coef), times W, optional accumulate, optional
+    softplus' epilogue of the source layer with its column sums."""
+    from gaussianavatar_amd import _native, fused
+    lib = _native.ganet()
+    torch.manual_seed(M % 31 + O)
+    dev = torch.device("cuda")
+    G = torch.randn(M, 128, device=dev)
+    z = torch.randn(M, 128, device=dev) * 2
+    coef = torch.randn(3, 128, device=dev)
+    Wt = torch.randn(O, 128, device=dev) * 0.1
+    out = torch.randn(M, O, device=dev)
+    prev = out.clone()
+    src_z = torch.randn(M, O, device=dev) * 2 if sig else None
+    sc = torch.empty(O, device=dev).uniform_(0.3, 2.0) if sig else None
+    sh = torch.empty(O, device=dev).uniform_(-12, 25) if sig else None
+    parts = lib.ganet_mlp_bwd_data_parts()
+    part = torch.zeros(parts * 256, device=dev)
+    _native.ganet_check(lib.ganet_mlp_bwd_data(M, O, fused._ptr(G), 128, fused._ptr(z), 128, fused._ptr(coef),
+                                               fused._ptr(Wt), fused._ptr(out), O, int(accumulate), fused._ptr(src_z),
+                                               O if sig else 0, fused._ptr(sc), fused._ptr(sh),
+                                               fused._ptr(part) if sig else None, fused._stream(dev)))
+    dz = coef[0].double() * G.double() + coef[1].double() * z.double() + coef[2].double()
+    ref = dz @ Wt.double().t()
+    if accumulate:
+        ref = ref + prev.double()
+    if sig:
+        u = src_z.double() * sc.double() + sh.double()
+        ref = ref * torch.where(u > 20, torch.ones_like(u), torch.sigmoid(u))
+    assert float((out.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 2e-5
+    if sig:
+        p = part.reshape(parts, 2, 128).double().sum(0)
+        assert float((p[0] - ref.sum(0)).abs().max()) <= 1e-4 * float(ref.abs().sum(0).max()) + 1e-3
+        r2 = (ref * src_z.double()).sum(0)
+        assert float((p[1] - r2).abs().max()) <= 1e-4 * float((ref * src_z.double()).abs().sum(0).max()) + 1e-3
+
+
+@pytest.mark.parametrize("M,N8", [(262144, 3), (5001, 1), (37, 3)])
+def test_mlp_head_bwd_and_stats_match_torch_batchnorm_backward(M, N8):
+    """Head kernel + coefficient kernel: dz = A G + q z + p must equal autograd's gradient of
+    softplus(batch_norm(z)) w.r.t. z; d gamma / d beta likewise."""
+    from gaussianavatar_amd import _native, fused
+    lib = _native.ganet()
+    torch.manual_seed(N8)
+    dev = torch.device("cuda")
+    z = (torch.randn(M, 128, device=dev) * 1.5 + torch.linspace(-2, 2, 128, device=dev)).requires_grad_(True)
+    gamma = torch.empty(128, device=dev).uniform_(0.5, 2).requires_grad_(True)
+    beta = torch.empty(128, device=dev).uniform_(-1, 1).requires_grad_(True)
+    W8 = torch.randn(N8, 128, device=dev) * 0.3
+    g = torch.randn(M, N8, device=dev)
+    y = F.softplus(F.batch_norm(z, None, None, gamma, beta, True, 0.1, 1e-5))
+    (y @ W8.t() * g).sum().backward()
+    with torch.no_grad():
+        mean = z.mean(0)
+        rstd = torch.rsqrt(z.var(0, unbiased=False) + 1e-5)
+        sc = (gamma * rstd).contiguous()
+        sh = (beta - mean * sc).contiguous()
+    G = torch.empty(M, 128, device=dev)
+    parts = lib.ganet_mlp_head_bwd_parts()
+    part = torch.zeros(parts * 256, device=dev)
+    _native.ganet_check(lib.ganet_mlp_head_bwd(M, N8, fused._ptr(g), fused._ptr(W8), fused._ptr(z.detach()), 128,
+                                               fused._ptr(sc), fused._ptr(sh), fused._ptr(G), 128, fused._ptr(part),
+                                               fused._stream(dev)))
+    coef = torch.empty(3, 128, device=dev)
+    dg = torch.empty(128, device=dev)
+    db = torch.empty(128, device=dev)
+    _native.ganet_check(lib.ganet_mlp_bwd_stats(M, parts, fused._ptr(part), fused._ptr(mean), fused._ptr(rstd),
+                                                fused._ptr(sc), fused._ptr(coef), fused._ptr(dg), fused._ptr(db),
+                                                fused._stream(dev)))
+    dz = coef[0] * G + coef[1] * z.detach() + coef[2]
+    tol = 2e-3 * float(z.grad.abs().max()) + 1e-7
+    assert float((dz - z.grad).abs().max()) <= tol
+    assert float((dg - gamma.grad).abs().max()) <= 1e-3 * float(gamma.grad.abs().max()) + 1e-4
+    assert float((db - beta.grad).abs().max()) <= 1e-3 * float(beta.grad.abs().max()) + 1e-4
