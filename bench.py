@@ -33,6 +33,25 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+EVENT_EVERY = 10          # timed steps whose dominant-family launches carry HIP events
+MFMA_F32_PEAK_TF = 157.3  # dense fp32-input MFMA peak (same guide; v_mfma_f32_32x32x2_f32)
+
+
+def decoder_flops(model) -> dict:
+    """Algorithmic flops (2 M N K per GEMM) of one stage-1 iteration's decoder launches, by kernel
+    family. Stage 1 evaluates the batch-invariant decoder once: M = UV texels (S^2)."""
+    dec = model.net.decoder
+    M = float(model.uv_coord_map.shape[0])
+    h, cin = dec.hsize, dec.in_size
+    hidden = cin * h + 3 * h * h + (h + cin) * h + 6 * h * h      # conv1, conv2-4, conv5, conv6/7 x 3 heads
+    outs = h * (3 + 1 + 3)                                        # conv8 x 3 heads
+    return {
+        "mlp_fwd": 2.0 * M * (hidden + outs),
+        "wgrad_act": 2.0 * M * (hidden + outs),
+        # input gradients: every hidden GEMM except conv1's activation operand (there is none)
+        "mlp_bwd_data": 2.0 * M * hidden,
+        "head_bwd": 2.0 * M * outs,
+    }
 
 
 def algorithmic_bytes(P: int, D: float, npix: int) -> dict:
@@ -141,7 +160,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from gaussianavatar_amd import rasterizer
+    from gaussianavatar_amd import fused, rasterizer
     from gaussianavatar_amd.avatar_model import AvatarModel, collate_frames, default_params
     from gaussianavatar_amd.losses import l1_loss_w, ssim
 
@@ -175,24 +194,52 @@ def main():
         model.step(epoch)
         return loss
 
-    for i in range(args.warmup):
+    # Kernel timing. Bracketing EVERY launch with HIP events costs ~1.4 ms per iteration (~100
+    # launches x 2 event packets), so: the last few WARM-UP steps run fully instrumented (complete
+    # per-kernel table + which kernel family dominates the iteration); in the TIMED region only that
+    # dominant family is bracketed, and only on every EVENT_EVERY-th step (an event pair costs ~40 us of
+    # lost launch overlap, 12 launches/iteration would still be ~6 %) — `roofline` is computed from those.
+    events = not args.no_kernel_events
+    probe = min(3, args.warmup) if events else 0
+    for i in range(args.warmup - probe):
         step(i)
+    probe_r, probe_n = {}, {}
+    if probe:
+        rasterizer.check_overflow(block=True)
+        rasterizer.profile_enable(True)
+        fused.profile_enable(True)
+        rasterizer.profile_read(reset=True)
+        fused.profile_read(reset=True)
+        for i in range(args.warmup - probe, args.warmup):
+            step(i)
+        probe_r = rasterizer.profile_read(reset=True)
+        probe_n = fused.profile_read(reset=True)
+        rasterizer.profile_enable(False)
+        fused.profile_enable(False)
     rasterizer.check_overflow(block=True)
     rasterizer.pair_statistics(reset=True)
-    if not args.no_kernel_events:
-        rasterizer.profile_enable(True)
-        rasterizer.profile_read(reset=True)
+    share = {k: ms / probe for k, (ms, n) in list(probe_r.items()) + list(probe_n.items()) if n} if probe else {}
+    dom_family = max(share, key=share.get) if share else None
+    dom_lib = rasterizer if dom_family in probe_r else (fused if dom_family in probe_n else None)
+    sampled_steps = 0
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        sample = dom_lib is not None and i % EVENT_EVERY == 0
+        if sample:
+            dom_lib.profile_enable([dom_family])
+            sampled_steps += 1
         loss = step(args.warmup + i)
+        if sample:
+            dom_lib.profile_enable(False)
     parallel.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     elapsed = parallel.max_over_ranks(elapsed, dev)
-    prof = rasterizer.profile_read(reset=True) if not args.no_kernel_events else {}
+    timed = dom_lib.profile_read(reset=True) if dom_lib is not None else {}
     rasterizer.profile_enable(False)
+    fused.profile_enable(False)
     ncalls, mean_pairs = rasterizer.pair_statistics(reset=True)
     final_loss = float(loss)
 
@@ -212,45 +259,80 @@ def main():
                    "parallelism": f"frame-sharded dp{world}, one all-reduce of [N,7] output grads",
                    "mean_tile_pairs_per_frame": mean_pairs, "final_loss": final_loss},
     }
-    if prof:
+    if probe:
         # one launch of every rasterizer kernel processes all B frames of the rank's batch
         alg = {k: v * B for k, v in algorithmic_bytes(N, mean_pairs, H * W).items()}
-        kern = {}
-        for name, (ms, n) in prof.items():
-            if n:
-                kern[name] = {"launches": n, "avg_us": 1e3 * ms / n}
-        groups = {"preprocess": ["preprocess"], "binning": ["tile_scan", "scatter", "tile_sort"],
-                  "render_fwd": ["render_fwd"], "render_bwd": ["render_bwd"],
-                  "preprocess_bwd": ["preprocess_bwd"]}
+        dflops = decoder_flops(model)
+        stage_of = {"preprocess": "preprocess", "tile_scan": "binning", "scatter": "binning", "tile_sort": "binning",
+                    "render_fwd": "render_fwd", "render_bwd": "render_bwd", "preprocess_bwd": "preprocess_bwd"}
+
+        def describe(name, ms, n, iters):
+            """per-kernel-family record: time, and its algorithmic work priced against its roofline"""
+            d = {"launches_per_iter": n / iters, "avg_us": 1e3 * ms / n, "us_per_iter": 1e3 * ms / iters}
+            if name in dflops:
+                tf = dflops[name] / (d["us_per_iter"] * 1e-6) / 1e12
+                d.update({"bound": "mfma", "flops_per_iter": dflops[name], "TFLOPs": tf,
+                          "frac_of_peak": tf / MFMA_F32_PEAK_TF})
+            elif name in ("render_fwd", "render_bwd", "preprocess", "preprocess_bwd"):
+                gbs = alg[name] / (d["us_per_iter"] * 1e-6) / 1e9
+                d.update({"bound": "hbm", "algorithmic_bytes_per_launch": alg[name], "GBps": gbs,
+                          "frac_of_peak": gbs / HBM_PEAK_GBS})
+            return d
+
+        kern = {k: describe(k, ms, n, probe) for k, (ms, n) in list(probe_r.items()) + list(probe_n.items()) if n}
         table = {}
-        for gname, members in groups.items():
-            us = sum(kern[m]["avg_us"] for m in members if m in kern)
-            if us > 0:
-                gbs = alg[gname] / (us * 1e-6) / 1e9
-                table[gname] = {"avg_us": us, "algorithmic_bytes": alg[gname], "GBps": gbs,
-                                "frac_of_8TBps": gbs / HBM_PEAK_GBS}
-        dom = max(table, key=lambda k: table[k]["avg_us"])
-        # HBM traffic per launch: PMC counters need their own rocprofv3 passes, so the value is
-        # the one measured for this same command and committed under profiles/ (null if absent or
-        # if the workload differs from the default one)
-        traffic, traffic_note = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath) and (N, H, B) == (200_000, 1024, 2):
-            t = json.load(open(tpath)).get(dom)
-            if t:
-                traffic = (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0
-                traffic_note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of this command, "
-                                "profiles/r01_pmc_render.txt; 2*FETCH+WRITE (gfx950 wide-read correction)")
-        out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": table[dom]["GBps"],
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": table[dom]["frac_of_8TBps"],
-                           "traffic": traffic, "traffic_note": traffic_note,
-                           "avg_us": table[dom]["avg_us"], "frames_per_launch": B,
-                           "algorithmic_bytes_per_launch": table[dom]["algorithmic_bytes"]}
-        fwd_us = sum(table[k]["avg_us"] for k in ("preprocess", "binning", "render_fwd") if k in table)
-        bwd_us = sum(table[k]["avg_us"] for k in ("render_bwd", "preprocess_bwd") if k in table)
-        out["kernels"] = {"per_kernel": kern, "per_stage": table,
-                          "raster_fwd_us": fwd_us, "raster_bwd_us": bwd_us,
-                          "raster_bwd_frac_of_8TBps": (alg["render_bwd"] + alg["preprocess_bwd"]) / (bwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS if bwd_us else None}
+        for k, st in stage_of.items():
+            if k in kern:
+                table.setdefault(st, {"us_per_iter": 0.0})["us_per_iter"] += kern[k]["us_per_iter"]
+        for st, t in table.items():
+            t["algorithmic_bytes"] = alg[st]
+            t["GBps"] = alg[st] / (t["us_per_iter"] * 1e-6) / 1e9
+            t["frac_of_8TBps"] = t["GBps"] / HBM_PEAK_GBS
+        # ---- roofline of the dominant kernel family, from the events of the TIMED steps
+        ms, n = timed[dom_family]
+        d = describe(dom_family, ms, n, sampled_steps)
+        if d.get("bound") == "mfma":
+            roof = {"kernel": dom_family, "bound": "mfma", "achieved": d["TFLOPs"], "peak": MFMA_F32_PEAK_TF,
+                    "unit": "TFLOP/s", "frac": d["frac_of_peak"], "traffic": None,
+                    "avg_us": d["avg_us"], "launches_per_iter": d["launches_per_iter"], "us_per_iter": d["us_per_iter"],
+                    "algorithmic_flops_per_iter": d["flops_per_iter"],
+                    "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32, exact fp32), dense peak 157.3 TFLOP/s; the "
+                            "family's launches differ in shape, so flops and time are summed over one iteration"}
+        else:
+            st = stage_of.get(dom_family, dom_family)
+            gbs = alg[st] / (d["us_per_iter"] * 1e-6) / 1e9
+            roof = {"kernel": dom_family, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_us": d["avg_us"], "frames_per_launch": B,
+                    "algorithmic_bytes_per_launch": alg[st]}
+        roof["share_of_iteration"] = d["us_per_iter"] / (1e6 * elapsed / args.steps)
+        roof["measured"] = (f"HIP events on the launch stream around this family's launches in {sampled_steps} of the "
+                            f"{args.steps} timed steps ({n} launches)")
+        out["roofline"] = roof
+        # ---- the rasterizer backward (north_star's named kernel), from the instrumented warm-up steps.
+        # HBM traffic per launch: PMC counters need their own rocprofv3 passes, so the value is the one
+        # measured for this same command and committed under profiles/ (null if the workload differs)
+        if "render_bwd" in kern:
+            rb = kern["render_bwd"]
+            traffic, traffic_note = None, None
+            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+            if os.path.exists(tpath) and (N, H, B) == (200_000, 1024, 2):
+                t = json.load(open(tpath)).get("render_bwd")
+                if t:
+                    traffic = (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0
+                    traffic_note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of this command, "
+                                    "profiles/r01_pmc_render.txt; 2*FETCH+WRITE (gfx950 wide-read correction)")
+            out["roofline_raster_bwd"] = {
+                "kernel": "render_bwd", "bound": "hbm", "achieved": rb["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": rb["frac_of_peak"], "traffic": traffic, "traffic_note": traffic_note, "avg_us": rb["avg_us"],
+                "frames_per_launch": B, "algorithmic_bytes_per_launch": alg["render_bwd"],
+                "measured": f"HIP events, {probe} fully instrumented warm-up steps"}
+        fwd_us = sum(table[k]["us_per_iter"] for k in ("preprocess", "binning", "render_fwd") if k in table)
+        bwd_us = sum(table[k]["us_per_iter"] for k in ("render_bwd", "preprocess_bwd") if k in table)
+        out["kernels"] = {
+            "measured": f"HIP events around every launch during the last {probe} warm-up steps (instrumenting all "
+                        f"~100 launches costs ~1.4 ms/iteration, so the timed steps only carry the dominant family's)",
+            "per_kernel": kern, "raster_per_stage": table, "raster_fwd_us": fwd_us, "raster_bwd_us": bwd_us,
+            "raster_bwd_frac_of_8TBps": (alg["render_bwd"] + alg["preprocess_bwd"]) / (bwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS if bwd_us else None}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N, B)
     print(json.dumps(out))

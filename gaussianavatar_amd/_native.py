@@ -52,7 +52,8 @@ class GsrLayout(ctypes.Structure):
 
 
 def _load(name: str) -> ctypes.CDLL:
-    path = os.path.join(_LIBDIR, name)
+    # GA_LIB_DIR: development switch to A/B an alternative build of the libraries on the GPU box
+    path = os.path.join(os.environ.get("GA_LIB_DIR") or _LIBDIR, name)
     if not os.path.exists(path):
         raise NativeLibraryMissing(
             f"{path} not found: the HIP extension is not built. Run "
@@ -142,6 +143,7 @@ GANET_SYMBOLS = ["ganet_linear_wgrad_workspace", "ganet_linear_wgrad", "ganet_bn
                  "ganet_mlp_stats_floats", "ganet_mlp_fwd", "ganet_mlp_stats",
                  "ganet_wgrad_act_workspace", "ganet_wgrad_act", "ganet_mlp_bwd_data_parts",
                  "ganet_mlp_head_bwd_parts", "ganet_mlp_bwd_data", "ganet_mlp_head_bwd", "ganet_mlp_bwd_stats",
+                 "ganet_profile_enable", "ganet_profile_count", "ganet_profile_read", "ganet_profile_kernel_name",
                  "ganet_last_error", "ganet_abi_version"]
 
 
@@ -186,6 +188,11 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_mlp_head_bwd.argtypes = [c_int64, c_int32, P, P, P, c_int64, P, P, P, c_int64, P, P]
         lib.ganet_mlp_bwd_stats.restype = c_int
         lib.ganet_mlp_bwd_stats.argtypes = [c_int64, c_int32, P, P, P, P, P, P, P, P]
+        lib.ganet_profile_enable.argtypes = [c_int]
+        lib.ganet_profile_count.restype = c_int
+        lib.ganet_profile_read.argtypes = [P, P, c_int]
+        lib.ganet_profile_kernel_name.restype = c_char_p
+        lib.ganet_profile_kernel_name.argtypes = [c_int]
         lib.ganet_last_error.restype = c_char_p
         lib.ganet_abi_version.restype = c_int
         if lib.ganet_abi_version() != 2:

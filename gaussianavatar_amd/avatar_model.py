@@ -261,6 +261,13 @@ class AvatarModel:
         self.optimizer.zero_grad()
         if self._pose_opt_active(epoch):
             self.optimizer_pose.zero_grad()
+        elif self.model_parms.train_stage == 1:
+            # The reference leaves the sparse pose/transl gradients un-zeroed until the pose optimiser
+            # starts (/root/reference/model/avatar_model.py:258-263): they pile up in .grad (a sparse
+            # add + periodic coalesce every iteration) and are thrown away by the first active
+            # zero_grad. Dropping them right away gives the same training trajectory.
+            self.pose.weight.grad = None
+            self.transl.weight.grad = None
 
     def step(self, epoch):
         if self.model_parms.train_stage == 2:

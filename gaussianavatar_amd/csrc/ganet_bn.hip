@@ -10,6 +10,8 @@
 // Chan's parallel (count, mean, M2) update, so there is no E[x^2]-E[x]^2 cancellation.
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
+#include <vector>
 
 #include "ganet.h"
 #include "ganet_common.h"
@@ -290,6 +292,35 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// ---------------------------------------------------------------- opt-in profiler
+namespace {
+struct ProfRec { hipEvent_t start, stop; int id; };
+std::mutex g_prof_mu;
+unsigned g_prof_mask = 0;     // bit k: time kernel id k
+std::vector<ProfRec> g_prof_recs;     // recorded, not yet read
+std::vector<ProfRec> g_prof_free;     // recycled event pairs
+double g_prof_ms[K_COUNT] = {0};
+long long g_prof_n[K_COUNT] = {0};
+}  // namespace
+
+ProfScope::ProfScope(KernelId id, hipStream_t s) : slot(-1), stream(s) {
+  if (!((g_prof_mask >> id) & 1u)) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfRec r;
+  if (!g_prof_free.empty()) { r = g_prof_free.back(); g_prof_free.pop_back(); }
+  else { if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return; }
+  r.id = id;
+  if (hipEventRecord(r.start, s) != hipSuccess) return;
+  g_prof_recs.push_back(r);
+  slot = (int)g_prof_recs.size() - 1;
+}
+
+ProfScope::~ProfScope() {
+  if (slot < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (slot < (int)g_prof_recs.size()) (void)hipEventRecord(g_prof_recs[slot].stop, stream);
+}
+
 int check_hip(hipError_t e, const char* what) {
   if (e == hipSuccess) return 0;
   set_error("%s: %s", what, hipGetErrorString(e));
@@ -354,6 +385,40 @@ int ganet_bn_act_bwd(int64_t M, int32_t C, const float* x, const float* gamma, c
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elementwise_grid(M * C / 4)), dim3(WG), 0, stream, M, C,
                      x, dy, gamma, beta, mean, rstd, sums, act, dx);
   return check_hip(hipGetLastError(), "ganet_bn_act_bwd");
+}
+
+int ganet_profile_enable(int mask) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_mask = (unsigned)mask;
+  return 0;
+}
+
+int ganet_profile_count(void) { return K_COUNT; }
+
+int ganet_profile_read(double* ms_sum, int64_t* launches, int reset) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& r : g_prof_recs) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.stop) == hipSuccess &&
+        hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+      g_prof_ms[r.id] += ms;
+      g_prof_n[r.id] += 1;
+    }
+    g_prof_free.push_back(r);
+  }
+  g_prof_recs.clear();
+  for (int k = 0; k < K_COUNT; ++k) {
+    if (ms_sum) ms_sum[k] = g_prof_ms[k];
+    if (launches) launches[k] = g_prof_n[k];
+    if (reset) { g_prof_ms[k] = 0; g_prof_n[k] = 0; }
+  }
+  return 0;
+}
+
+const char* ganet_profile_kernel_name(int id) {
+  static const char* names[K_COUNT] = {"mlp_fwd", "mlp_stats", "wgrad_act", "wgrad_reduce",
+                                       "mlp_bwd_data", "head_bwd", "bwd_stats", "ssim_fwd", "ssim_bwd"};
+  return (id >= 0 && id < K_COUNT) ? names[id] : "";
 }
 
 const char* ganet_last_error(void) { return g_err; }

@@ -253,7 +253,10 @@ mlp_stats_kernel(int nparts, int NP, int64_t M, const float* __restrict__ col_pa
 // a workgroup combine their tiles through LDS (deterministic order), the per-workgroup partials
 // are summed by wgrad_act_reduce_kernel.
 constexpr int WG_W = 256;
-constexpr int UNROLL = 4;
+#ifndef GANET_WGRAD_UNROLL
+#define GANET_WGRAD_UNROLL 4
+#endif
+constexpr int UNROLL = GANET_WGRAD_UNROLL;   // reduction steps (of 2 rows) per register group
 constexpr int WGRAD_MAX_BLOCKS = 256;
 
 template <int NTW, int KTW, bool ACT, bool GPRO>
@@ -470,6 +473,7 @@ int ganet_mlp_fwd(int64_t M, int32_t N, int32_t K1, int32_t K2, const float* x1,
                     "hipFuncSetAttribute")) return 3;                                             \
       attr_set = true;                                                                             \
     }                                                                                              \
+    ProfScope prof_(K_MLP_FWD, stream);                                                            \
     hipLaunchKernelGGL((mlp_fwd_kernel<A, B, T>), grid, block, lds, stream, M, N, x1, ld1, x2, ld2, \
                        in_scale, in_shift, W, bias, z, ldz, col_part);                             \
   } while (0)
@@ -497,6 +501,7 @@ int ganet_mlp_stats(int64_t M, int32_t N, const float* col_part, const float* ga
     return 1;
   }
   const int np = ((N + 31) / 32) * 32;
+  ProfScope prof_(K_MLP_STATS, static_cast<hipStream_t>(stream_));
   hipLaunchKernelGGL(mlp_stats_kernel, dim3(N), dim3(256), 0, static_cast<hipStream_t>(stream_),
                      FWD_BLOCKS * WAVES, np, M, col_part, gamma, beta, eps, mean, rstd, scale, shift,
                      running_mean, running_var, momentum,
@@ -547,6 +552,7 @@ int ganet_wgrad_act(int64_t M, int32_t N, int32_t K, const float* g, int64_t ldg
                     "hipFuncSetAttribute")) return 3;                                              \
       attr_set = true;                                                                             \
     }                                                                                              \
+    ProfScope prof_(K_WGRAD, stream);                                                              \
     hipLaunchKernelGGL((wgrad_act_kernel<T, KT_, A, G>), grid, block, lds, stream, M, N, K, g, ldg, \
                        gz, ldgz, gcoef, x, ldx, in_scale, in_shift, partial, rpw);                 \
   } while (0)
@@ -566,8 +572,11 @@ int ganet_wgrad_act(int64_t M, int32_t N, int32_t K, const float* g, int64_t ldg
   int rc = check_hip(hipGetLastError(), "wgrad_act_kernel");
   if (rc) return rc;
   const int total = N * K + N;
-  hipLaunchKernelGGL(wgrad_act_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, stream, nb, N, K,
-                     partial, dW, db);
+  {
+    ProfScope prof_(K_WGRAD_REDUCE, stream);
+    hipLaunchKernelGGL(wgrad_act_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, stream, nb, N, K,
+                       partial, dW, db);
+  }
   return check_hip(hipGetLastError(), "wgrad_act_reduce_kernel");
 }
 

@@ -295,6 +295,7 @@ int ganet_mlp_bwd_data(int64_t M, int32_t O, const float* g, int64_t ldg, const 
                     "hipFuncSetAttribute")) return 3;                                              \
       attr_set = true;                                                                             \
     }                                                                                              \
+    ProfScope prof_(K_BWD_DATA, stream);                                                           \
     hipLaunchKernelGGL((mlp_bwd_kernel<T, AC, SG>), grid, block, lds, stream, M, O, g, ldg, gz, ldgz, \
                        gcoef, Wt, out, ldo, src_z, ld_src, src_scale, src_shift, col_part);        \
   } while (0)
@@ -323,6 +324,7 @@ int ganet_mlp_head_bwd(int64_t M, int32_t N8, const float* g, const float* W8, c
     set_error("ganet_mlp_head_bwd: invalid arguments");
     return 1;
   }
+  ProfScope prof_(K_HEAD_BWD, static_cast<hipStream_t>(stream_));
   hipLaunchKernelGGL(head_bwd_kernel, dim3(HEAD_BLOCKS), dim3(256), 0,
                      static_cast<hipStream_t>(stream_), M, N8, g, W8, z, ldz, scale, shift, G, ldG,
                      col_part);
@@ -336,6 +338,7 @@ int ganet_mlp_bwd_stats(int64_t M, int32_t nparts, const float* col_part, const 
     set_error("ganet_mlp_bwd_stats: invalid arguments");
     return 1;
   }
+  ProfScope prof_(K_BWD_STATS, static_cast<hipStream_t>(stream_));
   hipLaunchKernelGGL(bwd_stats_kernel, dim3(128), dim3(256), 0, static_cast<hipStream_t>(stream_),
                      nparts, M, col_part, mean, rstd, scale, coef, dgamma, dbeta);
   return check_hip(hipGetLastError(), "bwd_stats_kernel");

@@ -165,6 +165,7 @@ int ganet_ssim_fwd(int32_t planes, int32_t H, int32_t W, const float* img1, cons
   int rc = check_hip(hipMemsetAsync(ssim_sum, 0, sizeof(float), stream), "memset ssim_sum");
   if (rc) return rc;
   const dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, planes);
+  ProfScope prof_(K_SSIM_FWD, stream);
   hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(TX * TY), 0, stream, H, W, img1, img2, ssim_sum,
                      partials, (size_t)planes * H * W, make_window());
   return check_hip(hipGetLastError(), "ssim_fwd_kernel");
@@ -178,6 +179,7 @@ int ganet_ssim_bwd(int32_t planes, int32_t H, int32_t W, const float* img1, cons
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, planes);
+  ProfScope prof_(K_SSIM_BWD, stream);
   hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(TX * TY), 0, stream, H, W, img1, img2, partials,
                      (size_t)planes * H * W, scale_dev, dimg1, make_window());
   return check_hip(hipGetLastError(), "ssim_bwd_kernel");

@@ -28,7 +28,7 @@ void set_error(const char* fmt, ...) {
 namespace {
 struct ProfRec { hipEvent_t start, stop; int id; };
 std::mutex g_prof_mu;
-bool g_prof_on = false;
+unsigned g_prof_mask = 0;     // bit k: time kernel id k
 std::vector<ProfRec> g_prof_recs;     // recorded, not yet read
 std::vector<ProfRec> g_prof_free;     // recycled event pairs
 double g_prof_ms[K_COUNT] = {0};
@@ -36,7 +36,7 @@ int64_t g_prof_n[K_COUNT] = {0};
 }  // namespace
 
 ProfScope::ProfScope(KernelId id, hipStream_t s) : slot(-1), stream(s) {
-  if (!g_prof_on) return;
+  if (!((g_prof_mask >> id) & 1u)) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfRec r;
   if (!g_prof_free.empty()) { r = g_prof_free.back(); g_prof_free.pop_back(); }
@@ -380,7 +380,7 @@ int gsr_read_status(const void* workspace, int32_t P, int32_t W, int32_t H, int6
 
 int gsr_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_prof_on = on != 0;
+  g_prof_mask = (unsigned)on;
   return GSR_OK;
 }
 

@@ -23,6 +23,34 @@ def _stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def profile_kernels() -> tuple:
+    lib = _native.ganet()
+    return tuple(lib.ganet_profile_kernel_name(i).decode() for i in range(lib.ganet_profile_count()))
+
+
+def profile_enable(on=True) -> None:
+    """Bracket the decoder / SSIM kernel launches with HIP events on their stream (bench only). `on`:
+    True = every kernel, False = off, or an iterable of kernel names to time only those."""
+    names = profile_kernels()
+    if on is True:
+        mask = (1 << len(names)) - 1
+    elif not on:
+        mask = 0
+    else:
+        mask = sum(1 << names.index(k) for k in on)
+    _native.ganet_check(_native.ganet().ganet_profile_enable(mask))
+
+
+def profile_read(reset: bool = True) -> dict:
+    """{kernel name: (total ms, launches)} from the in-library HIP events (blocks until they completed)."""
+    lib = _native.ganet()
+    n = lib.ganet_profile_count()
+    ms = (ctypes.c_double * n)()
+    cnt = (ctypes.c_int64 * n)()
+    _native.ganet_check(lib.ganet_profile_read(ms, cnt, 1 if reset else 0))
+    return {lib.ganet_profile_kernel_name(i).decode(): (ms[i], int(cnt[i])) for i in range(n)}
+
+
 def wgrad_supported(N: int, K: int) -> bool:
     return N <= 128 and K <= 224
 

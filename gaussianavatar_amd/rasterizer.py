@@ -172,9 +172,19 @@ def pair_statistics(reset: bool = False):
     return n, (s / n if n else 0.0)
 
 
-def profile_enable(on: bool = True) -> None:
-    """Bracket every rasterizer kernel launch with HIP events on its stream (bench only)."""
-    _native.gsr_check(_native.gsr().gsr_profile_enable(1 if on else 0))
+PROFILE_KERNELS = ("preprocess", "tile_scan", "scatter", "tile_sort", "render_fwd", "render_bwd", "preprocess_bwd")
+
+
+def profile_enable(on=True) -> None:
+    """Bracket rasterizer kernel launches with HIP events on their stream (bench only). `on`: True =
+    every kernel, False = off, or an iterable of kernel names (PROFILE_KERNELS) to time only those."""
+    if on is True:
+        mask = (1 << len(PROFILE_KERNELS)) - 1
+    elif not on:
+        mask = 0
+    else:
+        mask = sum(1 << PROFILE_KERNELS.index(k) for k in on)
+    _native.gsr_check(_native.gsr().gsr_profile_enable(mask))
 
 
 def profile_read(reset: bool = True) -> dict:

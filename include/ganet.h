@@ -127,6 +127,15 @@ int ganet_mlp_bwd_stats(int64_t M, int32_t nparts, const float* col_part, const 
                         const float* rstd, const float* scale, float* coef, float* dgamma,
                         float* dbeta, void* stream);
 
+/* Optional per-kernel timing (bench/profiling only; off by default, the one piece of process-global
+ * state in the library): every instrumented launch is bracketed by hipEvents recorded on the launch
+ * stream; ganet_profile_read waits for them and returns, per kernel id < ganet_profile_count(), the
+ * summed GPU time in ms and the launch count since the last reset. */
+int ganet_profile_enable(int mask);   /* bit k = time kernel id k; 0 = off */
+int ganet_profile_count(void);
+int ganet_profile_read(double* ms_sum, int64_t* launches, int reset);
+const char* ganet_profile_kernel_name(int id);
+
 const char* ganet_last_error(void);
 int ganet_abi_version(void);
 

@@ -216,7 +216,7 @@ int gsr_read_status(const void* workspace, int32_t P, int32_t W, int32_t H,
  * 5 render_bwd, 6 preprocess_bwd.
  */
 #define GSR_NUM_KERNELS 7
-int gsr_profile_enable(int on);
+int gsr_profile_enable(int mask);   /* bit k = time kernel id k; 0 = off; 0x7f = all */
 int gsr_profile_read(double* ms_sum, int64_t* launches, int reset);
 const char* gsr_profile_kernel_name(int id);
 

@@ -39,17 +39,23 @@ def main():
     print("mlp_fwd  K1=72+K2=128      %7.1f us" % timeit(lambda: fused._mlp_fwd(lib, M, 128, x72, z, sc, sh, W200, b, part, dev)))
     print("mlp_fwd  K2=128 N=3        %7.1f us" % timeit(lambda: fused._mlp_fwd(lib, M, 3, None, z, sc, sh, W3, b[:3].contiguous(), None, dev)))
     g = torch.randn(M, 128, device=dev)
+    gz = torch.randn(M, 128, device=dev)
+    coef = torch.randn(3, 128, device=dev)
     dW = torch.empty(128, 128, device=dev); db = torch.empty(128, device=dev)
     nb = lib.ganet_wgrad_act_workspace(M, 128, 128)
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-    f = lambda: lib.ganet_wgrad_act(M, 128, 128, fused._ptr(g), 128, fused._ptr(z), 128, fused._ptr(sc), fused._ptr(sh),
-                                    fused._ptr(dW), fused._ptr(db), fused._ptr(ws), nb, fused._stream(dev))
-    print("wgrad_act 128x128          %7.1f us" % timeit(f))
-    nb2 = lib.ganet_linear_wgrad_workspace(M, 128, 128)
-    ws2 = torch.empty(nb2, dtype=torch.uint8, device=dev)
-    f2 = lambda: lib.ganet_linear_wgrad(M, 128, 128, fused._ptr(g), 128, fused._ptr(z), 128, fused._ptr(dW), fused._ptr(db),
-                                        fused._ptr(ws2), nb2, fused._stream(dev))
-    print("linear_wgrad 128x128       %7.1f us" % timeit(f2))
+    st = fused._stream(dev)
+    P = fused._ptr
+    f = lambda: lib.ganet_wgrad_act(M, 128, 128, P(g), 128, None, 0, None, P(z), 128, P(sc), P(sh), P(dW), P(db), P(ws), nb, st)
+    print("wgrad_act raw g            %7.1f us" % timeit(f))
+    f = lambda: lib.ganet_wgrad_act(M, 128, 128, P(g), 128, P(gz), 128, P(coef), P(z), 128, P(sc), P(sh), P(dW), P(db), P(ws), nb, st)
+    print("wgrad_act (G,z,coef)       %7.1f us" % timeit(f))
+    out = torch.empty(M, 128, device=dev)
+    part = torch.zeros(lib.ganet_mlp_bwd_data_parts() * 256, device=dev)
+    f = lambda: lib.ganet_mlp_bwd_data(M, 128, P(g), 128, P(gz), 128, P(coef), P(W), P(out), 128, 0, P(z), 128, P(sc), P(sh), P(part), st)
+    print("mlp_bwd_data sig           %7.1f us" % timeit(f))
+    f = lambda: lib.ganet_mlp_bwd_data(M, 128, P(g), 128, P(gz), 128, P(coef), P(W), P(out), 128, 0, None, 0, None, None, None, st)
+    print("mlp_bwd_data raw           %7.1f us" % timeit(f))
     bn = torch.nn.BatchNorm1d(128).cuda().train()
     print("bn+softplus fwd            %7.1f us" % timeit(lambda: fused.batchnorm_act(z, bn, "softplus")))
 
