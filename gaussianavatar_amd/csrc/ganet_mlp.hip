@@ -34,12 +34,21 @@ namespace ganet {
 
 namespace {
 
-constexpr int WG = 512;               // 8 waves, one workgroup per CU
+#ifndef GANET_FWD_WG
+#define GANET_FWD_WG 512
+#endif
+#ifndef GANET_FWD_WPE
+#define GANET_FWD_WPE 2
+#endif
+#ifndef GANET_FWD_BLOCKS
+#define GANET_FWD_BLOCKS 256
+#endif
+constexpr int WG = GANET_FWD_WG;      // 8 waves, one workgroup per CU
 constexpr int WAVES = WG / 64;
 constexpr int SLAB = 32;              // rows per wave step
-constexpr int FWD_BLOCKS = 256;
+constexpr int FWD_BLOCKS = GANET_FWD_BLOCKS;
 template <int K1B, int K2B, int NT>
-__global__ void __attribute__((amdgpu_flat_work_group_size(WG, WG), amdgpu_waves_per_eu(2, 2)))
+__global__ void __attribute__((amdgpu_flat_work_group_size(WG, WG), amdgpu_waves_per_eu(GANET_FWD_WPE, GANET_FWD_WPE)))
 mlp_fwd_kernel(int64_t M, int N, const float* __restrict__ x1, int64_t ld1,
                const float* __restrict__ x2, int64_t ld2, const float* __restrict__ in_scale,
                const float* __restrict__ in_shift, const float* __restrict__ W,
@@ -57,11 +66,21 @@ mlp_fwd_kernel(int64_t M, int N, const float* __restrict__ x1, int64_t ld1,
   const int lane = threadIdx.x & 63;
   const int h = lane >> 5, col = lane & 31;
 
-  for (int i = threadIdx.x; i < NP * (K / 4); i += WG) {
-    const int n = i / (K / 4), k4 = i - n * (K / 4);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (n < N) v = *reinterpret_cast<const float4*>(W + (size_t)n * K + 4 * k4);
-    s_w[n * LDW4 + k4] = v;
+  {   // stage W: all global loads first (branch-free, clamped row), then the LDS stores
+    constexpr int PER = (NP * (K / 4) + WG - 1) / WG;
+    float4 wv[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = min((int)threadIdx.x + j * WG, NP * (K / 4) - 1);
+      const int n = i / (K / 4), k4 = i - n * (K / 4);
+      wv[j] = *reinterpret_cast<const float4*>(W + (size_t)min(n, N - 1) * K + 4 * k4);
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = threadIdx.x + j * WG;
+      const int n = i / (K / 4), k4 = i - n * (K / 4);
+      if (i < NP * (K / 4)) s_w[n * LDW4 + k4] = n < N ? wv[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
   for (int i = threadIdx.x; i < 2 * K2B; i += WG) {
     s_sc[i] = *reinterpret_cast<const float4*>(in_scale + 4 * i);
@@ -120,17 +139,23 @@ mlp_fwd_kernel(int64_t M, int N, const float* __restrict__ x1, int64_t ld1,
       if (b >= K1B) {
         const float4 sc = s_sc[soff + 2 * (b - K1B)];
         const float4 sh = s_sh[soff + 2 * (b - K1B)];
+#ifdef GANET_EXP_NOACT
+        av0 = fmaf(sc.x, av0, sh.x); av1 = fmaf(sc.y, av1, sh.y); av2 = fmaf(sc.z, av2, sh.z); av3 = fmaf(sc.w, av3, sh.w);
+#else
         av0 = softplus_f(fmaf(sc.x, av0, sh.x));
         av1 = softplus_f(fmaf(sc.y, av1, sh.y));
         av2 = softplus_f(fmaf(sc.z, av2, sh.z));
         av3 = softplus_f(fmaf(sc.w, av3, sh.w));
+#endif
         // the raw values are dead now: refill the slot (activated blocks). The two scheduling
         // barriers let VALU / LDS / scalar work flow across but pin the load between this block's
         // and the previous block's MFMAs — left alone, the scheduler sinks the refills to just
         // before their use and exposes the full HBM latency.
+#ifndef GANET_EXP_NOLOAD
         __builtin_amdgcn_sched_barrier(kSchedMask);
         a[slot] = (b + D < KB) ? load_block(p1c, p2c, b + D) : load_block(p1n, p2n, b + D - KB);
         __builtin_amdgcn_sched_barrier(kSchedMask);
+#endif
       }
       float4 bw[NT];
 #pragma unroll
@@ -154,6 +179,10 @@ mlp_fwd_kernel(int64_t M, int N, const float* __restrict__ x1, int64_t ld1,
     // epilogue: + bias, store, column statistics. C/D layout of the 32x32 MFMA: column = lane & 31,
     // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int64_t row0 = slab * SLAB;
+#ifdef GANET_EXP_NOEPI
+    if (acc[0][0] == 123.456f) z[0] = acc[1][1] + acc[2][2] + acc[3 % NT][3];
+    else
+#endif
     if (row0 + SLAB <= M && N == NP) {
       float* zr = z + (row0 + 4 * h) * ldz + col;
 #pragma unroll

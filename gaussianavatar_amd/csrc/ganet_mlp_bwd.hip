@@ -55,11 +55,21 @@ mlp_bwd_kernel(int64_t M, int O, const float* __restrict__ g, int64_t ldg,
   const int lane = threadIdx.x & 63;
   const int h = lane >> 5, col = lane & 31;
 
-  for (int i = threadIdx.x; i < NP * (K / 4); i += WG) {
-    const int n = i / (K / 4), k4 = i - n * (K / 4);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (n < O) v = *reinterpret_cast<const float4*>(Wt + (size_t)n * K + 4 * k4);
-    s_w[n * LDW4 + k4] = v;
+  {   // stage Wt: all global loads first (branch-free, clamped row), then the LDS stores
+    constexpr int PER = (NP * (K / 4) + WG - 1) / WG;
+    float4 wv[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = min((int)threadIdx.x + j * WG, NP * (K / 4) - 1);
+      const int n = i / (K / 4), k4 = i - n * (K / 4);
+      wv[j] = *reinterpret_cast<const float4*>(Wt + (size_t)min(n, O - 1) * K + 4 * k4);
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = threadIdx.x + j * WG;
+      const int n = i / (K / 4), k4 = i - n * (K / 4);
+      if (i < NP * (K / 4)) s_w[n * LDW4 + k4] = n < O ? wv[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
   for (int i = threadIdx.x; i < 32; i += WG) {
     s_cA[i] = *reinterpret_cast<const float4*>(gcoef + 4 * i);
@@ -139,18 +149,34 @@ mlp_bwd_kernel(int64_t M, int O, const float* __restrict__ g, int64_t ldg,
     // epilogue. C/D layout: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int64_t row0 = slab * SLAB;
     const bool full = row0 + SLAB <= M && O == NP;
+    // The source layer's pre-activations are not cached: issue the loads of ALL tiles before the
+    // first use, so that a slab pays one memory latency instead of one per tile.
+    constexpr bool PRELOAD = SIG && !ACCUM;     // (the accumulate variant would spill: per tile there)
+    float sz[PRELOAD ? NT : 1][16];
+    if (PRELOAD) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int o = t * 32 + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const bool ok = full || (row < M && o < O);
+          sz[t][r] = src_z[(ok ? row : 0) * ld_src + (ok ? o : 0)];
+        }
+      }
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int o = t * 32 + col;
-      float sz[16], ex[16];
+      float ex[16], szt[16];
+      if (ACCUM) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const bool ok = full || (row < M && o < O);
-        const int64_t rr = ok ? row : 0;
-        const int oo = ok ? o : 0;
-        if (SIG) sz[r] = src_z[rr * ld_src + oo];
-        if (ACCUM) ex[r] = out[rr * ldo + oo];
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const bool ok = full || (row < M && o < O);
+          ex[r] = out[(ok ? row : 0) * ldo + (ok ? o : 0)];
+          if (SIG) szt[r] = src_z[(ok ? row : 0) * ld_src + (ok ? o : 0)];
+        }
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -159,8 +185,9 @@ mlp_bwd_kernel(int64_t M, int O, const float* __restrict__ g, int64_t ldg,
         float v = acc[t][r];
         if (ACCUM) v += ex[r];
         if (SIG) {
-          v *= softplus_grad_f(fmaf(ssc[t], sz[r], ssh[t]));
-          if (ok) { csum[t] += v; csz[t] = fmaf(v, sz[r], csz[t]); }
+          const float zv = PRELOAD ? sz[PRELOAD ? t : 0][r] : szt[r];
+          v *= softplus_grad_f(fmaf(ssc[t], zv, ssh[t]));
+          if (ok) { csum[t] += v; csz[t] = fmaf(v, zv, csz[t]); }
         }
         if (ok) out[row * ldo + o] = v;
       }
