@@ -37,11 +37,12 @@ EVENT_EVERY = 10          # timed steps whose dominant-family launches carry HIP
 MFMA_F32_PEAK_TF = 157.3  # dense fp32-input MFMA peak (same guide; v_mfma_f32_32x32x2_f32)
 
 
-def decoder_flops(model) -> dict:
-    """Algorithmic flops (2 M N K per GEMM) of one stage-1 iteration's decoder launches, by kernel
-    family. Stage 1 evaluates the batch-invariant decoder once: M = UV texels (S^2)."""
+def decoder_flops(model, frames: int = 1) -> dict:
+    """Algorithmic flops (2 M N K per GEMM) of one iteration's decoder launches, by kernel family.
+    Stage 1 evaluates the batch-invariant decoder once (frames=1): M = UV texels (S^2); stage 2
+    evaluates it for every frame of the rank's batch: M = frames * S^2."""
     dec = model.net.decoder
-    M = float(model.uv_coord_map.shape[0])
+    M = float(model.uv_coord_map.shape[0]) * frames
     h, cin = dec.hsize, dec.in_size
     hidden = cin * h + 3 * h * h + (h + cin) * h + 6 * h * h      # conv1, conv2-4, conv5, conv6/7 x 3 heads
     outs = h * (3 + 1 + 3)                                        # conv8 x 3 heads
@@ -145,6 +146,11 @@ def main():
     ap.add_argument("--points", type=int, default=200_000)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--frames-per-gpu", type=int, default=2)
+    ap.add_argument("--height", type=int, default=0, help="image height if it differs from --size (e.g. 1080)")
+    ap.add_argument("--stage", type=int, default=1, choices=(1, 2),
+                    help="2 = stage-2 iteration (pose-encoder UNet on, per-frame decoder input); secondary "
+                         "workload of BASELINE.json configs[4], the headline metric is stage 1")
+    ap.add_argument("--smpl-type", default="smpl", choices=("smpl", "smplx"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket rasterizer kernels with HIP events in the timed region")
@@ -167,12 +173,14 @@ def main():
     torch.manual_seed(0)      # identical init on every rank (replicas must start identical)
     B = args.frames_per_gpu
     mp, npar, op = default_params(batch_size=B, num_points=args.points, image_width=args.size,
-                                  image_height=args.size, num_frames=max(16, B * world))
+                                  image_height=args.height or args.size, num_frames=max(16, B * world),
+                                  train_stage=args.stage, smpl_type=args.smpl_type)
     model = AvatarModel(mp, npar, op, train=True, device=dev)
     model.training_setup()
     model.net.train()
     ds = model.train_dataset
-    H = W = args.size
+    W = args.size
+    H = args.height or args.size
     # target images: white background (as the reference composites) with a grey silhouette band
     gt = torch.ones(B, 3, H, W, device=dev)
     gt[:, :, H // 5: 4 * H // 5, 2 * W // 5: 3 * W // 5] = 0.6
@@ -182,13 +190,26 @@ def main():
         ids = [(s * world * B + rank * B + k) % nf for k in range(B)]
         batches.append(collate_frames([ds[i] for i in ids], dev))
     epoch, iteration = 1, 7   # iteration 7 < 1000: scale warm-up gives ~3.5 mm Gaussians at init
+    if args.stage == 2:
+        # the reference's stage 2 starts from a trained stage-1 checkpoint (no scale warm-up,
+        # /root/reference/model/avatar_model.py:416); a random-init scale head would give 0.5 m
+        # Gaussians (every Gaussian on every tile). Stand-in: scale head biased to ~3.5 mm.
+        with torch.no_grad():
+            model.net.decoder.conv8N.weight.mul_(0.01)
+            model.net.decoder.conv8N.bias.fill_(-5.65)
 
     def step(i):
         batch = batches[i % len(batches)]
-        image, points, offset_loss, geo_loss, scale_loss = model.train_stage1(batch, iteration)
-        Ll1 = (1.0 - op.lambda_dssim) * l1_loss_w(image, gt)
-        ssim_loss = op.lambda_dssim * (1.0 - ssim(image, gt))
-        loss = op.lambda_scale * scale_loss + op.lambda_rgl * offset_loss + Ll1 + ssim_loss + geo_loss
+        if args.stage == 1:            # /root/reference/train.py:68-76
+            image, points, offset_loss, geo_loss, scale_loss = model.train_stage1(batch, iteration)
+            Ll1 = (1.0 - op.lambda_dssim) * l1_loss_w(image, gt)
+            ssim_loss = op.lambda_dssim * (1.0 - ssim(image, gt))
+            loss = op.lambda_scale * scale_loss + op.lambda_rgl * offset_loss + Ll1 + ssim_loss + geo_loss
+        else:                          # /root/reference/train.py:78-86
+            image, points, pose_loss, offset_loss = model.train_stage2(batch, iteration)
+            Ll1 = (1.0 - op.lambda_dssim) * l1_loss_w(image, gt)
+            ssim_loss = op.lambda_dssim * (1.0 - ssim(image, gt))
+            loss = op.lambda_rgl * offset_loss + Ll1 + ssim_loss + pose_loss * 10
         model.zero_grad(epoch)
         loss.backward()
         model.step(epoch)
@@ -252,9 +273,11 @@ def main():
         "value": value, "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"stage-1 train iteration (LBS + feature net + skinning + Gaussian rasterizer "
+        "config": {"workload": f"stage-{args.stage} train iteration (LBS + feature net + skinning + Gaussian rasterizer "
                                f"fwd+bwd + L1/DSSIM + Adam), {N} Gaussians, {W}x{H}, {B} frames per GPU "
-                               f"(BASELINE.json configs[2]); synthetic SMPL-shaped body, random-init net",
+                               + ("(BASELINE.json configs[2])" if (args.stage, N, W, H) == (1, 200_000, 1024, 1024)
+                                  else "(secondary workload)")
+                               + f"; synthetic {args.smpl_type.upper()}-shaped body, random-init net",
                    "gaussians": N, "image": [H, W], "frames_per_gpu": B, "global_batch": B * world,
                    "parallelism": f"frame-sharded dp{world}, one all-reduce of [N,7] output grads",
                    "mean_tile_pairs_per_frame": mean_pairs, "final_loss": final_loss},
@@ -262,7 +285,7 @@ def main():
     if probe:
         # one launch of every rasterizer kernel processes all B frames of the rank's batch
         alg = {k: v * B for k, v in algorithmic_bytes(N, mean_pairs, H * W).items()}
-        dflops = decoder_flops(model)
+        dflops = decoder_flops(model, 1 if args.stage == 1 else B)
         stage_of = {"preprocess": "preprocess", "tile_scan": "binning", "scatter": "binning", "tile_sort": "binning",
                     "render_fwd": "render_fwd", "render_bwd": "render_bwd", "preprocess_bwd": "preprocess_bwd"}
 
