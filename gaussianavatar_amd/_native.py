@@ -182,8 +182,8 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_mlp_bwd_data_parts.restype = c_int32
         lib.ganet_mlp_head_bwd_parts.restype = c_int32
         lib.ganet_mlp_bwd_data.restype = c_int
-        lib.ganet_mlp_bwd_data.argtypes = [c_int64, c_int32, P, c_int64, P, c_int64, P, P, P, c_int64, c_int32, P,
-                                           c_int64, P, P, P, P]
+        lib.ganet_mlp_bwd_data.argtypes = [c_int64, c_int32, P, c_int64, P, c_int64, P, P, c_int64, P, c_int64, c_int32,
+                                           P, c_int64, P, P, P, P]
         lib.ganet_mlp_head_bwd.restype = c_int
         lib.ganet_mlp_head_bwd.argtypes = [c_int64, c_int32, P, P, P, c_int64, P, P, P, c_int64, P, P]
         lib.ganet_mlp_bwd_stats.restype = c_int

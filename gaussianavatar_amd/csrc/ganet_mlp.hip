@@ -215,18 +215,27 @@ mlp_fwd_kernel(int64_t M, int N, const float* __restrict__ x1, int64_t ld1,
     }
   }
   if (col_part) {
-    // per-wave partial column sums -> [gridDim.x * WAVES][2][NP]
-    float* o = col_part + (size_t)wave_global * 2 * NP;
+    // per-workgroup partial column sums -> [gridDim.x][2][NP]: the waves combine through LDS (W is
+    // dead by now), in fixed order
+    __syncthreads();
+    float* s_red = reinterpret_cast<float*>(s_mem);        // [WAVES][2 * NP]
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const float s = csum[t] + __shfl_xor(csum[t], 32);
       const float q = csq[t] + __shfl_xor(csq[t], 32);
-      if (h == 0) { o[t * 32 + col] = s; o[NP + t * 32 + col] = q; }
+      if (h == 0) { s_red[wave * 2 * NP + t * 32 + col] = s; s_red[wave * 2 * NP + NP + t * 32 + col] = q; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * NP; i += WG) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) v += s_red[w * 2 * NP + i];
+      col_part[(size_t)blockIdx.x * 2 * NP + i] = v;
     }
   }
 }
 
-// One workgroup per column: sum the per-wave partials in double, then mean / rstd, the folded
+// One workgroup per column: sum the per-workgroup partials in double, then mean / rstd, the folded
 // scale = gamma * rstd and shift = beta - mean * scale the next layer's prologue applies, and the
 // running statistics exactly as F.batch_norm(training=True) updates them.
 __global__ void __launch_bounds__(256)
@@ -472,7 +481,7 @@ extern "C" {
 
 size_t ganet_mlp_stats_floats(int32_t N) {
   if (N <= 0 || N > 128) return 0;
-  return (size_t)FWD_BLOCKS * WAVES * 2 * (size_t)(((N + 31) / 32) * 32);
+  return (size_t)FWD_BLOCKS * 2 * (size_t)(((N + 31) / 32) * 32);
 }
 
 int ganet_mlp_fwd(int64_t M, int32_t N, int32_t K1, int32_t K2, const float* x1, int64_t ld1,
@@ -532,7 +541,7 @@ int ganet_mlp_stats(int64_t M, int32_t N, const float* col_part, const float* ga
   const int np = ((N + 31) / 32) * 32;
   ProfScope prof_(K_MLP_STATS, static_cast<hipStream_t>(stream_));
   hipLaunchKernelGGL(mlp_stats_kernel, dim3(N), dim3(256), 0, static_cast<hipStream_t>(stream_),
-                     FWD_BLOCKS * WAVES, np, M, col_part, gamma, beta, eps, mean, rstd, scale, shift,
+                     FWD_BLOCKS, np, M, col_part, gamma, beta, eps, mean, rstd, scale, shift,
                      running_mean, running_var, momentum,
                      reinterpret_cast<long long*>(num_batches_tracked));
   return check_hip(hipGetLastError(), "mlp_stats_kernel");

@@ -34,12 +34,12 @@ constexpr int SLAB = 32;
 constexpr int BWD_BLOCKS = 256;
 constexpr int HEAD_BLOCKS = 512;
 
-// out[M,O] (+)= (A G + q Z + p)[M,128] . Wt[O,128]^T ; SIG: out *= softplus'(src_scale src_z + src_shift)
+// out[M,O] (+)= (A G + q Z + p)[M,128] . W[128, 0:O] ; SIG: out *= softplus'(src_scale src_z + src_shift)
 template <int NT, bool ACCUM, bool SIG>
 __global__ void __attribute__((amdgpu_flat_work_group_size(WG, WG), amdgpu_waves_per_eu(2, 2)))
 mlp_bwd_kernel(int64_t M, int O, const float* __restrict__ g, int64_t ldg,
                const float* __restrict__ gz, int64_t ldgz, const float* __restrict__ gcoef,
-               const float* __restrict__ Wt, float* __restrict__ out, int64_t ldo,
+               const float* __restrict__ W, int64_t ldw, float* __restrict__ out, int64_t ldo,
                const float* __restrict__ src_z, int64_t ld_src, const float* __restrict__ src_scale,
                const float* __restrict__ src_shift, float* __restrict__ col_part) {
   constexpr int KB = 16, K = 128;
@@ -55,20 +55,22 @@ mlp_bwd_kernel(int64_t M, int O, const float* __restrict__ g, int64_t ldg,
   const int lane = threadIdx.x & 63;
   const int h = lane >> 5, col = lane & 31;
 
-  {   // stage Wt: all global loads first (branch-free, clamped row), then the LDS stores
-    constexpr int PER = (NP * (K / 4) + WG - 1) / WG;
-    float4 wv[PER];
+  {   // stage W[128(n)][ldw] transposed into s_w[o][n] (row o of the LDS image = column o of W):
+      // all global loads first (scalar: W may be a column slice with any alignment), then LDS stores
+    constexpr int PER = (K * NP + WG - 1) / WG;            // elements per thread
+    float* s_wf = reinterpret_cast<float*>(s_w);
+    float wv[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
-      const int i = min((int)threadIdx.x + j * WG, NP * (K / 4) - 1);
-      const int n = i / (K / 4), k4 = i - n * (K / 4);
-      wv[j] = *reinterpret_cast<const float4*>(Wt + (size_t)min(n, O - 1) * K + 4 * k4);
+      const int i = min((int)threadIdx.x + j * WG, K * NP - 1);
+      const int n = i / NP, o = i - n * NP;               // consecutive threads: consecutive columns o
+      wv[j] = W[(size_t)n * ldw + min(o, O - 1)];
     }
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
       const int i = threadIdx.x + j * WG;
-      const int n = i / (K / 4), k4 = i - n * (K / 4);
-      if (i < NP * (K / 4)) s_w[n * LDW4 + k4] = n < O ? wv[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int n = i / NP, o = i - n * NP;
+      if (i < K * NP) s_wf[o * (4 * LDW4) + n] = o < O ? wv[j] : 0.f;
     }
   }
   for (int i = threadIdx.x; i < 32; i += WG) {
@@ -194,12 +196,21 @@ mlp_bwd_kernel(int64_t M, int O, const float* __restrict__ g, int64_t ldg,
     }
   }
   if (SIG && col_part) {
-    float* op = col_part + (size_t)wave_global * 2 * 128;
+    // per-workgroup partial sums -> [gridDim.x][2][128], combined through LDS in fixed order
+    __syncthreads();
+    float* s_red = reinterpret_cast<float*>(s_mem);        // [WAVES][256]
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const float s = csum[t] + __shfl_xor(csum[t], 32);
       const float q = csz[t] + __shfl_xor(csz[t], 32);
-      if (h == 0) { op[t * 32 + col] = s; op[128 + t * 32 + col] = q; }
+      if (h == 0) { s_red[wave * 256 + t * 32 + col] = s; s_red[wave * 256 + 128 + t * 32 + col] = q; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += WG) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) v += s_red[w * 256 + i];
+      col_part[(size_t)blockIdx.x * 256 + i] = v;
     }
   }
 }
@@ -295,17 +306,18 @@ using namespace ganet;
 
 extern "C" {
 
-int32_t ganet_mlp_bwd_data_parts(void) { return BWD_BLOCKS * WAVES; }
+int32_t ganet_mlp_bwd_data_parts(void) { return BWD_BLOCKS; }
 int32_t ganet_mlp_head_bwd_parts(void) { return HEAD_BLOCKS; }
 
 int ganet_mlp_bwd_data(int64_t M, int32_t O, const float* g, int64_t ldg, const float* gz, int64_t ldgz,
-                       const float* gcoef, const float* Wt, float* out, int64_t ldo, int32_t accumulate,
+                       const float* gcoef, const float* W, int64_t ldw, float* out, int64_t ldo,
+                       int32_t accumulate,
                        const float* src_z, int64_t ld_src, const float* src_scale,
                        const float* src_shift, float* col_part, void* stream_) {
   const bool sig = src_z != nullptr;
-  if (M <= 0 || O <= 0 || O > 128 || !g || !gz || !gcoef || !Wt || !out || ldo < O || (ldg % 4) ||
+  if (M <= 0 || O <= 0 || O > 128 || !g || !gz || !gcoef || !W || ldw < O || !out || ldo < O || (ldg % 4) ||
       (ldgz % 4) || ldg < 128 || ldgz < 128 || !aligned16(g) || !aligned16(gz) || !aligned16(gcoef) ||
-      !aligned16(Wt) || (sig && (!src_scale || !src_shift || !col_part || ld_src < O))) {
+      (sig && (!src_scale || !src_shift || !col_part || ld_src < O))) {
     set_error("ganet_mlp_bwd_data: invalid arguments");
     return 1;
   }
@@ -324,7 +336,7 @@ int ganet_mlp_bwd_data(int64_t M, int32_t O, const float* g, int64_t ldg, const 
     }                                                                                              \
     ProfScope prof_(K_BWD_DATA, stream);                                                           \
     hipLaunchKernelGGL((mlp_bwd_kernel<T, AC, SG>), grid, block, lds, stream, M, O, g, ldg, gz, ldgz, \
-                       gcoef, Wt, out, ldo, src_z, ld_src, src_scale, src_shift, col_part);        \
+                       gcoef, W, ldw, out, ldo, src_z, ld_src, src_scale, src_shift, col_part);    \
   } while (0)
   const bool acc = accumulate != 0;
   if (nt == 4 && !acc && sig) LAUNCH(4, false, true);

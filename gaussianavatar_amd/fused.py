@@ -205,9 +205,16 @@ _HEAD_TAGS = ("", "N", "SH")
 _K1_PAD = 72          # decoder input (64 geometry features + 2 uv = 66 columns) padded to 8-float blocks
 
 
+def decoder_input_pad(dec, like) -> int:
+    """Zero columns a caller may append to the decoder input so that the fused path can use it without
+    a padding copy (0 when the fused path does not apply)."""
+    probe = like.new_empty((1, dec.in_size))
+    return _K1_PAD - dec.in_size if decoder_supported(dec, probe) else 0
+
+
 def decoder_supported(dec, x) -> bool:
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and not dec.use_relu
-            and dec.hsize == 128 and dec.in_size <= _K1_PAD and x.shape[1] == dec.in_size
+            and dec.hsize == 128 and dec.in_size <= _K1_PAD and x.shape[1] in (dec.in_size, _K1_PAD)
             and all(getattr(dec, bn).training == dec.training and getattr(dec, bn).affine
                     and getattr(dec, bn).momentum is not None for _, bn in _decoder_bn_layers())
             and (dec.training or not torch.is_grad_enabled()))
@@ -239,7 +246,7 @@ class _DecoderFn(torch.autograd.Function):
     def forward(ctx, x, dec, *params):
         lib = _native.ganet()
         dev = x.device
-        M, cin = x.shape
+        M, cin = x.shape[0], dec.in_size
         layers = _decoder_bn_layers()
         nl = len(layers)
         conv_w = [params[4 * i].squeeze(-1) for i in range(nl)]
@@ -249,8 +256,12 @@ class _DecoderFn(torch.autograd.Function):
         out_w = [params[4 * nl + 2 * j].squeeze(-1) for j in range(3)]
         out_b = [params[4 * nl + 2 * j + 1] for j in range(3)]
         training = dec.training
-        xp = torch.zeros((M, _K1_PAD), dtype=torch.float32, device=dev)
-        xp[:, :cin] = x
+        if x.shape[1] == _K1_PAD and x.is_contiguous():
+            xp = x                           # the caller appended the zero columns (decoder_input_pad)
+        else:
+            xp = torch.zeros((M, _K1_PAD), dtype=torch.float32, device=dev)
+            xp[:, :cin] = x
+        ctx.x_cols = x.shape[1]
         pad_w = lambda w: torch.cat([w, w.new_zeros(w.shape[0], _K1_PAD - cin)], 1).contiguous()
         col_part = torch.empty(lib.ganet_mlp_stats_floats(128), dtype=torch.float32, device=dev) if training else None
 
@@ -353,14 +364,15 @@ class _DecoderFn(torch.autograd.Function):
                                                         _ptr(coef), _ptr(dg), _ptr(dbt), st))
             coefs[i], g_gamma[i], g_beta[i] = coef, dg, dbt
 
-        def data_grad(gi, Wt, out, accumulate, src):
-            """out (+)= dz_gi . W ; with src: out = G_src (and its column sums in col_part)."""
-            O = Wt.shape[0]
+        def data_grad(gi, W, out, accumulate, src):
+            """out[:, :O] (+)= dz_gi . W (W [128, O], possibly a column slice of a wider weight); with
+            src: out = G_src (and its column sums in col_part)."""
+            O = W.shape[1]
             sz = None if src is None else zs[src]
             sc, sh = (None, None) if src is None else stats[src][2:]
             _native.ganet_check(lib.ganet_mlp_bwd_data(
-                M, O, _ptr(Gs[gi]), Gs[gi].stride(0), _ptr(zs[gi]), zs[gi].stride(0), _ptr(coefs[gi]), _ptr(Wt),
-                _ptr(out), out.stride(0), int(accumulate), _ptr(sz), 0 if sz is None else sz.stride(0),
+                M, O, _ptr(Gs[gi]), Gs[gi].stride(0), _ptr(zs[gi]), zs[gi].stride(0), _ptr(coefs[gi]), _ptr(W),
+                W.stride(0), _ptr(out), out.stride(0), int(accumulate), _ptr(sz), 0 if sz is None else sz.stride(0),
                 _ptr(sc), _ptr(sh), _ptr(col_part) if src is not None else None, st))
 
         Gs, coefs = [None] * nl, [None] * nl
@@ -380,43 +392,43 @@ class _DecoderFn(torch.autograd.Function):
             dW, db = wgrad(None, i7, i6)
             g_conv_w[i7], g_conv_b[i7] = dW.unsqueeze(-1), db
             Gs[i6] = f32(M, 128)
-            data_grad(i7, conv_w[i7].t().contiguous(), Gs[i6], False, i6)
+            data_grad(i7, conv_w[i7], Gs[i6], False, i6)
             Gs[i7] = None
             finish(i6, n_data)
             dW, db = wgrad(None, i6, 4)
             g_conv_w[i6], g_conv_b[i6] = dW.unsqueeze(-1), db
             last = pos == len(heads) - 1
-            data_grad(i6, conv_w[i6].t().contiguous(), G5, pos > 0, 4 if last else None)
+            data_grad(i6, conv_w[i6], G5, pos > 0, 4 if last else None)
             Gs[i6] = None
         dx = None
         if heads:
             Gs[4] = G5
             finish(4, n_data)
             w5 = conv_w[4]
-            pad_rows = lambda wt: torch.cat([wt, wt.new_zeros(_K1_PAD - cin, wt.shape[1])], 0).contiguous()
             dWy, db = wgrad(None, 4, 3)
             dWx, _ = wgrad(None, 4, None, _K1_PAD)
             g_conv_w[4], g_conv_b[4] = torch.cat([dWx[:, :cin], dWy], 1).unsqueeze(-1), db
             need_dx = ctx.needs_input_grad[0]
             if need_dx:
-                dxp = f32(M, _K1_PAD)
-                data_grad(4, pad_rows(w5[:, :cin].t()), dxp, False, None)
+                # [M, x_cols]: when the caller passed the zero-padded input, the pad columns of its
+                # gradient are never read (they belong to a constant) and stay unwritten
+                dx = f32(M, ctx.x_cols)
+                data_grad(4, w5[:, :cin], dx, False, None)
             Gs[3] = f32(M, 128)
-            data_grad(4, w5[:, cin:].t().contiguous(), Gs[3], False, 3)
+            data_grad(4, w5[:, cin:], Gs[3], False, 3)
             Gs[4] = None
             for i in (3, 2, 1):
                 finish(i, n_data)
                 dW, db = wgrad(None, i, i - 1)
                 g_conv_w[i], g_conv_b[i] = dW.unsqueeze(-1), db
                 Gs[i - 1] = f32(M, 128)
-                data_grad(i, conv_w[i].t().contiguous(), Gs[i - 1], False, i - 1)
+                data_grad(i, conv_w[i], Gs[i - 1], False, i - 1)
                 Gs[i] = None
             finish(0, n_data)
             dW, db = wgrad(None, 0, None, _K1_PAD)
             g_conv_w[0], g_conv_b[0] = dW[:, :cin].contiguous().unsqueeze(-1), db
             if need_dx:
-                data_grad(0, pad_rows(conv_w[0].t()), dxp, True, None)
-                dx = dxp[:, :cin]
+                data_grad(0, conv_w[0], dx, True, None)
         grads = []
         for i in range(nl):
             grads += [g_conv_w[i], g_conv_b[i], g_gamma[i], g_beta[i]]

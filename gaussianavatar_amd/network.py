@@ -276,8 +276,15 @@ class POP_no_unet(nn.Module):
                 pts = pix.reshape(b, C, HW).transpose(1, 2)
         else:
             pts = pix.reshape(b, C, HW).transpose(1, 2)
-        x = torch.cat([pts, uv_loc], dim=2)                                   # [b, HW, C+2]
-        r, s, c = self.decoder.forward_points(x.reshape(b * HW, C + uv_loc.shape[-1]))
+        parts = [pts, uv_loc]
+        pad = fused.decoder_input_pad(self.decoder, pts)
+        if pad:       # the fused decoder wants 8-float k-blocks: append the zero columns here, for free
+            zkey = (b, HW, pad, pts.device)
+            if getattr(self, "_zero_pad", (None, None))[0] != zkey:
+                self._zero_pad = (zkey, pts.new_zeros(b, HW, pad))
+            parts.append(self._zero_pad[1])
+        x = torch.cat(parts, dim=2)                                           # [b, HW, C+2 (+pad)]
+        r, s, c = self.decoder.forward_points(x.reshape(b * HW, x.shape[2]))
         r, s, c = (t.reshape(b, HW, -1) for t in (r, s, c))
         if shared:
             r, s, c = (t.expand(B, -1, -1) for t in (r, s, c))

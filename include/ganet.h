@@ -105,8 +105,8 @@ int ganet_wgrad_act(int64_t M, int32_t N, int32_t K, const float* g, int64_t ldg
 /* ---- input-gradient side with the BatchNorm + softplus backward folded in (ganet_mlp_bwd.hip) ----
  * For a hidden layer with stored pre-activation z, u = scale z + shift, y = softplus(u):
  *   G  = dL/dy . softplus'(u);   dz = A G + q z + p   (per-column A, q, p from the sums of G and G z).
- * ganet_mlp_bwd_data:  out[M,O] (+)= (A g + q gz + p)[M,128] . Wt[O,128]^T   (Wt = W^T of the layer,
- *   O = 128 or <= 96); with src_z != NULL the result is multiplied by softplus'(src_scale src_z +
+ * ganet_mlp_bwd_data:  out[M,O] (+)= (A g + q gz + p)[M,128] . W[128, 0:O]   (W = the layer's weight
+ *   [128 out, in] or a column slice of it, row stride ldw; O = 128 or <= 96); with src_z != NULL the result is multiplied by softplus'(src_scale src_z +
  *   src_shift) — i.e. out = G of the SOURCE layer — and col_part ([ganet_mlp_bwd_data_parts()][2][128])
  *   receives the partial column sums of out and out . src_z.
  * ganet_mlp_head_bwd:  the same for the narrow output heads (g [M,N8], N8 <= 4, W8 [N8,128]):
@@ -117,7 +117,8 @@ int ganet_wgrad_act(int64_t M, int32_t N, int32_t K, const float* g, int64_t ldg
 int32_t ganet_mlp_bwd_data_parts(void);
 int32_t ganet_mlp_head_bwd_parts(void);
 int ganet_mlp_bwd_data(int64_t M, int32_t O, const float* g, int64_t ldg, const float* gz, int64_t ldgz,
-                       const float* gcoef, const float* Wt, float* out, int64_t ldo, int32_t accumulate,
+                       const float* gcoef, const float* W, int64_t ldw, float* out, int64_t ldo,
+                       int32_t accumulate,
                        const float* src_z, int64_t ld_src, const float* src_scale,
                        const float* src_shift, float* col_part, void* stream);
 int ganet_mlp_head_bwd(int64_t M, int32_t N8, const float* g, const float* W8, const float* z,

@@ -305,7 +305,8 @@ def test_mlp_bwd_data_matches_torch(M, O, accumulate, sig):
     G = torch.randn(M, 128, device=dev)
     z = torch.randn(M, 128, device=dev) * 2
     coef = torch.randn(3, 128, device=dev)
-    Wt = torch.randn(O, 128, device=dev) * 0.1
+    Wfull = torch.randn(128, O + 5, device=dev) * 0.1          # the kernel reads a column slice [128, O]
+    Wt = Wfull[:, 3:3 + O].t()
     out = torch.randn(M, O, device=dev)
     prev = out.clone()
     src_z = torch.randn(M, O, device=dev) * 2 if sig else None
@@ -314,7 +315,8 @@ def test_mlp_bwd_data_matches_torch(M, O, accumulate, sig):
     parts = lib.ganet_mlp_bwd_data_parts()
     part = torch.zeros(parts * 256, device=dev)
     _native.ganet_check(lib.ganet_mlp_bwd_data(M, O, fused._ptr(G), 128, fused._ptr(z), 128, fused._ptr(coef),
-                                               fused._ptr(Wt), fused._ptr(out), O, int(accumulate), fused._ptr(src_z),
+                                               fused._ptr(Wfull[:, 3:]), Wfull.stride(0), fused._ptr(out), O,
+                                               int(accumulate), fused._ptr(src_z),
                                                O if sig else 0, fused._ptr(sc), fused._ptr(sh),
                                                fused._ptr(part) if sig else None, fused._stream(dev)))
     dz = coef[0].double() * G.double() + coef[1].double() * z.double() + coef[2].double()
