@@ -139,23 +139,17 @@ mlp_fwd_kernel(int64_t M, int N, const float* __restrict__ x1, int64_t ld1,
       if (b >= K1B) {
         const float4 sc = s_sc[soff + 2 * (b - K1B)];
         const float4 sh = s_sh[soff + 2 * (b - K1B)];
-#ifdef GANET_EXP_NOACT
-        av0 = fmaf(sc.x, av0, sh.x); av1 = fmaf(sc.y, av1, sh.y); av2 = fmaf(sc.z, av2, sh.z); av3 = fmaf(sc.w, av3, sh.w);
-#else
         av0 = softplus_f(fmaf(sc.x, av0, sh.x));
         av1 = softplus_f(fmaf(sc.y, av1, sh.y));
         av2 = softplus_f(fmaf(sc.z, av2, sh.z));
         av3 = softplus_f(fmaf(sc.w, av3, sh.w));
-#endif
         // the raw values are dead now: refill the slot (activated blocks). The two scheduling
         // barriers let VALU / LDS / scalar work flow across but pin the load between this block's
         // and the previous block's MFMAs — left alone, the scheduler sinks the refills to just
         // before their use and exposes the full HBM latency.
-#ifndef GANET_EXP_NOLOAD
         __builtin_amdgcn_sched_barrier(kSchedMask);
         a[slot] = (b + D < KB) ? load_block(p1c, p2c, b + D) : load_block(p1n, p2n, b + D - KB);
         __builtin_amdgcn_sched_barrier(kSchedMask);
-#endif
       }
       float4 bw[NT];
 #pragma unroll
@@ -179,10 +173,6 @@ mlp_fwd_kernel(int64_t M, int N, const float* __restrict__ x1, int64_t ld1,
     // epilogue: + bias, store, column statistics. C/D layout of the 32x32 MFMA: column = lane & 31,
     // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int64_t row0 = slab * SLAB;
-#ifdef GANET_EXP_NOEPI
-    if (acc[0][0] == 123.456f) z[0] = acc[1][1] + acc[2][2] + acc[3 % NT][3];
-    else
-#endif
     if (row0 + SLAB <= M && N == NP) {
       float* zr = z + (row0 + 4 * h) * ldz + col;
 #pragma unroll

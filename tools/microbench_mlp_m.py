@@ -9,7 +9,9 @@ sc = torch.rand(128, device=dev) + 0.5; sh = torch.randn(128, device=dev)
 W = torch.randn(128, 128, device=dev) * 0.1; b = torch.randn(128, device=dev)
 coef = torch.randn(3, 128, device=dev)
 part = torch.zeros(lib.ganet_mlp_stats_floats(128), device=dev)
-for M in (32768, 65536, 131072, 262144, 524288):
+import os
+MS = [int(os.environ['GA_M'])] if os.environ.get('GA_M') else (32768, 65536, 131072, 262144, 524288)
+for M in MS:
     z = torch.randn(M, 128, device=dev); g = torch.randn(M, 128, device=dev); out = torch.empty(M, 128, device=dev)
     dW = torch.empty(128, 128, device=dev); db = torch.empty(128, device=dev)
     nb = lib.ganet_wgrad_act_workspace(M, 128, 128); ws = torch.empty(nb, dtype=torch.uint8, device=dev)
