@@ -368,7 +368,81 @@ wgrad_act_kernel(int64_t M, int N, int K, const float* __restrict__ g, int64_t l
     }
   };
 
-  if (r0 < r1) {
+  // Fast path (the hidden layers: 128 x 128, all row strides 128, whole range in bounds): row/column
+  // offsets become instruction immediates (one 64-bit base per operand and group instead of one
+  // address computation per load), no row predicates, and softplus in log2 units — scale/shift are
+  // pre-multiplied by log2(e) and the ln 2 factor is applied once when the tile is written out.
+  bool fast = false;
+  float out_scale = 1.f;
+  if constexpr (NTW == 4 && KTW == 4) {
+    fast = N == 128 && K == 128 && ldg == 128 && ldx == 128 && (!GPRO || ldgz == 128) &&
+           r0 + rows_per_wave <= M && M >= 2 * UNROLL;
+  }
+  if (fast) {
+    constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+    float sc2[KTW], sh2[KTW];
+#pragma unroll
+    for (int i = 0; i < KTW; ++i) { sc2[i] = sc[i] * kLog2e; sh2[i] = sh[i] * kLog2e; }
+    if (ACT) out_scale = kLn2;
+    auto load_fast = [&](Group& q, int64_t m) {
+      const int64_t base = (min(m, M - 2 * UNROLL) + half) * 128 + col;   // prefetch past the end: clamped
+      const float* gp = g + base;
+      const float* xq = x + base;
+      const float* zp = GPRO ? gz + base : nullptr;
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) q.a[u][j] = gp[u * 256 + j * 32];
+        if (GPRO) {
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) q.c[u][j] = zp[u * 256 + j * 32];
+        }
+#pragma unroll
+        for (int i = 0; i < KTW; ++i) q.b[u][i] = xq[u * 256 + i * 32];
+      }
+    };
+    auto compute_fast = [&](const Group& q) {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        float av[NTW], bv[KTW];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+          av[j] = GPRO ? fmaf(cA[j], q.a[u][j], fmaf(cq[j], q.c[u][j], cp[j])) : q.a[u][j];
+          bias[j] += av[j];
+        }
+#pragma unroll
+        for (int i = 0; i < KTW; ++i) {
+          if (ACT) {                       // softplus(u) / ln 2 with u2 = u log2(e)
+            const float u2 = fmaf(sc2[i], q.b[u][i], sh2[i]);
+            const float e = __builtin_amdgcn_exp2f(u2);
+            const float lg = __builtin_amdgcn_logf(1.0f + e);
+            const float ser = e * fmaf(e, -0.5f * kLog2e, kLog2e);
+            const float l = e < 1e-3f ? ser : lg;
+            bv[i] = u2 > 20.0f * kLog2e ? u2 : l;
+          } else {
+            bv[i] = q.b[u][i];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+          for (int i = 0; i < KTW; ++i)
+            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[i], acc[j][i], 0, 0, 0);
+      }
+    };
+    Group qa, qb;
+    load_fast(qa, r0);
+    for (int64_t m = r0; m < r1; m += 4 * UNROLL) {
+      load_fast(qb, m + 2 * UNROLL);
+      __builtin_amdgcn_sched_barrier(0);
+      compute_fast(qa);
+      __builtin_amdgcn_sched_barrier(0);
+      load_fast(qa, m + 4 * UNROLL);
+      __builtin_amdgcn_sched_barrier(0);
+      compute_fast(qb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else if (r0 < r1) {
     Group qa, qb;
     load(qa, r0);
     for (int64_t m = r0; m < r1; m += 4 * UNROLL) {
@@ -400,7 +474,7 @@ wgrad_act_kernel(int64_t M, int N, int K, const float* __restrict__ g, int64_t l
 #pragma unroll
       for (int i = 0; i < KTW; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tile[lds_index(j, i, r)] = acc[j][i][r];
+        for (int r = 0; r < 16; ++r) tile[lds_index(j, i, r)] = acc[j][i][r] * out_scale;
       if (half == 0) tile[NP * KP + j * 32 + col] = bias[j];
     }
   }
@@ -411,7 +485,7 @@ wgrad_act_kernel(int64_t M, int N, int K, const float* __restrict__ g, int64_t l
 #pragma unroll
       for (int i = 0; i < KTW; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tile[lds_index(j, i, r)] += acc[j][i][r];
+        for (int r = 0; r < 16; ++r) tile[lds_index(j, i, r)] += acc[j][i][r] * out_scale;
       if (half == 0) tile[NP * KP + j * 32 + col] += bias[j];
     }
   }
@@ -455,8 +529,9 @@ wgrad_act_reduce_kernel(int nblocks, int N, int K, const float* __restrict__ par
 int plan_wgrad(int64_t M, int64_t* rows_per_wave) {
   const int waves = WG_W / 64;
   int64_t rpw = (M + (int64_t)WGRAD_MAX_BLOCKS * waves - 1) / ((int64_t)WGRAD_MAX_BLOCKS * waves);
-  rpw = ((rpw + 4 * UNROLL - 1) / (4 * UNROLL)) * (4 * UNROLL);
-  if (rpw < 4 * UNROLL) rpw = 4 * UNROLL;
+  constexpr int kGran = 4 * UNROLL;
+  rpw = ((rpw + kGran - 1) / kGran) * kGran;
+  if (rpw < kGran) rpw = kGran;
   *rows_per_wave = rpw;
   return (int)((M + rpw * waves - 1) / (rpw * waves));
 }
