@@ -30,7 +30,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from . import parallel
+from . import fused, parallel
 from .lbs import SMPLBody, skin
 from .network import POP_no_unet, UnetNoCond5DS
 from .renderer import render_batch, render_frames  # noqa: F401
@@ -135,6 +135,9 @@ class AvatarModel:
         valid = assets["valid_idx"].reshape(-1)
         self.valid_idx = valid.to(dev)
         self.valid_index = torch.nonzero(valid, as_tuple=False).reshape(-1).to(dev)      # int64 [N]
+        inv = torch.full((valid.numel(),), -1, dtype=torch.int64)
+        inv[self.valid_index.cpu()] = torch.arange(self.valid_index.numel())
+        self.inv_index = inv.to(dev)                                                     # int64 [HW]
         self.uv_coord_map = assets["uv_coord_map"].to(dev)                               # [HW,2], no grad
         query_map = assets["query_posmap"].reshape(-1, 3)
         self.query_points = query_map[valid].to(dev).contiguous()[None].expand(self.batch_size, -1, -1)
@@ -292,26 +295,37 @@ class AvatarModel:
 
     def _decode(self, B, pose_featmap, iteration, warmup: bool):
         """Net -> per-Gaussian residuals/scales/colours on the valid texels.
-        Returns (pred_res_all [b,HW,3] (x0.02), point_res [B,N,3], scales [B,N,3], colours [B,N,3])."""
+        Returns (offset_loss = mean((0.02 pred_res)^2) over all texels, point_res [B,N,3], scales [B,N,3],
+        colours [B,N,3])."""
         S_in = self.model_parms.inp_posmap_size
         geom = self.geo_feature.expand(B, -1, S_in, S_in)                 # broadcast view: dedup in stage 1
         uv = self.uv_coord_map[None].expand(B, -1, -1)
-        res, scales, shs = self.net.forward_points(pose_featmap, geom, uv)
-        shared = res.shape[0] > 1 and res.stride(0) == 0
-        if shared:
-            res, scales, shs = res[:1], scales[:1], shs[:1]
-        res = res * 0.02
-        if warmup and iteration < 1000:
-            scales = scales * 1e-3 * iteration
-        # gather the valid texels on the single copy; one concatenated [b,N,7] tensor is the DP
-        # exchange point (parallel.exchange_output_grads is the identity on one rank)
-        packed = torch.cat([res, scales, shs], dim=2).index_select(1, self.valid_index)
+        scale_mult = 1e-3 * iteration if (warmup and iteration < 1000) else 1.0
+        if geom.is_cuda:
+            # decoder heads (logits) -> packed [b,N,7] + offset-regulariser sum in one kernel
+            res, s_logit, c_logit = self.net.forward_points(pose_featmap, geom, uv, raw_heads=True)
+            shared = res.shape[0] > 1 and res.stride(0) == 0
+            if shared:
+                res, s_logit, c_logit = res[:1], s_logit[:1], c_logit[:1]
+            packed, sq_sum = fused.decode_pack(res, s_logit, c_logit, self.valid_index, self.inv_index, 0.02, scale_mult)
+            offset_loss = sq_sum / float(res.shape[0] * res.shape[1] * 3)
+        else:
+            res, scales, shs = self.net.forward_points(pose_featmap, geom, uv)
+            shared = res.shape[0] > 1 and res.stride(0) == 0
+            if shared:
+                res, scales, shs = res[:1], scales[:1], shs[:1]
+            res = res * 0.02
+            scales = scales * scale_mult if scale_mult != 1.0 else scales
+            offset_loss = torch.mean(res ** 2)
+            # gather the valid texels on the single copy; one concatenated [b,N,7] tensor is the DP
+            # exchange point (parallel.exchange_output_grads is the identity on one rank)
+            packed = torch.cat([res, scales, shs], dim=2).index_select(1, self.valid_index)
         if shared or self.model_parms.train_stage == 1:
             packed = parallel.exchange_output_grads(packed)
         if shared:
             packed = packed.expand(B, -1, -1)
         point_res, pscale, pshs = packed[..., 0:3], packed[..., 3:4], packed[..., 4:7]
-        return res, point_res, pscale.expand(-1, -1, 3), pshs
+        return offset_loss, point_res, pscale.expand(-1, -1, 3), pshs
 
     def _render_frames(self, batch_data, full_pred, colors, scales):
         """The reference renders the frames one by one (avatar_model.py:332-365); here the whole
@@ -328,17 +342,16 @@ class AvatarModel:
     def _forward(self, batch_data, iteration, pose, transl, pose_featmap, warmup):
         B = pose.shape[0]
         live = self._body(pose, transl, batch_data.get("rest_pose"))
-        res_all, point_res, scales, colors = self._decode(B, pose_featmap, iteration, warmup)
+        offset_loss, point_res, scales, colors = self._decode(B, pose_featmap, iteration, warmup)
         full_pred = skin(self.query_points[:B] if self.query_points.shape[0] >= B else self.query_points[:1].expand(B, -1, -1),
                          point_res, self.query_lbs[0], live.cano2live)
         image = self._render_frames(batch_data, full_pred, colors, scales)
-        return image, full_pred, res_all, scales
+        return image, full_pred, offset_loss, scales
 
     def train_stage1(self, batch_data, iteration):
         idx = batch_data["pose_idx"]
-        image, full_pred, res_all, scales = self._forward(
+        image, full_pred, offset_loss, scales = self._forward(
             batch_data, iteration, self.pose(idx), self.transl(idx), None, warmup=True)
-        offset_loss = torch.mean(res_all ** 2)
         geo_loss = torch.mean(self.geo_feature ** 2)
         scale_loss = torch.mean(scales)
         return image, full_pred, offset_loss, geo_loss, scale_loss
@@ -346,9 +359,8 @@ class AvatarModel:
     def train_stage2(self, batch_data, iteration):
         idx = batch_data["pose_idx"]
         pose_featmap = self.pose_encoder(batch_data["inp_pos_map"])
-        image, full_pred, res_all, scales = self._forward(
+        image, full_pred, offset_loss, scales = self._forward(
             batch_data, iteration, self.pose(idx), self.transl(idx), pose_featmap, warmup=False)
-        offset_loss = torch.mean(res_all ** 2)
         pose_loss = torch.mean(pose_featmap ** 2)
         return image, full_pred, pose_loss, offset_loss,
 

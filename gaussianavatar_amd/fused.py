@@ -196,6 +196,45 @@ def ssim_mean(img1, img2):
     return _SsimFn.apply(img1, img2)
 
 
+class _DecodePackFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, res, s_logit, c_logit, valid_index, inv_index, res_scale, scale_mult):
+        lib = _native.ganet()
+        b, HW = res.shape[0], res.shape[1]
+        N = valid_index.shape[0]
+        res, s_logit, c_logit = res.contiguous(), s_logit.contiguous(), c_logit.contiguous()
+        packed = torch.empty((b, N, 7), dtype=torch.float32, device=res.device)
+        sq = torch.empty(1, dtype=torch.float32, device=res.device)
+        _native.ganet_check(lib.ganet_decode_pack_fwd(b, HW, N, _ptr(res), _ptr(s_logit), _ptr(c_logit),
+                                                      _ptr(valid_index), float(res_scale), float(scale_mult),
+                                                      _ptr(packed), _ptr(sq), _stream(res.device)))
+        ctx.save_for_backward(res, s_logit, c_logit, inv_index)
+        ctx.consts = (float(res_scale), float(scale_mult), N)
+        return packed, sq[0]
+
+    @staticmethod
+    def backward(ctx, d_packed, d_sq):
+        lib = _native.ganet()
+        res, s_logit, c_logit, inv_index = ctx.saved_tensors
+        res_scale, scale_mult, N = ctx.consts
+        b, HW = res.shape[0], res.shape[1]
+        d_res, d_s, d_c = torch.empty_like(res), torch.empty_like(s_logit), torch.empty_like(c_logit)
+        if d_packed is None:
+            d_packed = torch.zeros((b, N, 7), dtype=torch.float32, device=res.device)
+        d_sqv = None if d_sq is None else d_sq.reshape(1).float().contiguous()
+        _native.ganet_check(lib.ganet_decode_pack_bwd(b, HW, N, _ptr(res), _ptr(s_logit), _ptr(c_logit), _ptr(inv_index),
+                                                      res_scale, scale_mult, _ptr(d_packed.contiguous()), _ptr(d_sqv),
+                                                      _ptr(d_res), _ptr(d_s), _ptr(d_c), _stream(res.device)))
+        return d_res, d_s, d_c, None, None, None, None
+
+
+def decode_pack(res, s_logit, c_logit, valid_index, inv_index, res_scale, scale_mult):
+    """Decoder-head logits ([b,HW,3], [b,HW,1], [b,HW,3]) -> (packed [b,N,7] = residual*res_scale,
+    sigmoid(scale)*scale_mult, sigmoid(colour) on the valid texels; sum over all texels of
+    (res_scale*residual)^2)."""
+    return _DecodePackFn.apply(res, s_logit, c_logit, valid_index, inv_index, res_scale, scale_mult)
+
+
 # ------------------------------------------------------------------------------------------------
 # Whole-decoder autograd function on the fused layer kernels (ganet_mlp.hip): no normalised
 # activation is ever stored, BatchNorm statistics come out of the producing GEMM's epilogue.

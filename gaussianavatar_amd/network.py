@@ -91,13 +91,15 @@ class ShapeDecoder(nn.Module):
         c = getattr(self, conv)
         return fused.linear(x, c.weight.squeeze(-1), c.bias)
 
-    def forward_points(self, x):
-        """x [M, in_size] -> (residual [M,3], scale [M,1], colour [M,3])."""
+    def forward_points(self, x, raw_heads: bool = False):
+        """x [M, in_size] -> (residual [M,3], scale [M,1], colour [M,3]); with raw_heads the scale and
+        colour heads are returned as logits (the caller applies the sigmoids, fused.decode_pack)."""
+        act = (lambda t: t) if raw_heads else torch.sigmoid
         if fused.decoder_supported(self, x):
             # whole decoder on the fused MFMA layer kernels (activation-on-load, statistics in the
             # epilogue); the per-layer formulation below is the CPU / unsupported-shape path
             r, s, c = fused.decoder_mlp(self, x)
-            return r, torch.sigmoid(s), torch.sigmoid(c)
+            return r, act(s), act(c)
         x1 = self._layer(x, "conv1", "bn1")
         x2 = self._layer(x1, "conv2", "bn2")
         x3 = self._layer(x2, "conv3", "bn3")
@@ -108,7 +110,7 @@ class ShapeDecoder(nn.Module):
             h6 = self._layer(x5, f"conv6{tag}", f"bn6{tag}")
             h7 = self._layer(h6, f"conv7{tag}", f"bn7{tag}")
             outs.append(self._out(h7, f"conv8{tag}"))
-        return outs[0], torch.sigmoid(outs[1]), torch.sigmoid(outs[2])
+        return outs[0], act(outs[1]), act(outs[2])
 
     def forward(self, x):
         """Reference layout: x [B, C, L] -> ([B,3,L], [B,1,L], [B,3,L])."""
@@ -240,8 +242,8 @@ class POP_no_unet(nn.Module):
         self._bilinear_cache = (key, result)
         return result
 
-    def forward_points(self, pose_featmap, geom_featmap, uv_loc, dedup: bool = True):
-        """-> (residuals [B,HW,3], scales [B,HW,1], colours [B,HW,3]).
+    def forward_points(self, pose_featmap, geom_featmap, uv_loc, dedup: bool = True, raw_heads: bool = False):
+        """-> (residuals [B,HW,3], scales [B,HW,1], colours [B,HW,3]); raw_heads: scale/colour logits.
 
         If `dedup` and the inputs are batch-invariant (stage 1: pose_featmap None, geom_featmap
         and uv_loc expanded views of single maps) the net runs once and the result is expanded."""
@@ -284,7 +286,7 @@ class POP_no_unet(nn.Module):
                 self._zero_pad = (zkey, pts.new_zeros(b, HW, pad))
             parts.append(self._zero_pad[1])
         x = torch.cat(parts, dim=2)                                           # [b, HW, C+2 (+pad)]
-        r, s, c = self.decoder.forward_points(x.reshape(b * HW, x.shape[2]))
+        r, s, c = self.decoder.forward_points(x.reshape(b * HW, x.shape[2]), raw_heads=raw_heads)
         r, s, c = (t.reshape(b, HW, -1) for t in (r, s, c))
         if shared:
             r, s, c = (t.expand(B, -1, -1) for t in (r, s, c))

@@ -128,6 +128,25 @@ int ganet_mlp_bwd_stats(int64_t M, int32_t nparts, const float* col_part, const 
                         const float* rstd, const float* scale, float* coef, float* dgamma,
                         float* dbeta, void* stream);
 
+/* ---- decoder heads -> packed per-Gaussian records (ganet_pack.hip) --------------------------------
+ * One kernel for pred_res * res_scale, the two sigmoid heads (x scale_mult for the scale warm-up), the
+ * gather of the N valid texels (valid_index [N], int64, texel index in [0,HW)) and the sum over ALL
+ * texels of (res_scale * res)^2 (offset regulariser numerator, accumulated into res_sq_sum[0], which
+ * the call zeroes first). res [frames*HW,3], scale_logit [frames*HW,1], colour_logit [frames*HW,3];
+ * packed [frames,N,7] = (residual 3, scale 1, colour 3). Replaces the element-wise chain of
+ * /root/reference/model/avatar_model.py:298-324 + the sigmoids of model/network.py:79-81.
+ * Backward: inv_index [HW] (int64; n for a valid texel, -1 otherwise), d_sq_sum device scalar
+ * (may be NULL); every element of the three gradient tensors is written. */
+int ganet_decode_pack_fwd(int32_t frames, int64_t HW, int64_t N, const float* res,
+                          const float* scale_logit, const float* colour_logit,
+                          const int64_t* valid_index, float res_scale, float scale_mult, float* packed,
+                          float* res_sq_sum, void* stream);
+int ganet_decode_pack_bwd(int32_t frames, int64_t HW, int64_t N, const float* res,
+                          const float* scale_logit, const float* colour_logit,
+                          const int64_t* inv_index, float res_scale, float scale_mult,
+                          const float* d_packed, const float* d_sq_sum, float* d_res,
+                          float* d_scale_logit, float* d_colour_logit, void* stream);
+
 /* Optional per-kernel timing (bench/profiling only; off by default, the one piece of process-global
  * state in the library): every instrumented launch is bracketed by hipEvents recorded on the launch
  * stream; ganet_profile_read waits for them and returns, per kernel id < ganet_profile_count(), the

@@ -371,3 +371,28 @@ def test_mlp_head_bwd_and_stats_match_torch_batchnorm_backward(M, N8):
     assert float((dz - z.grad).abs().max()) <= tol
     assert float((dg - gamma.grad).abs().max()) <= 1e-3 * float(gamma.grad.abs().max()) + 1e-4
     assert float((db - beta.grad).abs().max()) <= 1e-3 * float(beta.grad.abs().max()) + 1e-4
+
+
+@pytest.mark.parametrize("b,HW,N", [(1, 512 * 512, 200000), (2, 4096, 3000), (1, 100, 0)])
+def test_decode_pack_matches_torch_chain(b, HW, N):
+    """ganet_decode_pack_fwd/bwd against the reference's element-wise chain: x0.02, sigmoid heads, scale
+    warm-up, gather of the valid texels, sum of squared residuals."""
+    from gaussianavatar_amd import fused
+    torch.manual_seed(HW % 11)
+    dev = "cuda"
+    valid = torch.randperm(HW, device=dev)[:N].sort().values
+    inv = torch.full((HW,), -1, dtype=torch.int64, device=dev)
+    inv[valid] = torch.arange(N, device=dev)
+    mk = lambda c: (torch.randn(b, HW, c, device=dev) * 2).requires_grad_(True)
+    r1, s1, c1 = mk(3), mk(1), mk(3)
+    r2, s2, c2 = (t.detach().clone().requires_grad_(True) for t in (r1, s1, c1))
+    packed, sq = fused.decode_pack(r1, s1, c1, valid, inv, 0.02, 0.007)
+    ref = torch.cat([r2 * 0.02, torch.sigmoid(s2) * 0.007, torch.sigmoid(c2)], 2).index_select(1, valid)
+    ref_sq = ((r2 * 0.02) ** 2).sum()
+    torch.testing.assert_close(packed, ref, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(sq, ref_sq, rtol=1e-4, atol=1e-6)
+    w = torch.randn_like(ref)
+    ((packed * w).sum() + 3.0 * sq).backward()
+    ((ref * w).sum() + 3.0 * ref_sq).backward()
+    for a, bb in ((r1, r2), (s1, s2), (c1, c2)):
+        torch.testing.assert_close(a.grad, bb.grad, rtol=1e-4, atol=1e-7)
