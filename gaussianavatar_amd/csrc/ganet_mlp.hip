@@ -79,12 +79,16 @@ mlp_fwd_kernel(int64_t M, int N, const float* __restrict__ x1, int64_t ld1,
     for (int j = 0; j < PER; ++j) {
       const int i = threadIdx.x + j * WG;
       const int n = i / (K / 4), k4 = i - n * (K / 4);
-      if (i < NP * (K / 4)) s_w[n * LDW4 + k4] = n < N ? wv[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      // columns of the activated operand carry the ln 2 of the log2-unit softplus (ganet_mlp_common.h)
+      const float f = (n < N) ? ((k4 >= 2 * K1B) ? kLn2 : 1.0f) : 0.0f;
+      if (i < NP * (K / 4)) s_w[n * LDW4 + k4] = make_float4(wv[j].x * f, wv[j].y * f, wv[j].z * f, wv[j].w * f);
     }
   }
-  for (int i = threadIdx.x; i < 2 * K2B; i += WG) {
-    s_sc[i] = *reinterpret_cast<const float4*>(in_scale + 4 * i);
-    s_sh[i] = *reinterpret_cast<const float4*>(in_shift + 4 * i);
+  for (int i = threadIdx.x; i < 2 * K2B; i += WG) {     // folded BatchNorm, pre-multiplied by log2(e)
+    const float4 a = *reinterpret_cast<const float4*>(in_scale + 4 * i);
+    const float4 c = *reinterpret_cast<const float4*>(in_shift + 4 * i);
+    s_sc[i] = make_float4(a.x * kLog2e, a.y * kLog2e, a.z * kLog2e, a.w * kLog2e);
+    s_sh[i] = make_float4(c.x * kLog2e, c.y * kLog2e, c.z * kLog2e, c.w * kLog2e);
   }
   __syncthreads();
 
@@ -139,10 +143,10 @@ mlp_fwd_kernel(int64_t M, int N, const float* __restrict__ x1, int64_t ld1,
       if (b >= K1B) {
         const float4 sc = s_sc[soff + 2 * (b - K1B)];
         const float4 sh = s_sh[soff + 2 * (b - K1B)];
-        av0 = softplus_f(fmaf(sc.x, av0, sh.x));
-        av1 = softplus_f(fmaf(sc.y, av1, sh.y));
-        av2 = softplus_f(fmaf(sc.z, av2, sh.z));
-        av3 = softplus_f(fmaf(sc.w, av3, sh.w));
+        av0 = softplus_log2(fmaf(sc.x, av0, sh.x));
+        av1 = softplus_log2(fmaf(sc.y, av1, sh.y));
+        av2 = softplus_log2(fmaf(sc.z, av2, sh.z));
+        av3 = softplus_log2(fmaf(sc.w, av3, sh.w));
         // the raw values are dead now: refill the slot (activated blocks). The two scheduling
         // barriers let VALU / LDS / scalar work flow across but pin the load between this block's
         // and the previous block's MFMAs — left alone, the scheduler sinks the refills to just
@@ -379,7 +383,6 @@ wgrad_act_kernel(int64_t M, int N, int K, const float* __restrict__ g, int64_t l
            r0 + rows_per_wave <= M && M >= 2 * UNROLL;
   }
   if (fast) {
-    constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
     float sc2[KTW], sh2[KTW];
 #pragma unroll
     for (int i = 0; i < KTW; ++i) { sc2[i] = sc[i] * kLog2e; sh2[i] = sh[i] * kLog2e; }
@@ -413,12 +416,7 @@ wgrad_act_kernel(int64_t M, int N, int K, const float* __restrict__ g, int64_t l
 #pragma unroll
         for (int i = 0; i < KTW; ++i) {
           if (ACT) {                       // softplus(u) / ln 2 with u2 = u log2(e)
-            const float u2 = fmaf(sc2[i], q.b[u][i], sh2[i]);
-            const float e = __builtin_amdgcn_exp2f(u2);
-            const float lg = __builtin_amdgcn_logf(1.0f + e);
-            const float ser = e * fmaf(e, -0.5f * kLog2e, kLog2e);
-            const float l = e < 1e-3f ? ser : lg;
-            bv[i] = u2 > 20.0f * kLog2e ? u2 : l;
+            bv[i] = softplus_log2(fmaf(sc2[i], q.b[u][i], sh2[i]));
           } else {
             bv[i] = q.b[u][i];
           }

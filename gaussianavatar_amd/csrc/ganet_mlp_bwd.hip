@@ -85,8 +85,8 @@ mlp_bwd_kernel(int64_t M, int O, const float* __restrict__ g, int64_t ldg,
   for (int t = 0; t < NT; ++t) {
     csum[t] = 0.f; csz[t] = 0.f;
     const int o = min(t * 32 + col, O - 1);
-    ssc[t] = SIG ? src_scale[o] : 0.f;
-    ssh[t] = SIG ? src_shift[o] : 0.f;
+    ssc[t] = SIG ? src_scale[o] * kLog2e : 0.f;          // log2 units (ganet_mlp_common.h)
+    ssh[t] = SIG ? src_shift[o] * kLog2e : 0.f;
   }
 
   const int64_t nslab = (M + SLAB - 1) / SLAB;
@@ -188,7 +188,7 @@ mlp_bwd_kernel(int64_t M, int O, const float* __restrict__ g, int64_t ldg,
         if (ACCUM) v += ex[r];
         if (SIG) {
           const float zv = PRELOAD ? sz[PRELOAD ? t : 0][r] : szt[r];
-          v *= softplus_grad_f(fmaf(ssc[t], zv, ssh[t]));
+          v *= sigmoid_log2(fmaf(ssc[t], zv, ssh[t]));
           if (ok) { csum[t] += v; csz[t] = fmaf(v, zv, csz[t]); }
         }
         if (ok) out[row * ldo + o] = v;
@@ -228,8 +228,10 @@ head_bwd_kernel(int64_t M, int N8, const float* __restrict__ g, const float* __r
 #pragma unroll
   for (int n = 0; n < 4; ++n)
     w[n] = n < N8 ? *reinterpret_cast<const float4*>(W8 + (size_t)n * 128 + 4 * cg) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4 sc = *reinterpret_cast<const float4*>(scale + 4 * cg);
-  const float4 sh = *reinterpret_cast<const float4*>(shift + 4 * cg);
+  float4 sc = *reinterpret_cast<const float4*>(scale + 4 * cg);
+  float4 sh = *reinterpret_cast<const float4*>(shift + 4 * cg);
+  sc.x *= kLog2e; sc.y *= kLog2e; sc.z *= kLog2e; sc.w *= kLog2e;
+  sh.x *= kLog2e; sh.y *= kLog2e; sh.z *= kLog2e; sh.w *= kLog2e;
   float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sgz = sg;
   for (int64_t row = (int64_t)blockIdx.x * 8 + rsub; row < M; row += (int64_t)gridDim.x * 8) {
     float gv[4];
@@ -241,10 +243,10 @@ head_bwd_kernel(int64_t M, int N8, const float* __restrict__ g, const float* __r
     d.y = gv[0] * w[0].y + gv[1] * w[1].y + gv[2] * w[2].y + gv[3] * w[3].y;
     d.z = gv[0] * w[0].z + gv[1] * w[1].z + gv[2] * w[2].z + gv[3] * w[3].z;
     d.w = gv[0] * w[0].w + gv[1] * w[1].w + gv[2] * w[2].w + gv[3] * w[3].w;
-    d.x *= softplus_grad_f(fmaf(sc.x, zv.x, sh.x));
-    d.y *= softplus_grad_f(fmaf(sc.y, zv.y, sh.y));
-    d.z *= softplus_grad_f(fmaf(sc.z, zv.z, sh.z));
-    d.w *= softplus_grad_f(fmaf(sc.w, zv.w, sh.w));
+    d.x *= sigmoid_log2(fmaf(sc.x, zv.x, sh.x));
+    d.y *= sigmoid_log2(fmaf(sc.y, zv.y, sh.y));
+    d.z *= sigmoid_log2(fmaf(sc.z, zv.z, sh.z));
+    d.w *= sigmoid_log2(fmaf(sc.w, zv.w, sh.w));
     *reinterpret_cast<float4*>(G + row * ldG + 4 * cg) = d;
     sg.x += d.x; sg.y += d.y; sg.z += d.z; sg.w += d.w;
     sgz.x = fmaf(d.x, zv.x, sgz.x); sgz.y = fmaf(d.y, zv.y, sgz.y);

@@ -11,23 +11,29 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // llvm.amdgcn.sched.barrier mask: VALU | SALU | DS | transcendental may cross; MFMA and VMEM may not
 constexpr int kSchedMask = 0x2 | 0x4 | 0x80 | 0x100 | 0x200 | 0x400;
 
-// softplus(u) = log1p(exp(u)) (torch.nn.Softplus: beta 1, threshold 20); the series keeps full
-// relative precision where exp(u) vanishes against the 1 in 1 + e. Straight-line code on the
-// hardware exp2/log2 (no branches: this runs between MFMAs).
-__device__ __forceinline__ float softplus_f(float u) {
-  const float e = __builtin_amdgcn_exp2f(u * 1.4426950408889634f);
-  const float lg = __builtin_amdgcn_logf(1.0f + e) * 0.6931471805599453f;
-  const float ser = e * (1.0f - 0.5f * e);
-  const float sp = e < 1e-3f ? ser : lg;
-  return u > 20.0f ? u : sp;
+// fp32-input MFMA runs at the vector-ALU rate on gfx950 and does NOT overlap with other VALU work of
+// the SIMD (measured: tools/ubench/mfma_lds — 4 softplus per 16 MFMAs cost 20 % of the MFMA rate), so
+// the activation math next to the MFMAs is written for minimum instruction count:
+//   softplus(u) = max(u, 0) + log1p(exp(-|u|))     (no threshold / small-argument branches needed:
+//   t = exp(-|u|) is in (0, 1], so 1 + t never overflows and the absolute error is <= 1 ulp of 1)
+// in log2 units: kLog2e is folded into the argument by the caller where it can be, the final ln 2 too.
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+// log2-unit softplus: returns softplus(u) / ln 2 for u2 = u * log2(e).   5 instructions (2 transcendental)
+__device__ __forceinline__ float softplus_log2(float u2) {
+  const float t = __builtin_amdgcn_exp2f(-__builtin_fabsf(u2));
+  return __builtin_fmaxf(u2, 0.0f) + __builtin_amdgcn_logf(1.0f + t);
 }
 
-// d softplus(u) / du = sigmoid(u) (1 where torch's threshold makes softplus the identity)
-__device__ __forceinline__ float softplus_grad_f(float u) {
-  const float e = __builtin_amdgcn_exp2f(-u * 1.4426950408889634f);
-  const float s = __builtin_amdgcn_rcpf(1.0f + e);
-  return u > 20.0f ? 1.0f : s;
+// softplus(u) (torch.nn.Softplus: beta 1; its threshold 20 is reproduced exactly by rounding)
+__device__ __forceinline__ float softplus_f(float u) { return kLn2 * softplus_log2(u * kLog2e); }
+
+// d softplus(u) / du = sigmoid(u) for u2 = u * log2(e)                      3 instructions
+__device__ __forceinline__ float sigmoid_log2(float u2) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-u2));
 }
+__device__ __forceinline__ float softplus_grad_f(float u) { return sigmoid_log2(u * kLog2e); }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

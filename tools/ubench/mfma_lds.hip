@@ -23,6 +23,17 @@ __global__ void __launch_bounds__(512) k(float* out, int slabs, float a0) {
       for (int t = 0; t < 4; ++t) bw[t] = s_w[woff + t * 32 * LDW4 + 2 * b];
       float av0 = a, av1 = a, av2 = a, av3 = a;
       if (MODE == 2) { av0 = fmaf(a, 1.01f, b); av1 = fmaf(a, 1.02f, b); av2 = fmaf(a, 1.03f, b); av3 = fmaf(a, 1.04f, b); }
+      if (MODE == 3) {
+        auto sp = [](float u) {
+          const float e = __builtin_amdgcn_exp2f(u * 1.4426950408889634f);
+          const float lg = __builtin_amdgcn_logf(1.0f + e) * 0.6931471805599453f;
+          const float ser = e * (1.0f - 0.5f * e);
+          const float r = e < 1e-3f ? ser : lg;
+          return u > 20.0f ? u : r;
+        };
+        const float x0 = a + 0.01f * (b + sl);
+        av0 = sp(fmaf(x0, 1.01f, 0.1f)); av1 = sp(fmaf(x0, 1.02f, 0.2f)); av2 = sp(fmaf(x0, 1.03f, 0.3f)); av3 = sp(fmaf(x0, 1.04f, 0.4f));
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bw[t].x, acc[t], 0, 0, 0);
 #pragma unroll
@@ -53,6 +64,7 @@ void run(int blocks, const char* name, int slabs = 64) {
   hipFree(out);
 }
 int main() {
-  for (int sl : {1, 2, 4, 8, 16, 64}) run<0>(256, "LDS-fed B, 2 waves/SIMD", sl);
+  for (int sl : {4, 64}) run<0>(256, "LDS-fed B, 2 waves/SIMD", sl);
+  for (int sl : {4, 64}) run<3>(256, "LDS-fed B + softplus A", sl);
   return 0;
 }
