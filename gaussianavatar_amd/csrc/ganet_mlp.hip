@@ -498,27 +498,35 @@ wgrad_act_kernel(int64_t M, int N, int K, const float* __restrict__ g, int64_t l
   for (int n = threadIdx.x; n < N; n += WG_W) out[(size_t)N * K + n] = t0[NP * KP + n] + t1[NP * KP + n];
 }
 
-// 64 outputs per block, 4 partial walkers per output, combined through LDS (deterministic)
-__global__ void __launch_bounds__(256)
+// Sum of the per-workgroup partial tiles (deterministic order). 64 outputs per block, 16 walkers per
+// output: every walker issues its (up to 16) loads back to back, the walkers combine through LDS.
+constexpr int RED_WALKERS = 16;
+__global__ void __launch_bounds__(64 * RED_WALKERS)
 wgrad_act_reduce_kernel(int nblocks, int N, int K, const float* __restrict__ partial,
                         float* __restrict__ dW, float* __restrict__ db) {
-  __shared__ float s_part[4][64];
+  __shared__ float s_part[RED_WALKERS][64];
   const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + lane;
   const int total = N * K + N;
-  float s0 = 0.f, s1 = 0.f;
+  float acc = 0.f;
   if (e < total) {
-    int b = part;
-    for (; b + 4 < nblocks; b += 8) {
-      s0 += partial[(size_t)b * total + e];
-      s1 += partial[(size_t)(b + 4) * total + e];
+    for (int b0 = part; b0 < nblocks; b0 += RED_WALKERS * 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int b = b0 + u * RED_WALKERS;
+        v[u] = b < nblocks ? partial[(size_t)b * total + e] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc += v[u];
     }
-    if (b < nblocks) s0 += partial[(size_t)b * total + e];
   }
-  s_part[part][lane] = s0 + s1;
+  s_part[part][lane] = acc;
   __syncthreads();
   if (part == 0 && e < total) {
-    const float s = (s_part[0][lane] + s_part[1][lane]) + (s_part[2][lane] + s_part[3][lane]);
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < RED_WALKERS; ++w) s += s_part[w][lane];
     if (e < N * K) dW[e] = s;
     else if (db) db[e - N * K] = s;
   }
@@ -675,7 +683,7 @@ int ganet_wgrad_act(int64_t M, int32_t N, int32_t K, const float* g, int64_t ldg
   const int total = N * K + N;
   {
     ProfScope prof_(K_WGRAD_REDUCE, stream);
-    hipLaunchKernelGGL(wgrad_act_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, stream, nb, N, K,
+    hipLaunchKernelGGL(wgrad_act_reduce_kernel, dim3((total + 63) / 64), dim3(64 * RED_WALKERS), 0, stream, nb, N, K,
                        partial, dW, db);
   }
   return check_hip(hipGetLastError(), "wgrad_act_reduce_kernel");

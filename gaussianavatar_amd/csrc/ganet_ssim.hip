@@ -1,13 +1,16 @@
-// ganet_ssim.hip — SSIM (11x11 Gaussian window, sigma 1.5, zero padding) forward and backward
-// as separable, LDS-tiled passes.
+// ganet_ssim.hip — SSIM (11x11 Gaussian window, sigma 1.5, zero padding) forward and backward as
+// separable streaming passes.
 //
 // Reference: /root/reference/utils/loss_utils.py:23-53 — five grouped 11x11 convolutions
 // (mu1, mu2, E[x1^2], E[x2^2], E[x1 x2]) plus ~15 element-wise kernels over [B,3,H,W], and
-// their autograd counterparts. Here one workgroup owns a 32x16 output tile of one image plane:
-// it stages the (32+10)x(16+10) input patch in LDS, runs the horizontal then the vertical 11-tap
-// pass for all five moments, evaluates the SSIM map and — because the loss is always
-// differentiated — the three partial derivatives dS/dmu1, dS/dE[x1^2], dS/dE[x1 x2] in the same
-// pass. The backward pass convolves those three maps with the (symmetric) window and combines
+// their autograd counterparts. Here a WAVE owns a vertical strip of 64 columns x STRIP rows of one
+// image plane and streams down its rows (no workgroup barriers): a row (+5 columns of halo each side)
+// goes through a per-wave LDS line, every lane takes the 11 horizontal taps of its column, and the
+// vertical pass is a ring of 11 partially accumulated output rows held in registers (each new input
+// row is scattered into the 11 output rows it contributes to; the oldest one is then complete).
+// Forward evaluates the SSIM map and — because the loss is always differentiated — the three partial
+// derivatives dS/dmu1, dS/dE[x1^2], dS/dE[x1 x2] in the same pass; backward convolves those three maps
+// with the (symmetric) window and combines
 //     dL/dx1 = scale * ( conv(dS/dmu1) + 2 x1 conv(dS/dE11) + x2 conv(dS/dE12) ).
 #include <cmath>
 
@@ -18,8 +21,13 @@ namespace ganet {
 
 namespace {
 
-constexpr int TX = 32, TY = 16, R = 5, WIN = 11;
-constexpr int PX = TX + 2 * R, PY = TY + 2 * R;   // staged patch 42 x 26
+constexpr int R = 5, WIN = 11;
+#ifndef GANET_SSIM_STRIP
+#define GANET_SSIM_STRIP 34
+#endif
+constexpr int STRIP = GANET_SSIM_STRIP;   // output rows per wave (STRIP + 10 input rows = whole rounds of 11)
+constexpr int WAVES = 4;                  // strips stacked in a workgroup
+constexpr int LINE = 64 + 2 * R + 6;      // LDS line per input map (padded to 80 floats)
 constexpr float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
 
 struct Window { float w[WIN]; };
@@ -32,119 +40,144 @@ Window make_window() {
   return k;
 }
 
-template <int NQ>
-__device__ __forceinline__ void load_patch(const float* const* src, float (*patch)[PY][PX + 1], int H,
-                                           int W, int x0, int y0) {
-  for (int i = threadIdx.x; i < PX * PY; i += TX * TY) {
-    const int py = i / PX, px = i - py * PX;
-    const int gx = x0 + px - R, gy = y0 + py - R;
-    const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
+// Streams the rows ys-5 .. ys+STRIP+4 of NIN input maps through the wave. `horiz(taps, h)` turns the
+// 11 taps of every input map at this lane's column into NQ horizontally filtered values; `emit(y, v)`
+// receives the NQ fully filtered values of output row y (only rows of the strip that exist).
+template <int NIN, int NQ, class Horiz, class Emit>
+__device__ __forceinline__ void stream_strip(const float* const* src, int H, int W, int x0, int ys,
+                                             float* line, const Window& k, Horiz horiz, Emit emit) {
+  const int lane = threadIdx.x & 63;
+  float acc[WIN][NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) patch[q][py][px] = in ? src[q][(size_t)gy * W + gx] : 0.f;
+  for (int j = 0; j < WIN; ++j)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[j][q] = 0.f;
+  const int gx0 = x0 - R + lane;                 // first column this lane stages
+  const int gx1 = x0 + 64 - R + lane;            // lanes 0..9: the right halo
+  const bool c0 = gx0 >= 0 && gx0 < W, c1 = lane < 2 * R && gx1 < W;
+  // the next row's values are fetched into registers while the current row is being filtered
+  float nv0[NIN], nv1[NIN];
+  auto fetch = [&](int y) {
+    const bool rowok = y >= 0 && y < H;
+#pragma unroll
+    for (int q = 0; q < NIN; ++q) {
+      const float* row = src[q] + (size_t)(rowok ? y : 0) * W;
+      nv0[q] = (rowok && c0) ? row[gx0] : 0.f;
+      nv1[q] = (rowok && c1) ? row[gx1] : 0.f;
+    }
+  };
+  fetch(ys - R);
+  for (int base = -R; base < STRIP + R; base += WIN) {
+#pragma unroll
+    for (int j = 0; j < WIN; ++j) {              // row r = base + j sits in ring slot j
+      const int r = base + j;
+      const int y = ys + r;
+      __builtin_amdgcn_wave_barrier();           // previous row's LDS reads are done (in-order LDS)
+#pragma unroll
+      for (int q = 0; q < NIN; ++q) {
+        line[q * LINE + lane] = nv0[q];
+        if (lane < 2 * R) line[q * LINE + 64 + lane] = nv1[q];
+      }
+      __builtin_amdgcn_wave_barrier();
+      fetch(y + 1);
+      float taps[NIN][WIN];
+#pragma unroll
+      for (int q = 0; q < NIN; ++q)
+#pragma unroll
+        for (int t = 0; t < WIN; ++t) taps[q][t] = line[q * LINE + lane + t];
+      float h[NQ];
+      horiz(taps, h);
+      // scatter into the output rows r-5 .. r+5 (ring slots (j + d) mod 11), weight w[5 - d]
+#pragma unroll
+      for (int d = -R; d <= R; ++d) {
+        const int slot = (j + d + WIN) % WIN;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[slot][q] = fmaf(k.w[R - d], h[q], acc[slot][q]);
+      }
+      // output row r-5 is complete
+      const int done = (j + WIN - R) % WIN;
+      const int yo = y - R;
+      if (r - R >= 0 && r - R < STRIP && yo < H) emit(yo, acc[done]);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) acc[done][q] = 0.f;
+    }
   }
 }
 
-__global__ void __launch_bounds__(TX * TY)
+__global__ void __launch_bounds__(64 * WAVES)
 ssim_fwd_kernel(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
                 float* __restrict__ ssim_sum, float* __restrict__ partials, size_t map_stride,
                 Window k) {
-  __shared__ float s_in[2][PY][PX + 1];
-  __shared__ float s_h[5][PY][TX + 1];
-  __shared__ float s_red[TX * TY / 64];
+  __shared__ float s_line[WAVES][2 * LINE];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int plane = blockIdx.z;
-  const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+  const int x0 = blockIdx.x * 64, ys = (blockIdx.y * WAVES + wave) * STRIP;
+  if (ys >= H) return;
   const size_t poff = (size_t)plane * H * W;
   const float* src[2] = {img1 + poff, img2 + poff};
-  load_patch<2>(src, s_in, H, W, x0, y0);
-  __syncthreads();
-  // horizontal pass: PY rows x TX columns, five moments
-  for (int i = threadIdx.x; i < PY * TX; i += TX * TY) {
-    const int py = i / TX, tx = i - py * TX;
-    float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
-#pragma unroll
-    for (int t = 0; t < WIN; ++t) {
-      const float a = s_in[0][py][tx + t], b = s_in[1][py][tx + t], w = k.w[t];
-      m1 = fmaf(w, a, m1); m2 = fmaf(w, b, m2);
-      e11 = fmaf(w, a * a, e11); e22 = fmaf(w, b * b, e22); e12 = fmaf(w, a * b, e12);
-    }
-    s_h[0][py][tx] = m1; s_h[1][py][tx] = m2; s_h[2][py][tx] = e11; s_h[3][py][tx] = e22; s_h[4][py][tx] = e12;
-  }
-  __syncthreads();
-  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-  const int gx = x0 + tx, gy = y0 + ty;
+  const int gx = x0 + lane;
   float S = 0.f;
-  if (gx < W && gy < H) {
+  auto horiz = [&](const float (*taps)[WIN], float* h) {
     float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
 #pragma unroll
     for (int t = 0; t < WIN; ++t) {
-      const float w = k.w[t];
-      m1 = fmaf(w, s_h[0][ty + t][tx], m1); m2 = fmaf(w, s_h[1][ty + t][tx], m2);
-      e11 = fmaf(w, s_h[2][ty + t][tx], e11); e22 = fmaf(w, s_h[3][ty + t][tx], e22);
-      e12 = fmaf(w, s_h[4][ty + t][tx], e12);
+      const float a = taps[0][t], b = taps[1][t];
+      const float wa = k.w[t] * a, wb = k.w[t] * b;
+      m1 += wa; m2 += wb;
+      e11 = fmaf(wa, a, e11); e22 = fmaf(wb, b, e22); e12 = fmaf(wa, b, e12);
     }
+    h[0] = m1; h[1] = m2; h[2] = e11; h[3] = e22; h[4] = e12;
+  };
+  auto emit = [&](int y, const float* v) {
+    if (gx >= W) return;
+    const float m1 = v[0], m2 = v[1], e11 = v[2], e22 = v[3], e12 = v[4];
     const float n1 = 2.f * m1 * m2 + C1;
     const float n2 = 2.f * (e12 - m1 * m2) + C2;
     const float d1 = m1 * m1 + m2 * m2 + C1;
     const float d2 = (e11 - m1 * m1) + (e22 - m2 * m2) + C2;
     const float inv = 1.0f / (d1 * d2);
-    S = n1 * n2 * inv;
-    const size_t o = poff + (size_t)gy * W + gx;
-    partials[o] = 2.f * m2 * (n2 - n1) * inv - 2.f * m1 * S * (1.0f / d1 - 1.0f / d2);   // dS/dmu1
-    partials[map_stride + o] = -S / d2;                                                    // dS/dE[x1^2]
+    const float Sv = n1 * n2 * inv;
+    S += Sv;
+    const size_t o = poff + (size_t)y * W + gx;
+    partials[o] = 2.f * m2 * (n2 - n1) * inv - 2.f * m1 * Sv * (1.0f / d1 - 1.0f / d2);   // dS/dmu1
+    partials[map_stride + o] = -Sv / d2;                                                   // dS/dE[x1^2]
     partials[2 * map_stride + o] = 2.f * n1 * inv;                                         // dS/dE[x1 x2]
-  }
-  // block sum of the SSIM map
+  };
+  stream_strip<2, 5>(src, H, W, x0, ys, s_line[wave], k, horiz, emit);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) S += __shfl_xor(S, off);
-  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = S;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < TX * TY / 64; ++i) t += s_red[i];
-    atomicAdd(ssim_sum, t);
-  }
+  if (lane == 0) atomicAdd(ssim_sum, S);
 }
 
-__global__ void __launch_bounds__(TX * TY)
+__global__ void __launch_bounds__(64 * WAVES)
 ssim_bwd_kernel(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
                 const float* __restrict__ partials, size_t map_stride,
                 const float* __restrict__ scale_dev, float* __restrict__ dimg1, Window k) {
-  __shared__ float s_in[3][PY][PX + 1];
-  __shared__ float s_h[3][PY][TX + 1];
+  __shared__ float s_line[WAVES][3 * LINE];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int plane = blockIdx.z;
-  const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+  const int x0 = blockIdx.x * 64, ys = (blockIdx.y * WAVES + wave) * STRIP;
+  if (ys >= H) return;
   const size_t poff = (size_t)plane * H * W;
   const float* src[3] = {partials + poff, partials + map_stride + poff, partials + 2 * map_stride + poff};
-  load_patch<3>(src, s_in, H, W, x0, y0);
-  __syncthreads();
-  for (int i = threadIdx.x; i < PY * TX; i += TX * TY) {
-    const int py = i / TX, tx = i - py * TX;
+  const int gx = x0 + lane;
+  const float scale = scale_dev[0];
+  auto horiz = [&](const float (*taps)[WIN], float* h) {
     float a = 0.f, b = 0.f, c = 0.f;
 #pragma unroll
     for (int t = 0; t < WIN; ++t) {
-      const float w = k.w[t];
-      a = fmaf(w, s_in[0][py][tx + t], a);
-      b = fmaf(w, s_in[1][py][tx + t], b);
-      c = fmaf(w, s_in[2][py][tx + t], c);
+      a = fmaf(k.w[t], taps[0][t], a);
+      b = fmaf(k.w[t], taps[1][t], b);
+      c = fmaf(k.w[t], taps[2][t], c);
     }
-    s_h[0][py][tx] = a; s_h[1][py][tx] = b; s_h[2][py][tx] = c;
-  }
-  __syncthreads();
-  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-  const int gx = x0 + tx, gy = y0 + ty;
-  if (gx < W && gy < H) {
-    float a = 0.f, b = 0.f, c = 0.f;
-#pragma unroll
-    for (int t = 0; t < WIN; ++t) {
-      const float w = k.w[t];
-      a = fmaf(w, s_h[0][ty + t][tx], a);
-      b = fmaf(w, s_h[1][ty + t][tx], b);
-      c = fmaf(w, s_h[2][ty + t][tx], c);
-    }
-    const size_t o = poff + (size_t)gy * W + gx;
-    dimg1[o] = scale_dev[0] * (a + 2.f * img1[o] * b + img2[o] * c);
-  }
+    h[0] = a; h[1] = b; h[2] = c;
+  };
+  auto emit = [&](int y, const float* v) {
+    if (gx >= W) return;
+    const size_t o = poff + (size_t)y * W + gx;
+    dimg1[o] = scale * (v[0] + 2.f * img1[o] * v[1] + img2[o] * v[2]);
+  };
+  stream_strip<3, 3>(src, H, W, x0, ys, s_line[wave], k, horiz, emit);
 }
 
 }  // namespace
@@ -164,9 +197,9 @@ int ganet_ssim_fwd(int32_t planes, int32_t H, int32_t W, const float* img1, cons
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   int rc = check_hip(hipMemsetAsync(ssim_sum, 0, sizeof(float), stream), "memset ssim_sum");
   if (rc) return rc;
-  const dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, planes);
+  const dim3 grid((W + 63) / 64, (H + STRIP * WAVES - 1) / (STRIP * WAVES), planes);
   ProfScope prof_(K_SSIM_FWD, stream);
-  hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(TX * TY), 0, stream, H, W, img1, img2, ssim_sum,
+  hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(64 * WAVES), 0, stream, H, W, img1, img2, ssim_sum,
                      partials, (size_t)planes * H * W, make_window());
   return check_hip(hipGetLastError(), "ssim_fwd_kernel");
 }
@@ -178,9 +211,9 @@ int ganet_ssim_bwd(int32_t planes, int32_t H, int32_t W, const float* img1, cons
     return 1;
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, planes);
+  const dim3 grid((W + 63) / 64, (H + STRIP * WAVES - 1) / (STRIP * WAVES), planes);
   ProfScope prof_(K_SSIM_BWD, stream);
-  hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(TX * TY), 0, stream, H, W, img1, img2, partials,
+  hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(64 * WAVES), 0, stream, H, W, img1, img2, partials,
                      (size_t)planes * H * W, scale_dev, dimg1, make_window());
   return check_hip(hipGetLastError(), "ssim_bwd_kernel");
 }
