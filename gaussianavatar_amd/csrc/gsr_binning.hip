@@ -15,7 +15,7 @@ namespace {
 
 constexpr int SCAN_THREADS = 1024;
 constexpr int SORT_THREADS = 1024;
-constexpr int SORT_CAP = 4096;        // keys sorted in LDS at once (32 KiB)
+constexpr int SORT_CAP = 8192;        // keys sorted in LDS at once (64 KiB; avatar tiles reach ~4600)
 constexpr int MERGE_ITEMS = 8;        // outputs per thread per merge step
 
 // ------------------------------------------------------------------ K2

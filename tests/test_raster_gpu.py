@@ -91,10 +91,10 @@ def test_depth_ties_broken_by_index(raster_oracle):
 
 
 def test_crowded_tile_uses_merge_path(raster_oracle):
-    """More than 4096 entries in one tile: chunk sort in LDS + merge passes through HBM."""
-    sc = random_scene(9000, 64, 64, seed=11, kind="general", spread=0.02, scale_med=0.004)
+    """More than 8192 entries in one tile: chunk sort in LDS + merge passes through HBM."""
+    sc = random_scene(20000, 64, 64, seed=11, kind="general", spread=0.02, scale_med=0.004)
     ref, got = assert_forward_parity(raster_oracle, sc)
-    assert got["status"][3] > 4096, got["status"]
+    assert got["status"][3] > 8192, got["status"]
 
 
 def test_large_gaussians_cover_all_tiles(raster_oracle):
