@@ -76,7 +76,7 @@ def test_skin_matches_reference_golden():
     np.testing.assert_allclose(out2.cpu().numpy(), g["full_pred"], rtol=0, atol=TOL)
 
 
-@pytest.mark.parametrize("B,N,J", [(2, 1000, 24), (3, 777, 55), (9, 300, 24)])
+@pytest.mark.parametrize("B,N,J", [(2, 1000, 24), (3, 777, 55), (9, 300, 24), (2, 200_000, 24)])   # last: headline size
 def test_skin_backward_vs_oracle(B, N, J):
     from gaussianavatar_amd.lbs import skin
     from oracle import lbs_oracle as O

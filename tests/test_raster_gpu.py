@@ -272,3 +272,47 @@ def test_sh_colour_path(raster_oracle, deg):
         no_dir = rb["dmeans3D"] - raster_oracle.sh_backward(sc["means3D"], shs, deg, sc["campos"],
                                                             ref["sh"]["clamped"], rb["dcolors"])[1]
         assert np.abs(no_dir - rb["dmeans3D"]).max() > 1e-3 * np.abs(rb["dmeans3D"]).max()
+
+
+def test_full_size_parity_and_invariants(raster_oracle):
+    """BASELINE.json's headline size (200k avatar-like Gaussians, 1024 x 1024): direct parity with the
+    oracle (it takes ~1 s per direction), plus size-independent invariants of the splatting algebra."""
+    import torch
+    from gaussianavatar_amd.rasterizer import GaussianRasterizer
+    from tests.hip_helpers import hip_forward_backward, hip_tile_lists, scene_tensors, settings_from_scene
+    P, W, H = 200_000, 1024, 1024
+    sc = random_scene(P, W, H, seed=1, kind="avatar", spread=0.45, scale_med=0.0035)
+    ref, got = assert_forward_parity(raster_oracle, sc)
+    assert ref["D"] > 400_000
+    # sortedness: every tile list ordered by (depth bits, index), keys unique
+    depth_bits = ref["depth"].view(np.uint32).astype(np.uint64)
+    for lst in hip_tile_lists(got)[::7]:
+        if len(lst) > 1:
+            key = (depth_bits[lst] << np.uint64(32)) | lst.astype(np.uint64)
+            assert np.all(key[1:] > key[:-1])
+    # checksum of checksums: pairs per tile add up to the Gaussians' tile counts
+    assert int(got["tile_offset"][-1]) == int(ref["tiles_touched"].astype(np.int64).sum())
+    # backward parity at full size
+    g = np.random.default_rng(5).normal(0, 1, (3, H, W)).astype(np.float32)
+    rb = raster_oracle.backward(ref, g)
+    color, radii, grads = hip_forward_backward(sc, g)
+    for k in ("dmeans3D", "dcolors", "dscales"):
+        err = np.abs(grads[k] - rb[k]).max() / (np.abs(rb[k]).max() + 1e-12)
+        assert err <= GRAD_REL_TOL, (k, err)
+    # partition of unity: constant colour == background  =>  constant image (sum of weights + T = 1)
+    sc1 = dict(sc, colors=np.full((P, 3), 0.37, np.float32), bg=np.full(3, 0.37, np.float32))
+    t = scene_tensors(sc1, requires_grad=True)
+    img, _ = GaussianRasterizer(settings_from_scene(sc1))(
+        means3D=t["means3D"], means2D=None, opacities=t["opacities"], colors_precomp=t["colors"],
+        scales=t["scales"], rotations=t["rotations"])
+    assert float((img - 0.37).abs().max()) <= 2e-6
+    # linear in the colours: d(sum image)/d colour_i summed over Gaussians = sum over pixels of (1 - T)
+    img.sum().backward()
+    lhs = t["colors"].grad.double().sum(0).cpu().numpy()
+    rhs = float((1.0 - ref["final_T"].astype(np.float64)).sum())
+    assert np.all(np.abs(lhs - rhs) <= 1e-4 * rhs), (lhs, rhs)
+    # idempotence: a second forward reproduces the first bit for bit (no atomics in the forward image)
+    img2, _ = GaussianRasterizer(settings_from_scene(sc1))(
+        means3D=t["means3D"].detach(), means2D=None, opacities=t["opacities"].detach(),
+        colors_precomp=t["colors"].detach(), scales=t["scales"].detach(), rotations=t["rotations"].detach())
+    assert torch.equal(img.detach(), img2)
