@@ -65,7 +65,7 @@ _gsr = None
 _galbs = None
 
 GSR_SYMBOLS = ["gsr_workspace_bytes", "gsr_workspace_layout", "gsr_forward", "gsr_backward",
-               "gsr_mark_visible", "gsr_read_status", "gsr_last_error", "gsr_abi_version",
+               "gsr_mark_visible", "gsr_batch_status", "gsr_read_status", "gsr_last_error", "gsr_abi_version",
                "gsr_profile_enable", "gsr_profile_read", "gsr_profile_kernel_name",
                "gsr_forward_batch", "gsr_backward_batch"]
 GALBS_SYMBOLS = ["galbs_joint_saved_floats", "galbs_joint_transforms_fwd",
@@ -97,6 +97,8 @@ def gsr() -> ctypes.CDLL:
                                            P, P, c_size_t, c_int64, P, P, P, P, P, P, P, P, P, P]
         lib.gsr_mark_visible.restype = c_int
         lib.gsr_mark_visible.argtypes = [c_int32, P, P, P, P, P]
+        lib.gsr_batch_status.restype = c_int
+        lib.gsr_batch_status.argtypes = [P, c_int32, c_int32, c_int32, c_int32, c_int64, P, P]
         lib.gsr_read_status.restype = c_int
         lib.gsr_read_status.argtypes = [P, c_int32, c_int32, c_int32, c_int64, P, P]
         lib.gsr_last_error.restype = c_char_p

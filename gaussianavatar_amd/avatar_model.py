@@ -65,6 +65,24 @@ def default_params(**overrides):
     return model, net, opt
 
 
+class _UnpackRecords(torch.autograd.Function):
+    """packed [B,N,7] -> views (residual [B,N,3], scale repeated to [B,N,3], colour [B,N,3]). The
+    backward assembles the record gradient with one reduction + one cat instead of autograd's three
+    zero-filled slice_backward tensors, their sums and the expand reduction."""
+
+    @staticmethod
+    def forward(ctx, packed):
+        return packed[..., 0:3], packed[..., 3:4].expand(-1, -1, 3), packed[..., 4:7]
+
+    @staticmethod
+    def backward(ctx, g_res, g_scale, g_col):
+        ref = next(g for g in (g_res, g_scale, g_col) if g is not None)
+        z = lambda c: ref.new_zeros(ref.shape[:-1] + (c,))
+        return torch.cat([g_res if g_res is not None else z(3),
+                          g_scale.sum(-1, keepdim=True) if g_scale is not None else z(1),
+                          g_col if g_col is not None else z(3)], dim=-1)
+
+
 class SyntheticFrames(torch.utils.data.Dataset):
     """Dataset items with the keys of MonoDataset_train.__getitem__
     (/root/reference/scene/dataset_mono.py:224-257). Camera scalars are python numbers."""
@@ -327,8 +345,8 @@ class AvatarModel:
             packed = parallel.exchange_output_grads(packed)
         if shared:
             packed = packed.expand(B, -1, -1)
-        point_res, pscale, pshs = packed[..., 0:3], packed[..., 3:4], packed[..., 4:7]
-        return offset_loss, point_res, pscale.expand(-1, -1, 3), pshs
+        point_res, scales3, pshs = _UnpackRecords.apply(packed)
+        return offset_loss, point_res, scales3, pshs
 
     def _render_frames(self, batch_data, full_pred, colors, scales):
         """The reference renders the frames one by one (avatar_model.py:332-365); here the whole

@@ -363,6 +363,36 @@ int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,
                                        static_cast<hipStream_t>(stream_)), "mark_visible");
 }
 
+namespace {
+// [max pairs of a frame, any overflow, sum of word 2, longest tile list, total pairs, frames, max 6, max 7]
+__global__ void batch_status_kernel(const char* ws, size_t status_off, size_t ws_stride, int frames,
+                                    int32_t* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int64_t total = 0, s2 = 0;
+  int32_t mx0 = 0, mx1 = 0, mx3 = 0, mx6 = 0, mx7 = 0;
+  for (int f = 0; f < frames; ++f) {
+    const int32_t* st = reinterpret_cast<const int32_t*>(ws + (size_t)f * ws_stride + status_off);
+    mx0 = max(mx0, st[0]); mx1 = max(mx1, st[1]); s2 += st[2]; mx3 = max(mx3, st[3]);
+    total += st[0]; mx6 = max(mx6, st[6]); mx7 = max(mx7, st[7]);
+  }
+  out[0] = mx0; out[1] = mx1; out[2] = (int32_t)s2; out[3] = mx3;
+  out[4] = (int32_t)(total > 0x7fffffff ? 0x7fffffff : total); out[5] = frames; out[6] = mx6; out[7] = mx7;
+}
+}  // namespace
+
+int gsr_batch_status(const void* workspace, int32_t frames, int32_t P, int32_t W, int32_t H,
+                     int64_t max_pairs, int32_t* status_dev, void* stream_) {
+  GsrLayout L;
+  if (!workspace || !status_dev || frames < 1 || compute_layout(P, W, H, max_pairs, &L)) {
+    set_error("gsr_batch_status: invalid arguments");
+    return GSR_ERR_INVALID_ARGUMENT;
+  }
+  hipLaunchKernelGGL(batch_status_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream_),
+                     static_cast<const char*>(workspace), (size_t)L.status, (size_t)L.total_bytes, frames,
+                     status_dev);
+  return check_hip(hipGetLastError(), "batch_status_kernel");
+}
+
 int gsr_read_status(const void* workspace, int32_t P, int32_t W, int32_t H, int64_t max_pairs,
                     int32_t* status_host, void* stream_) {
   GsrLayout L;

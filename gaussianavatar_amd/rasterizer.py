@@ -460,14 +460,11 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
                 ctypes.byref(st), ctypes.byref(bt), P, _ptr(means3D), _ptr(col), None, 0, _ptr(opa),
                 _ptr(sca), _ptr(rot), None, _ptr(workspace), workspace.numel(), max_pairs,
                 _ptr(color), _ptr(radii), _stream_ptr(dev)))
-            lib.gsr_workspace_layout(P, W, H, max_pairs, ctypes.byref(L))
-            status = workspace.view(B, frame_bytes)[:, L.status:L.status + 32].contiguous().view(torch.int32)
-            # frame with the most pairs decides (status words: [needed, overflow, ...])
             # one record for the whole launch: [max pairs of a frame, any overflow, -, longest tile
-            # list, total pairs of all frames, frames, -, -]
-            worst = torch.stack([status[:, 0].max(), status[:, 1].max(), status[:, 2].sum(), status[:, 3].max(),
-                                 status[:, 0].sum(), torch.full((), B, dtype=torch.int32, device=dev),
-                                 status[:, 6].max(), status[:, 7].max()]).to(torch.int32)
+            # list, total pairs of all frames, frames, -, -] (gsr_batch_status, one tiny kernel)
+            worst = torch.empty(8, dtype=torch.int32, device=dev)
+            _native.gsr_check(lib.gsr_batch_status(_ptr(workspace), B, P, W, H, max_pairs, _ptr(worst),
+                                                   _stream_ptr(dev)))
             _capacity.post(worst, max_pairs, key)
             if not sync_check:
                 break

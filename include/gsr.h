@@ -203,6 +203,12 @@ int gsr_backward_batch(const GsrSettings* settings, const GsrBatch* batch, int32
 int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,
                      const float* projmatrix, uint8_t* out_visible, void* stream);
 
+/* Batched launches: combine the per-frame status words of `frames` consecutive workspaces into ONE
+ * device record status_dev[8] = [max pairs needed by a frame, any overflow, sum of word 2, longest
+ * tile list, total pairs of all frames, frames, max word 6, max word 7] (asynchronous, on `stream`). */
+int gsr_batch_status(const void* workspace, int32_t frames, int32_t P, int32_t W, int32_t H,
+                     int64_t max_pairs, int32_t* status_dev, void* stream);
+
 /* Blocking helper: waits for `stream`, copies the 8 status words to status_host. */
 int gsr_read_status(const void* workspace, int32_t P, int32_t W, int32_t H,
                     int64_t max_pairs, int32_t* status_host, void* stream);
