@@ -145,7 +145,7 @@ GANET_SYMBOLS = ["ganet_linear_wgrad_workspace", "ganet_linear_wgrad", "ganet_bn
                  "ganet_mlp_stats_floats", "ganet_mlp_fwd", "ganet_mlp_stats",
                  "ganet_wgrad_act_workspace", "ganet_wgrad_act", "ganet_mlp_bwd_data_parts",
                  "ganet_mlp_head_bwd_parts", "ganet_mlp_bwd_data", "ganet_mlp_head_bwd", "ganet_mlp_bwd_stats",
-                 "ganet_decode_pack_fwd", "ganet_decode_pack_bwd", "ganet_profile_enable", "ganet_profile_count", "ganet_profile_read", "ganet_profile_kernel_name",
+                 "ganet_decode_pack_fwd", "ganet_decode_pack_bwd", "ganet_upsample_cat_fwd", "ganet_upsample_cat_bwd", "ganet_profile_enable", "ganet_profile_count", "ganet_profile_read", "ganet_profile_kernel_name",
                  "ganet_last_error", "ganet_abi_version"]
 
 
@@ -194,6 +194,10 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_decode_pack_fwd.argtypes = [c_int32, c_int64, c_int64, P, P, P, P, c_float, c_float, P, P, P]
         lib.ganet_decode_pack_bwd.restype = c_int
         lib.ganet_decode_pack_bwd.argtypes = [c_int32, c_int64, c_int64, P, P, P, P, c_float, c_float, P, P, P, P, P, P]
+        lib.ganet_upsample_cat_fwd.restype = c_int
+        lib.ganet_upsample_cat_fwd.argtypes = [c_int32, c_int32, c_int32, c_int32, P, P, P, P, P, P, P, c_int64, P]
+        lib.ganet_upsample_cat_bwd.restype = c_int
+        lib.ganet_upsample_cat_bwd.argtypes = [c_int32, c_int32, c_int32, c_int32, P, c_int64, P, P, P, P, P, P, P, P, P]
         lib.ganet_profile_enable.argtypes = [c_int]
         lib.ganet_profile_count.restype = c_int
         lib.ganet_profile_read.argtypes = [P, P, c_int]

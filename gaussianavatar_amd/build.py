@@ -43,6 +43,7 @@ LIBS = {
         ("ganet_mlp.hip", []),
         ("ganet_mlp_bwd.hip", []),
         ("ganet_pack.hip", []),
+        ("ganet_upsample.hip", []),
     ],
 }
 

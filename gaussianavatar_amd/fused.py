@@ -196,6 +196,62 @@ def ssim_mean(img1, img2):
     return _SsimFn.apply(img1, img2)
 
 
+def bilinear_taps(Wm: torch.Tensor):
+    """Dense [S,R] bilinear weight matrix (<= 2 non-zeros per row) -> the tap lists the up-sampling
+    kernels take: (idx int32 [S,2], w float32 [S,2]) and the transposed lists in CSR form
+    (ptr int32 [R+1], src int32 [nnz], w float32 [nnz])."""
+    S, R = Wm.shape
+    w, idx = Wm.topk(2, dim=1)
+    assert float((Wm.sum(1) - w.sum(1)).abs().max()) < 1e-6, "more than two taps per row"
+    idx32 = idx.to(torch.int32).contiguous()
+    w = w.contiguous()
+    ic, wc = idx.cpu().reshape(-1), w.cpu().reshape(-1)
+    src = torch.arange(S).repeat_interleave(2)
+    keep = wc != 0
+    ic, wc, src = ic[keep], wc[keep], src[keep]
+    order = torch.argsort(ic * S + src)
+    ic, wc, src = ic[order], wc[order], src[order]
+    ptr = torch.zeros(R + 1, dtype=torch.int64)
+    ptr[1:] = torch.bincount(ic, minlength=R).cumsum(0)
+    dev = Wm.device
+    return (idx32, w, ptr.to(torch.int32).to(dev), src.to(torch.int32).to(dev), wc.float().to(dev))
+
+
+class _UpsampleCatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pix, uv, rows, cols, ldx):
+        lib = _native.ganet()
+        b, C, R, _ = pix.shape
+        S = rows[0].shape[0]
+        feat = pix.permute(0, 2, 3, 1).contiguous()                     # channels-last [b,R,R,C]
+        uvc = uv.contiguous()
+        x = torch.empty((b * S * S, ldx), dtype=torch.float32, device=pix.device)
+        _native.ganet_check(lib.ganet_upsample_cat_fwd(b, S, R, C, _ptr(feat), _ptr(rows[0]), _ptr(rows[1]),
+                                                       _ptr(cols[0]), _ptr(cols[1]), _ptr(uvc), _ptr(x), ldx,
+                                                       _stream(pix.device)))
+        ctx.rows, ctx.cols, ctx.dims = rows, cols, (b, C, R, S, ldx)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        lib = _native.ganet()
+        b, C, R, S, ldx = ctx.dims
+        rows, cols = ctx.rows, ctx.cols
+        dx = dx if (dx.stride(1) == 1 and dx.stride(0) >= C) else dx.contiguous()
+        dfeat = torch.empty((b, R, R, C), dtype=torch.float32, device=dx.device)
+        tmp = torch.empty((b, S, R, C), dtype=torch.float32, device=dx.device)
+        _native.ganet_check(lib.ganet_upsample_cat_bwd(b, S, R, C, _ptr(dx), dx.stride(0), _ptr(rows[2]), _ptr(rows[3]),
+                                                       _ptr(rows[4]), _ptr(cols[2]), _ptr(cols[3]), _ptr(cols[4]),
+                                                       _ptr(tmp), _ptr(dfeat), _stream(dx.device)))
+        return dfeat.permute(0, 3, 1, 2), None, None, None, None
+
+
+def upsample_cat(pix, uv, rows, cols, ldx):
+    """pix [b,64,R,R] bilinearly up-sampled at the separable texel grid (rows/cols = bilinear_taps of the
+    two weight matrices), concatenated with uv [b,S*S,2] and zero-padded to ldx columns -> [b*S*S, ldx]."""
+    return _UpsampleCatFn.apply(pix, uv, rows, cols, ldx)
+
+
 class _DecodePackFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, res, s_logit, c_logit, valid_index, inv_index, res_scale, scale_mult):

@@ -242,6 +242,13 @@ class POP_no_unet(nn.Module):
         self._bilinear_cache = (key, result)
         return result
 
+    def _bilinear_taps(self, mats):
+        """Tap lists (fused.bilinear_taps) of the two weight matrices, cached with them."""
+        cache = getattr(self, "_taps_cache", None)
+        if cache is None or cache[0] is not mats:
+            self._taps_cache = (mats, (fused.bilinear_taps(mats[0]), fused.bilinear_taps(mats[1])))
+        return self._taps_cache[1]
+
     def forward_points(self, pose_featmap, geom_featmap, uv_loc, dedup: bool = True, raw_heads: bool = False):
         """-> (residuals [B,HW,3], scales [B,HW,1], colours [B,HW,3]); raw_heads: scale/colour logits.
 
@@ -264,6 +271,17 @@ class POP_no_unet(nn.Module):
         HW = uv_loc.shape[1]
         if feat_res != uv_res:
             mats = self._separable_bilinear(uv_loc, feat_res, uv_res) if pix.is_cuda else None
+            pad = fused.decoder_input_pad(self.decoder, pix.new_empty(1)) if mats is not None else 0
+            if mats is not None and pad and C == 64 and uv_loc.shape[-1] == 2:
+                # separable query grid + fused decoder: one kernel writes the decoder's input rows
+                # (bilinear 2x2 taps, uv columns, zero padding) — no dense GEMMs, no cat
+                taps = self._bilinear_taps(mats)
+                x = fused.upsample_cat(pix, uv_loc, taps[0], taps[1], C + 2 + pad)
+                r, s, c = self.decoder.forward_points(x, raw_heads=raw_heads)
+                r, s, c = (t.reshape(b, HW, -1) for t in (r, s, c))
+                if shared:
+                    r, s, c = (t.expand(B, -1, -1) for t in (r, s, c))
+                return r, s, c
             if mats is not None:
                 # the query grid is separable (the reference's texel-centre grid): bilinear
                 # up-sampling = two small dense GEMMs that write the point-major layout directly

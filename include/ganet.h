@@ -147,6 +147,22 @@ int ganet_decode_pack_bwd(int32_t frames, int64_t HW, int64_t N, const float* re
                           const float* d_packed, const float* d_sq_sum, float* d_res,
                           float* d_scale_logit, float* d_colour_logit, void* stream);
 
+/* ---- bilinear up-sampling at the separable UV texel grid + decoder-input assembly (ganet_upsample.hip)
+ * x[(i,j), 0:C] = sum_{a,b<2} row_w[i,a] col_w[j,b] feat[row_idx[i,a], col_idx[j,b], :], followed by the two
+ * uv columns and zeros up to ldx — F.grid_sample(bilinear, align_corners=False, zero padding) at the
+ * reference's texel grid + the concatenation with uv (/root/reference/model/network.py:60-66,
+ * utils/general_utils.py:165-176). feat [frames,R,R,C] channels-last, C = 64; row/col taps [S,2] (index
+ * clamped into range, weight 0 for a tap that falls into the zero padding); uv [frames,S*S,2];
+ * x [frames*S*S, ldx]. Backward takes the transposed tap lists in CSR form (ptr [R+1], src, w), a scratch
+ * tmp [frames,S,R,C] and writes dfeat [frames,R,R,C] in full. */
+int ganet_upsample_cat_fwd(int32_t frames, int32_t S, int32_t R, int32_t C, const float* feat,
+                           const int32_t* row_idx, const float* row_w, const int32_t* col_idx,
+                           const float* col_w, const float* uv, float* x, int64_t ldx, void* stream);
+int ganet_upsample_cat_bwd(int32_t frames, int32_t S, int32_t R, int32_t C, const float* dx, int64_t ldx,
+                           const int32_t* row_ptr, const int32_t* row_src, const float* row_w,
+                           const int32_t* col_ptr, const int32_t* col_src, const float* col_w,
+                           float* tmp, float* dfeat, void* stream);
+
 /* Optional per-kernel timing (bench/profiling only; off by default, the one piece of process-global
  * state in the library): every instrumented launch is bracketed by hipEvents recorded on the launch
  * stream; ganet_profile_read waits for them and returns, per kernel id < ganet_profile_count(), the

@@ -396,3 +396,28 @@ def test_decode_pack_matches_torch_chain(b, HW, N):
     ((ref * w).sum() + 3.0 * ref_sq).backward()
     for a, bb in ((r1, r2), (s1, s2), (c1, c2)):
         torch.testing.assert_close(a.grad, bb.grad, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("b,feat,S", [(1, 128, 512), (2, 16, 64), (1, 8, 24)])
+def test_upsample_cat_matches_grid_sample(b, feat, S):
+    """ganet_upsample_cat_fwd/bwd (2x2 bilinear taps at the separable texel grid + uv columns + zero
+    padding) against F.grid_sample(align_corners=False, zero padding) + cat, forward and backward."""
+    from gaussianavatar_amd import fused
+    from gaussianavatar_amd.network import POP_no_unet, uv_to_grid
+    torch.manual_seed(S)
+    net = POP_no_unet(c_geom=64, hsize=128).cuda()
+    idx = torch.stack(torch.meshgrid(torch.arange(S), torch.arange(S), indexing="ij"), -1).reshape(-1, 2).float() / (S - 1)
+    uv = idx.cuda()[None].expand(b, -1, -1).contiguous()
+    mats = net._separable_bilinear(uv, feat, S)
+    assert mats is not None
+    taps = net._bilinear_taps(mats)
+    pix1 = torch.randn(b, 64, feat, feat, device="cuda", requires_grad=True)
+    pix2 = pix1.detach().clone().requires_grad_(True)
+    x = fused.upsample_cat(pix1, uv, taps[0], taps[1], 72)
+    ref = F.grid_sample(pix2, uv_to_grid(uv, S), mode="bilinear", align_corners=False)
+    ref = torch.cat([ref.reshape(b, 64, S * S).transpose(1, 2), uv, uv.new_zeros(b, S * S, 6)], 2).reshape(b * S * S, 72)
+    torch.testing.assert_close(x, ref, rtol=1e-5, atol=1e-6)
+    w = torch.randn_like(ref)
+    (x * w).sum().backward()
+    (ref * w).sum().backward()
+    torch.testing.assert_close(pix1.grad, pix2.grad, rtol=1e-4, atol=1e-5)
