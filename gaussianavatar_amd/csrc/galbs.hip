@@ -352,6 +352,90 @@ skin_kernel(int B, int N, int J, const float* __restrict__ points, int64_t pts_s
   }
 }
 
+// dL/dM_j = sum_n w_nj [g_n (x) (x_n, 1)] as a skinny GEMM on the matrix cores:  D[j][e] += W^T[j][n] O[n][e]
+// with O[n][4r+c] = g_n[r] * (x_n, 1)[c] (12 columns). v_mfma_f32_32x32x2_f32 takes two texels per
+// step: lane (col, half) supplies w[n0+half][col] as the A operand and builds its own B element from
+// g and x of texel n0+half. A wave walks a contiguous chunk of texels, the four waves of a workgroup
+// combine in LDS, one global atomic per (joint, entry) and workgroup. Replaces a per-joint wave
+// reduction (12 x 6 shuffles per active joint and texel group).
+typedef float skin_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int DM_BLOCKS = 512;
+
+template <int JT>     // joint tiles of 32 (1: SMPL, 2: SMPL-X)
+__global__ void __launch_bounds__(256)
+skin_dmats_kernel(int N, int J, const float* __restrict__ points, int64_t pts_stride,
+                  const float* __restrict__ res, int64_t res_stride,
+                  const float* __restrict__ weights, int64_t w_stride,
+                  const float* __restrict__ dout, float* __restrict__ dmats) {
+  __shared__ float s_acc[JT * 32][12];
+  const int b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int half = lane >> 5, col = lane & 31;
+  for (int q = threadIdx.x; q < JT * 32 * 12; q += 256) (&s_acc[0][0])[q] = 0.f;
+  __syncthreads();
+  points += (size_t)b * pts_stride;
+  if (res) res += (size_t)b * res_stride;
+  weights += (size_t)b * w_stride;
+  dout += (size_t)b * N * 3;
+  // this wave's texels: [n0, n1)
+  const int per = (N + gridDim.x * 4 - 1) / (gridDim.x * 4);
+  const int per2 = (per + 1) & ~1;
+  const int n0 = (blockIdx.x * 4 + wave) * per2;
+  const int n1 = min(n0 + per2, N);
+  skin_f32x16 acc[JT];
+#pragma unroll
+  for (int t = 0; t < JT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const int er = col >> 2, ec = col & 3;       // B element (row of g, column of (x,1)) of this lane
+  const bool eok = col < 12;
+  constexpr int U = 8;                          // steps whose loads are issued together
+  for (int nb = n0; nb < n1; nb += 2 * U) {
+    float av[U][JT], gv[U], xv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int n = nb + 2 * u + half;
+      const bool ok = n < n1;
+      const int nn = ok ? n : n0;
+      gv[u] = (ok && eok) ? dout[(size_t)nn * 3 + er] : 0.f;
+      float xc = 1.f;
+      if (ec < 3) {
+        xc = points[(size_t)nn * 3 + ec];
+        if (res) xc += res[(size_t)nn * 3 + ec];
+      }
+      xv[u] = xc;
+#pragma unroll
+      for (int t = 0; t < JT; ++t) {
+        const int j = min(t * 32 + col, J - 1);
+        const float w = weights[(size_t)nn * J + j];
+        av[u][t] = (ok && t * 32 + col < J) ? w : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float bval = gv[u] * xv[u];
+#pragma unroll
+      for (int t = 0; t < JT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][t], bval, acc[t], 0, 0, 0);
+    }
+  }
+  // D layout: column e = lane & 31, row j = (reg & 3) + 8 * (reg >> 2) + 4 * half
+  if (eok) {
+#pragma unroll
+    for (int t = 0; t < JT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (j < J && acc[t][r] != 0.f) atomicAdd(&s_acc[j][col], acc[t][r]);
+      }
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < J * 12; q += 256) {
+    const int j = q / 12, e = q - j * 12;
+    const float v = s_acc[j][e];
+    if (v != 0.f) unsafeAtomicAdd(&dmats[((size_t)b * J + j) * 16 + e], v);
+  }
+}
+
 int check_common(int B, int J) {
   if (B <= 0 || J <= 0 || J > GALBS_MAX_JOINTS) {
     set_error("bad sizes: B=%d J=%d (J <= %d)", B, J, GALBS_MAX_JOINTS);
@@ -429,11 +513,22 @@ int galbs_skin_bwd(int32_t B, int32_t N, int32_t J, const float* points, int64_t
   }
   if (N == 0) return 0;
   if (!points || !weights || !mats || !dL_dout) { set_error("galbs_skin_bwd: NULL argument"); return 1; }
-  dim3 grid = skin_grid(B, N);
-  if (dL_dmats && grid.x > 512) grid.x = 512;   // fewer blocks -> fewer global atomics
-  hipLaunchKernelGGL(skin_kernel<true>, grid, dim3(SKIN_THREADS), 0, s, B, N, J, points,
-                     pts_batch_stride, res, res_batch_stride, weights, w_batch_stride, mats, nullptr,
-                     dL_dout, dL_dres, dL_dmats);
+  if (dL_dmats) {      // matrix gradients: skinny GEMM on the matrix cores (skin_dmats_kernel)
+    const dim3 g2(DM_BLOCKS, B);
+    if (J <= 32)
+      hipLaunchKernelGGL(skin_dmats_kernel<1>, g2, dim3(256), 0, s, N, J, points, pts_batch_stride, res,
+                         res_batch_stride, weights, w_batch_stride, dL_dout, dL_dmats);
+    else
+      hipLaunchKernelGGL(skin_dmats_kernel<2>, g2, dim3(256), 0, s, N, J, points, pts_batch_stride, res,
+                         res_batch_stride, weights, w_batch_stride, dL_dout, dL_dmats);
+    int rc = check_hip(hipGetLastError(), "skin_dmats_kernel");
+    if (rc) return rc;
+  }
+  if (dL_dres) {
+    hipLaunchKernelGGL(skin_kernel<true>, skin_grid(B, N), dim3(SKIN_THREADS), 0, s, B, N, J, points,
+                       pts_batch_stride, res, res_batch_stride, weights, w_batch_stride, mats, nullptr,
+                       dL_dout, dL_dres, nullptr);
+  }
   return check_hip(hipGetLastError(), "skin_kernel<bwd>");
 }
 
