@@ -359,28 +359,28 @@ skin_kernel(int B, int N, int J, const float* __restrict__ points, int64_t pts_s
 // combine in LDS, one global atomic per (joint, entry) and workgroup. Replaces a per-joint wave
 // reduction (12 x 6 shuffles per active joint and texel group).
 typedef float skin_f32x16 __attribute__((ext_vector_type(16)));
-constexpr int DM_BLOCKS = 512;
+constexpr int DM_BLOCKS = 128;
+constexpr int DM_THREADS = 1024;        // 16 waves combine in LDS before the global atomics
 
 template <int JT>     // joint tiles of 32 (1: SMPL, 2: SMPL-X)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(DM_THREADS)
 skin_dmats_kernel(int N, int J, const float* __restrict__ points, int64_t pts_stride,
                   const float* __restrict__ res, int64_t res_stride,
                   const float* __restrict__ weights, int64_t w_stride,
                   const float* __restrict__ dout, float* __restrict__ dmats) {
-  __shared__ float s_acc[JT * 32][12];
+  __shared__ float s_acc[DM_THREADS / 64][JT * 32][12];     // one tile per wave, summed afterwards
   const int b = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int half = lane >> 5, col = lane & 31;
-  for (int q = threadIdx.x; q < JT * 32 * 12; q += 256) (&s_acc[0][0])[q] = 0.f;
-  __syncthreads();
   points += (size_t)b * pts_stride;
   if (res) res += (size_t)b * res_stride;
   weights += (size_t)b * w_stride;
   dout += (size_t)b * N * 3;
   // this wave's texels: [n0, n1)
-  const int per = (N + gridDim.x * 4 - 1) / (gridDim.x * 4);
+  constexpr int WPB = DM_THREADS / 64;
+  const int per = (N + gridDim.x * WPB - 1) / (gridDim.x * WPB);
   const int per2 = (per + 1) & ~1;
-  const int n0 = (blockIdx.x * 4 + wave) * per2;
+  const int n0 = (blockIdx.x * WPB + wave) * per2;
   const int n1 = min(n0 + per2, N);
   skin_f32x16 acc[JT];
 #pragma unroll
@@ -423,15 +423,14 @@ skin_dmats_kernel(int N, int J, const float* __restrict__ points, int64_t pts_st
 #pragma unroll
     for (int t = 0; t < JT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (j < J && acc[t][r] != 0.f) atomicAdd(&s_acc[j][col], acc[t][r]);
-      }
+      for (int r = 0; r < 16; ++r) s_acc[wave][t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half][col] = acc[t][r];
   }
   __syncthreads();
-  for (int q = threadIdx.x; q < J * 12; q += 256) {
+  for (int q = threadIdx.x; q < J * 12; q += DM_THREADS) {
     const int j = q / 12, e = q - j * 12;
-    const float v = s_acc[j][e];
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < DM_THREADS / 64; ++w) v += s_acc[w][j][e];
     if (v != 0.f) unsafeAtomicAdd(&dmats[((size_t)b * J + j) * 16 + e], v);
   }
 }
@@ -516,10 +515,10 @@ int galbs_skin_bwd(int32_t B, int32_t N, int32_t J, const float* points, int64_t
   if (dL_dmats) {      // matrix gradients: skinny GEMM on the matrix cores (skin_dmats_kernel)
     const dim3 g2(DM_BLOCKS, B);
     if (J <= 32)
-      hipLaunchKernelGGL(skin_dmats_kernel<1>, g2, dim3(256), 0, s, N, J, points, pts_batch_stride, res,
+      hipLaunchKernelGGL(skin_dmats_kernel<1>, g2, dim3(DM_THREADS), 0, s, N, J, points, pts_batch_stride, res,
                          res_batch_stride, weights, w_batch_stride, dL_dout, dL_dmats);
     else
-      hipLaunchKernelGGL(skin_dmats_kernel<2>, g2, dim3(256), 0, s, N, J, points, pts_batch_stride, res,
+      hipLaunchKernelGGL(skin_dmats_kernel<2>, g2, dim3(DM_THREADS), 0, s, N, J, points, pts_batch_stride, res,
                          res_batch_stride, weights, w_batch_stride, dL_dout, dL_dmats);
     int rc = check_hip(hipGetLastError(), "skin_dmats_kernel");
     if (rc) return rc;
