@@ -79,7 +79,7 @@ int ganet_ssim_bwd(int32_t planes, int32_t H, int32_t W, const float* img1, cons
  * activation. x1 (K1 columns, may be 0) is an un-activated operand (the decoder input / the skip
  * connection into conv5). K1 and K2 are multiples of 8, row strides multiples of 4 floats, operands
  * 16-byte aligned; supported shapes: (K1,K2,N) = (72,0,128) (0,128,128) (72,128,128) (0,128,<=32).
- * col_part (optional, ganet_mlp_stats_floats(N) floats) receives per-wave partial column sums and
+ * col_part (optional, ganet_mlp_stats_floats(N) floats) receives per-workgroup partial column sums and
  * sums of squares of z; ganet_mlp_stats reduces them to mean/rstd, the folded scale/shift for the
  * NEXT layer's prologue, and updates the running statistics like F.batch_norm(training=True).
  * ganet_wgrad_act is the matching weight gradient: dW[n,k] = sum_m g[m,n] softplus(in_scale_k
