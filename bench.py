@@ -315,8 +315,18 @@ def main():
         ms, n = timed[dom_family]
         d = describe(dom_family, ms, n, sampled_steps)
         if d.get("bound") == "mfma":
+            # HBM bytes of one 128->128 launch of this family (PMC passes committed under profiles/)
+            traffic, traffic_note = None, None
+            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+            if os.path.exists(tpath):
+                t = json.load(open(tpath)).get(dom_family)
+                if t:
+                    traffic = (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0
+                    traffic_note = ("HBM bytes of one 128->128 launch (M = 262,144) of this family: rocprofv3 --pmc "
+                                    "FETCH_SIZE / WRITE_SIZE, separate passes, profiles/r01_pmc_decoder_traffic.txt; "
+                                    "2*FETCH+WRITE (gfx950 wide-read correction); equals the algorithmic traffic")
             roof = {"kernel": dom_family, "bound": "mfma", "achieved": d["TFLOPs"], "peak": MFMA_F32_PEAK_TF,
-                    "unit": "TFLOP/s", "frac": d["frac_of_peak"], "traffic": None,
+                    "unit": "TFLOP/s", "frac": d["frac_of_peak"], "traffic": traffic, "traffic_note": traffic_note,
                     "avg_us": d["avg_us"], "launches_per_iter": d["launches_per_iter"], "us_per_iter": d["us_per_iter"],
                     "algorithmic_flops_per_iter": d["flops_per_iter"],
                     "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32, exact fp32), dense peak 157.3 TFLOP/s; the "
