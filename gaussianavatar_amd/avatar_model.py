@@ -18,8 +18,10 @@ What is different underneath (all output-preserving):
   * camera scalars stay python numbers (no .item() syncs), `uv_coord_map` carries no grad;
   * data parallelism: frames are sharded over ranks; ONE RCCL all-reduce of the per-Gaussian
     output gradients [N,7] per iteration keeps the replicas bit-identical (parallel.py).
-Disk assets (SMPL files, uv masks, lbs maps, datasets) are replaced by an `assets` dict
-(synthetic.make_assets) because none of them ship with the reference.
+Assets come from disk in the reference's formats when `model_parms.source_path` holds a dataset
+(dataset.py: MonoDataset_*, load_assets — SMPL files, uv masks, lbs maps, query posmaps, frames),
+and from the seeded in-memory generator (synthetic.make_assets) otherwise, because none of the
+reference's assets ship with it.
 """
 from __future__ import annotations
 
@@ -27,6 +29,7 @@ import os
 from types import SimpleNamespace
 from typing import Optional
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -35,6 +38,7 @@ from .lbs import SMPLBody, skin
 from .network import POP_no_unet, UnetNoCond5DS
 from .renderer import render_batch, render_frames  # noqa: F401
 from .synthetic import make_assets, make_frames
+from . import dataset as disk
 
 
 def default_params(**overrides):
@@ -43,6 +47,8 @@ def default_params(**overrides):
     num_frames, image_width, image_height."""
     model = SimpleNamespace(
         source_path="", model_path="./output/synthetic", project_path=os.getcwd(), stage1_out_path="",
+        smpl_model_path=os.getcwd() + "/assets/smpl_files/smpl", smplx_model_path=os.getcwd() + "/assets/smpl_files/smplx",
+        test_folder=os.getcwd() + "/assets/test_pose",
         save_epoch=30, train_stage=1, dataset_type="synthetic", smpl_gender="neutral", smpl_type="smpl",
         no_mask=0, fixed_inp=0, train_mode=0, cam_static=1, white_background=True,
         bullet_pose_list=[112, 217, 755], batch_size=2, query_posmap_size=512, inp_posmap_size=128,
@@ -113,18 +119,42 @@ class SyntheticFrames(torch.utils.data.Dataset):
 
 
 def collate_frames(items, device="cuda"):
-    """Collate to the batch dict the model consumes; tensors go to `device`, camera scalars stay
-    python lists (the reference's to_cuda turns them into 0-d CUDA tensors -> host syncs)."""
+    """Collate to the batch dict the model consumes; tensors go to `device` (None: stay on the
+    host, for loader worker processes), camera scalars stay python lists (the reference's to_cuda
+    turns them into 0-d CUDA tensors -> host syncs)."""
     out = {}
     for k in items[0]:
         v0 = items[0][k]
-        if torch.is_tensor(v0):
-            out[k] = torch.stack([it[k] for it in items]).to(device, non_blocking=True)
+        if isinstance(v0, np.ndarray):
+            out[k] = torch.from_numpy(np.stack([it[k] for it in items])).float()
+        elif torch.is_tensor(v0):
+            out[k] = torch.stack([it[k] for it in items])
         elif k == "pose_idx":
-            out[k] = torch.tensor([it[k] for it in items], dtype=torch.long, device=device)
+            out[k] = torch.tensor([it[k] for it in items], dtype=torch.long)
         else:
             out[k] = [it[k] for it in items]
+        if device is not None and torch.is_tensor(out[k]):
+            out[k] = out[k].to(device, non_blocking=True)
     return out
+
+
+def _host_collate(items):
+    return collate_frames(items, device=None)
+
+
+class _DeviceLoader:
+    """DataLoader whose worker processes decode and collate on the host (pinned); batches are
+    moved to the device as they are handed out."""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, device
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for batch in self.loader:
+            yield {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
 
 
 class AvatarModel:
@@ -139,15 +169,28 @@ class AvatarModel:
         self.batch_size = model_parms.batch_size if train else 1
         assert model_parms.smpl_type in ("smplx", "smpl")
         S = model_parms.query_posmap_size
-        if assets is None:
-            assets = make_assets(getattr(model_parms, "num_points", 200_000), S, model_parms.smpl_type)
-        if frames is None:
-            frames = make_frames(assets, getattr(model_parms, "num_frames", 16),
-                                 getattr(model_parms, "image_width", 1024),
-                                 getattr(model_parms, "image_height", 1024))
+        split = "train" if train else "test"
+        src = getattr(model_parms, "source_path", "")
+        self.from_disk = assets is None and bool(src) and os.path.isdir(os.path.join(src, split))
+        if self.from_disk:
+            # the reference's layout (avatar_model.py:41-98): frames + pose table from the dataset,
+            # masks / lbs map / posmaps / canonical joint transforms / body model from their files
+            self.train_dataset = disk.MonoDataset_train(model_parms)
+            self.smpl_data = self.train_dataset.smpl_data
+            assets = disk.load_assets(model_parms, split)
+            frames = dict(pose=self.train_dataset.pose_data.float(), transl=self.train_dataset.transl_data.float())
+        else:
+            if assets is None:
+                assets = make_assets(getattr(model_parms, "num_points", 200_000), S, model_parms.smpl_type)
+            if frames is None:
+                frames = make_frames(assets, getattr(model_parms, "num_frames", 16),
+                                     getattr(model_parms, "image_width", 1024),
+                                     getattr(model_parms, "image_height", 1024))
+            self.train_dataset = SyntheticFrames(frames, model_parms.train_stage, model_parms.inp_posmap_size)
         self.assets, self.frames = assets, frames
         dev = self.device
-        self.train_dataset = SyntheticFrames(frames, model_parms.train_stage, model_parms.inp_posmap_size)
+        if "fix_inp_map" in assets:
+            self.fix_inp_map = assets["fix_inp_map"].to(dev)[None].expand(self.batch_size, -1, -1, -1)
         joint_num = assets["num_joints"]
         self.smpl_model = SMPLBody(assets["joints_rest"], assets["parents"]).to(dev).eval()
         valid = assets["valid_idx"].reshape(-1)
@@ -258,6 +301,12 @@ class AvatarModel:
 
     # ------------------------------------------------------------------ data
     def getTrainDataloader(self):
+        if self.from_disk:      # image decoding in worker processes (avatar_model.py:238-244)
+            workers = int(getattr(self.model_parms, "num_workers", 4))
+            loader = torch.utils.data.DataLoader(
+                self.train_dataset, batch_size=self.batch_size, shuffle=True, num_workers=workers, drop_last=True,
+                collate_fn=_host_collate, pin_memory=self.device.type == "cuda", persistent_workers=workers > 0)
+            return _DeviceLoader(loader, self.device)
         return torch.utils.data.DataLoader(self.train_dataset, batch_size=self.batch_size, shuffle=True,
                                            num_workers=0, drop_last=True,
                                            collate_fn=lambda items: collate_frames(items, self.device))
@@ -266,15 +315,17 @@ class AvatarModel:
         return SyntheticFrames(self.frames, self.model_parms.train_stage, self.model_parms.inp_posmap_size, test=True)
 
     def getTestDataset(self):
-        self.test_dataset = self._free_dataset()
+        self.test_dataset = disk.MonoDataset_test(self.model_parms) if self.from_disk else self._free_dataset()
         return self.test_dataset
 
     def getNovelposeDataset(self):
-        self.novel_pose_dataset = self._free_dataset()
+        self.novel_pose_dataset = disk.MonoDataset_novel_pose(self.model_parms) if self.from_disk \
+            else self._free_dataset()
         return self.novel_pose_dataset
 
     def getNovelviewDataset(self):
-        self.novel_view_dataset = self._free_dataset()
+        self.novel_view_dataset = disk.MonoDataset_novel_view(self.model_parms, joints_rest=self.assets["joints_rest"]) \
+            if self.from_disk else self._free_dataset()
         return self.novel_view_dataset
 
     # ------------------------------------------------------------------ optimisation

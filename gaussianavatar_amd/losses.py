@@ -50,3 +50,17 @@ def ssim(img1, img2, window_size: int = 11, size_average: bool = True):
     if size_average:
         return ssim_map.mean()
     return ssim_map.mean(1).mean(1).mean(1)
+
+
+def adjust_loss_weights(init_weight, current_epoch, mode="decay", start=400, every=20):
+    """Regulariser schedule of the training loop (train.py:59 via utils/general_utils.py:261-280):
+    constant until `start` ('rise' starts at 1e-6 of the weight), then x0.85 ('decay') or x1.05
+    ('rise') per `every` epochs; every=0 keeps it constant."""
+    if mode not in ("decay", "rise"):
+        raise ValueError("mode must be 'decay' or 'rise'")
+    if current_epoch < start:
+        return init_weight * 1e-6 if mode == "rise" else init_weight
+    if every == 0:
+        return init_weight
+    steps = (current_epoch - start) // every
+    return init_weight * ((1.05 if mode == "rise" else 0.85) ** steps)

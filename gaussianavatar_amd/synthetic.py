@@ -216,3 +216,113 @@ def make_frames(assets: dict, num_frames: int, width: int, height: int, seed: in
     cam = make_camera(K, assets["extrinsic"], width, height)
     return dict(pose=torch.tensor(pose, dtype=torch.float32), transl=torch.tensor(transl, dtype=torch.float32),
                 rest_pose=torch.zeros(num_frames, 99), camera=cam)
+
+
+# ----------------------------------------------------------------------------- on-disk layout
+def synthetic_body_model(assets: dict, seed: int = 0) -> dict:
+    """An SMPL-file-shaped body model whose joint regression reproduces assets['joints_rest'] for
+    every beta: four vertices around each joint, J_regressor = their mean, shape directions with
+    zero mean per joint group. Keys as in the official files (v_template, shapedirs, J_regressor,
+    kintree_table, weights, posedirs, f)."""
+    rng = np.random.default_rng(seed)
+    J = assets["joints_rest"].double().numpy()
+    parents = np.asarray(assets["parents"], np.int64)
+    nj = J.shape[0]
+    off = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0]], np.float64) * 0.03
+    v_template = (J[:, None, :] + off[None]).reshape(nj * 4, 3)
+    J_regressor = np.zeros((nj, nj * 4))
+    for j in range(nj):
+        J_regressor[j, 4 * j:4 * j + 4] = 0.25
+    sd = rng.normal(0, 0.01, (nj, 4, 3, 10))
+    sd -= sd.mean(axis=1, keepdims=True)
+    kintree = np.stack([parents, np.arange(nj)]).astype(np.int64)
+    kintree[0, 0] = 2 ** 32 - 1                     # the official files store -1 as uint32
+    weights = np.repeat(np.eye(nj), 4, axis=0)
+    faces = np.stack([np.arange(0, nj * 4 - 2), np.arange(1, nj * 4 - 1), np.arange(2, nj * 4)], 1)
+    return dict(v_template=v_template, shapedirs=sd.reshape(nj * 4, 3, 10), J_regressor=J_regressor,
+                kintree_table=kintree.astype(np.uint32), weights=weights,
+                posedirs=np.zeros((nj * 4, 3, (nj - 1) * 9)), f=faces.astype(np.uint32))
+
+
+def write_dataset(source_path: str, project_path: str, assets: dict, frames: dict, images=None, masks=None,
+                  splits=("train", "test"), inp_posmap_size: int = 128, stage2: bool = True, seed: int = 0):
+    """Writes the synthetic assets in the reference's on-disk layout (see dataset.py's header for
+    the file list), so that AvatarModel(source_path=...) / MonoDataset_* read them back.
+
+    images [F,3,H,W] in [0,1] (default: white), masks [F,H,W] bool (default: all foreground).
+    Returns a dict of the paths a ModelParams needs (source_path, project_path, smpl_model_path,
+    smplx_model_path, test_folder)."""
+    import pickle
+
+    from PIL import Image
+    import scipy.sparse
+    st = assets["smpl_type"]
+    S = assets["query_posmap"].shape[0]
+    nj = assets["num_joints"]
+    cam = frames["camera"]
+    W, H = cam["width"], cam["height"]
+    F = frames["pose"].shape[0]
+    rng = np.random.default_rng(seed)
+    # ---- project assets
+    os.makedirs(os.path.join(project_path, "assets", "uv_masks"), exist_ok=True)
+    valid = assets["valid_idx"].numpy().reshape(-1)
+    faceid = np.full(S * S, -1, np.int64)
+    faceid[valid] = np.arange(valid.sum()) % (nj * 4 - 2)
+    np.save(os.path.join(project_path, "assets", "uv_masks", "uv_mask{}_with_faceid_{}.npy".format(S, st)),
+            faceid.reshape(S, S))
+    np.save(os.path.join(project_path, "assets", "lbs_map_{}_{}.npy".format(st, S)), assets["lbs_map"].numpy())
+    body = synthetic_body_model(assets, seed)
+    np.save(os.path.join(project_path, "assets", "{}_faces.npy".format(st)), body["f"])
+    model_dir = os.path.join(project_path, "assets", "smpl_files", st)
+    os.makedirs(model_dir, exist_ok=True)
+    if st == "smpl":       # official SMPL: latin1 pickle with a scipy.sparse joint regressor
+        blob = dict(body, J_regressor=scipy.sparse.csc_matrix(body["J_regressor"]))
+        with open(os.path.join(model_dir, "SMPL_NEUTRAL.pkl"), "wb") as f:
+            pickle.dump(blob, f, protocol=2)
+    else:
+        np.savez(os.path.join(model_dir, "SMPLX_NEUTRAL.npz"), **body)
+    def write_inp_map(folder, i):
+        # stand-in for the posed-body position maps of scripts/gen_pose_map_our_smpl.py
+        pm = (rng.standard_normal((inp_posmap_size, inp_posmap_size, 3)) * 0.3).astype(np.float32)
+        np.savez(os.path.join(folder, "inp_map", "inp_posemap_%s_%s.npz" % (inp_posmap_size, "%08d" % i)),
+                 **{"posmap" + str(inp_posmap_size): pm})
+
+    # ---- per-split data
+    body_pose = frames["pose"] if st == "smpl" else torch.cat([frames["pose"], frames["rest_pose"]], dim=1)
+    parms = {"beta": assets["betas"][:1].clone(), "trans": frames["transl"].clone(), "body_pose": body_pose.clone()}
+    for split in splits:
+        folder = os.path.join(source_path, split)
+        for sub in ("images", "masks", "cam_parms", "inp_map"):
+            os.makedirs(os.path.join(folder, sub), exist_ok=True)
+        torch.save(parms, os.path.join(folder, "smpl_parms.pth"))
+        torch.save(parms, os.path.join(folder, "smpl_parms_pred.pth"))
+        np.savez(os.path.join(folder, "cam_parms.npz"), extrinsic=cam["extrinsic"], intrinsic=cam["intrinsic"])
+        np.savez(os.path.join(folder, "query_posemap_{}_cano_{}.npz".format(S, st)),
+                 **{"posmap" + str(S): assets["query_posmap"].numpy()})
+        if inp_posmap_size != S:
+            step = S // inp_posmap_size
+            np.savez(os.path.join(folder, "query_posemap_{}_cano_{}.npz".format(inp_posmap_size, st)),
+                     **{"posmap" + str(inp_posmap_size): assets["query_posmap"].numpy()[::step, ::step]})
+        torch.save(assets["cano_joint_mat"][0].clone(), os.path.join(folder, "{}_cano_joint_mat.pth".format(st)))
+        for i in range(F):
+            name = "%08d" % i
+            img = np.full((H, W, 3), 255, np.uint8) if images is None else \
+                (images[i].permute(1, 2, 0).clamp(0, 1) * 255 + 0.5).to(torch.uint8).numpy()
+            Image.fromarray(img, "RGB").save(os.path.join(folder, "images", name + ".png"))
+            m = np.full((H, W), 255, np.uint8) if masks is None else (masks[i].numpy().astype(np.uint8) * 255)
+            Image.fromarray(m, "L").save(os.path.join(folder, "masks", name + ".png"))
+            np.savez(os.path.join(folder, "cam_parms", name + ".npz"), extrinsic=cam["extrinsic"], intrinsic=cam["intrinsic"])
+            if stage2:
+                write_inp_map(folder, i)
+    # ---- novel-pose folder (assets/test_pose of the reference: pose table + static camera)
+    test_folder = os.path.join(project_path, "assets", "test_pose")
+    os.makedirs(os.path.join(test_folder, "inp_map"), exist_ok=True)
+    if stage2:
+        for i in range(F):
+            write_inp_map(test_folder, i)
+    torch.save(parms, os.path.join(test_folder, "smpl_parms.pth"))
+    np.savez(os.path.join(test_folder, "cam_parms.npz"), extrinsic=cam["extrinsic"], intrinsic=cam["intrinsic"])
+    return dict(source_path=source_path, project_path=project_path,
+                smpl_model_path=os.path.join(project_path, "assets", "smpl_files", "smpl"),
+                smplx_model_path=os.path.join(project_path, "assets", "smpl_files", "smplx"),
+                test_folder=test_folder)

@@ -196,12 +196,74 @@ def make_raster():
     np.savez_compressed(os.path.join(OUT, "raster_golden.npz"), **save)
 
 
+def make_dataset():
+    """Items of the reference's MonoDataset_train/_test/_novel_pose/_novel_view
+    (scene/dataset_mono.py) and its to_cuda / getIdxMap_torch on a dataset written by
+    synthetic.write_dataset. scene.dataset_mono imports cv2 (absent here) for one Rodrigues
+    call: a numpy stand-in module is registered for the import."""
+    import tempfile
+    import types
+    from types import SimpleNamespace
+    from tests.scenes import dataset_fixture
+
+    def rodrigues(v):
+        v = np.asarray(v, np.float64).reshape(3)
+        th = np.linalg.norm(v)
+        if th < 1e-12:
+            return np.eye(3), None
+        k = v / th
+        K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K), None
+    sys.modules.setdefault("cv2", types.SimpleNamespace(Rodrigues=rodrigues))
+    from scene import dataset_mono as R
+    # dataset_mono.py:222 hands an int8 array to Image.fromarray(..., "RGB"); the Pillow the
+    # reference pins reinterprets the bytes, Pillow 12 here refuses the dtype. Same bytes:
+    _fromarray = R.Image.fromarray
+    R.Image.fromarray = lambda a, mode=None: _fromarray(a.view(np.uint8) if a.dtype == np.int8 else a, mode)
+    # torch 2.10 refuses `tensor[i, j] = numpy.float32` (graphics_utils.py:65 with the float32 K of
+    # dataset_mono.py:166): hand K over as float64 (exact upcast of the same values).
+    _proj = R.getProjectionMatrix
+    R.getProjectionMatrix = lambda **kw: _proj(**dict(kw, K=np.asarray(kw["K"], np.float64)))
+    from utils.general_utils import to_cuda, getIdxMap_torch
+    out = {}
+    for st in ("smpl", "smplx"):
+        with tempfile.TemporaryDirectory() as tmp:
+            assets, frames, paths = dataset_fixture(tmp, st)
+            for stage in (1, 2):
+                for cam_static in (1, 0):
+                    parms = SimpleNamespace(train_stage=stage, smpl_type=st, smpl_gender="neutral", no_mask=0,
+                                            cam_static=cam_static, inp_posmap_size=16, query_posmap_size=32, **paths)
+                    sets = {"train": R.MonoDataset_train(parms), "test": R.MonoDataset_test(parms)}
+                    if cam_static:
+                        sets["novel_pose"] = R.MonoDataset_novel_pose(parms)
+                        nv = R.MonoDataset_novel_view(parms)
+                        # update_smpl() needs the licensed numpy SMPL model; set what it computes
+                        nv.Th = assets["joints_rest"][0].double().numpy() + nv.smpl_data["trans"][2].double().numpy()
+                        nv.data_length, nv.fix_pose_idx = 5, 2
+                        sets["novel_view"] = nv
+                    for name, ds in sets.items():
+                        for i in (0, 3):
+                            item = ds[i]
+                            batch = to_cuda({k: (v if not isinstance(v, (int, float)) else torch.tensor([v]))
+                                             for k, v in item.items()}, device="cpu")
+                            for k, v in batch.items():
+                                out["%s/s%d/c%d/%s/%d/%s" % (st, stage, cam_static, name, i, k)] = np.asarray(v)
+                        out["%s/s%d/c%d/%s/len" % (st, stage, cam_static, name)] = np.asarray(len(ds))
+    out["idx_map_8"] = getIdxMap_torch(torch.rand(3, 8, 8)).numpy()
+    np.savez_compressed(os.path.join(OUT, "dataset_golden.npz"), **out)
+    print("dataset_golden.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["dataset"]:
+        make_dataset()
+        sys.exit(0)
     lo = make_lbs()
     make_skin(lo)
     make_net()
     make_camera_loss()
     make_raster()
+    make_dataset()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

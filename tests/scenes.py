@@ -47,3 +47,21 @@ def random_scene(P: int, W: int, H: int, seed: int = 0, kind: str = "general", s
 def cam_kwargs(sc):
     return dict(viewmatrix=sc["viewmatrix"], projmatrix=sc["projmatrix"], bg=sc["bg"], W=sc["W"],
                 H=sc["H"], tanfovx=sc["tanfovx"], tanfovy=sc["tanfovy"])
+
+
+def dataset_fixture(tmp, smpl_type):
+    """A small dataset in the reference's on-disk layout (synthetic.write_dataset): 700 points on
+    a 32x32 UV map, 4 frames of 64x48 with random images and masks. oracle/make_golden.py reads it
+    with the reference's MonoDataset_* classes, tests/test_dataset.py with ours."""
+    import os
+
+    import torch
+    from gaussianavatar_amd.synthetic import make_assets, make_frames, write_dataset
+    assets = make_assets(700, 32, smpl_type)
+    frames = make_frames(assets, 4, 64, 48)
+    g = torch.Generator().manual_seed(11)
+    images = torch.rand(4, 3, 48, 64, generator=g)
+    masks = torch.rand(4, 48, 64, generator=g) > 0.4
+    paths = write_dataset(os.path.join(tmp, "data"), os.path.join(tmp, "proj"), assets, frames,
+                          images=images, masks=masks, inp_posmap_size=16)
+    return assets, frames, paths

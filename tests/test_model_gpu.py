@@ -134,3 +134,20 @@ def test_reference_renderer_shim_runs_unchanged():
     assert img.shape == (3, 64, 96)
     img.sum().backward()
     assert torch.isfinite(t["means3D"].grad).all()
+
+
+def test_train_eval_loops_on_disk_dataset(tmp_path):
+    """tools/train_disk.py: a teacher avatar's frames written in the reference's on-disk layout,
+    fitted through MonoDataset_train with the loop of the reference's train.py, then rendered from
+    the checkpoint with the loops of eval.py / render_novel_pose.py (test split, novel poses,
+    novel-view orbit)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "train_disk", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "train_disk.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.run(str(tmp_path), points=6000, size=128, frames=4, epochs=300, uv=128, inp=32, log=lambda *_: None)
+    assert res["iterations"] == 600 and res["novel_pose_frames"] == 4 and res["novel_view_frames"] == 6
+    assert res["novel_pose_shape"] == [3, 1024, 1024]
+    assert res["loss_last"] < 0.3 * res["loss_first"], res
+    assert res["psnr_test"] > res["psnr_untrained"] + 6.0, res
