@@ -1,5 +1,7 @@
 """GPU integration: the AvatarModel hot path end to end, checked against an all-CPU evaluation
 of the reference's formulas (torch CPU nets + oracle LBS + oracle rasterizer)."""
+import os
+
 import numpy as np
 import pytest
 import torch
