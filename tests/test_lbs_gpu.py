@@ -76,7 +76,8 @@ def test_skin_matches_reference_golden():
     np.testing.assert_allclose(out2.cpu().numpy(), g["full_pred"], rtol=0, atol=TOL)
 
 
-@pytest.mark.parametrize("B,N,J", [(2, 1000, 24), (3, 777, 55), (9, 300, 24), (2, 200_000, 24)])   # last: headline size
+@pytest.mark.parametrize("B,N,J", [(2, 1000, 24), (3, 777, 55), (9, 300, 24), (2, 200_000, 24),
+                                   (1, 250_000, 55)])   # last two: headline size, SMPL-X stage-2 size
 def test_skin_backward_vs_oracle(B, N, J):
     from gaussianavatar_amd.lbs import skin
     from oracle import lbs_oracle as O

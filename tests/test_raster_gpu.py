@@ -316,3 +316,22 @@ def test_full_size_parity_and_invariants(raster_oracle):
         means3D=t["means3D"].detach(), means2D=None, opacities=t["opacities"].detach(),
         colors_precomp=t["colors"].detach(), scales=t["scales"].detach(), rotations=t["rotations"].detach())
     assert torch.equal(img.detach(), img2)
+
+
+def test_1080p_parity_with_partial_tile_row(raster_oracle):
+    """BASELINE.json's stage-2 image size: 1920 x 1080 is 120 x 68 tiles whose last row is half
+    outside the image (1080 = 67.5 * 16); 300k Gaussians of the general kind (anisotropic, rotated,
+    translucent) spread over the whole frame, forward and backward against the oracle."""
+    from tests.hip_helpers import hip_forward_backward
+    P, W, H = 300_000, 1920, 1080
+    sc = random_scene(P, W, H, seed=21, kind="general", spread=1.2, scale_med=0.006)
+    ref, got = assert_forward_parity(raster_oracle, sc)
+    assert got["tile_offset"].shape[0] == 120 * 68 + 1
+    last_row = got["tile_offset"][120 * 67:]
+    assert int(last_row[-1] - last_row[0]) > 0          # the partial tile row is populated
+    g = np.random.default_rng(8).normal(0, 1, (3, H, W)).astype(np.float32)
+    rb = raster_oracle.backward(ref, g)
+    _c, _r, grads = hip_forward_backward(sc, g)
+    for k in ("dmeans3D", "dcolors", "dscales", "dopacity", "drots"):
+        err = np.abs(grads[k] - rb[k]).max() / (np.abs(rb[k]).max() + 1e-12)
+        assert err <= GRAD_REL_TOL, (k, err)
