@@ -262,7 +262,7 @@ def main():
     rasterizer.profile_enable(False)
     fused.profile_enable(False)
     ncalls, mean_pairs = rasterizer.pair_statistics(reset=True)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     if rank != 0:
         return

@@ -135,7 +135,10 @@ def allgather_sparse_grads(params: List[torch.Tensor]) -> None:
 
 def barrier() -> None:
     if world_size() > 1:
-        dist.barrier(group=_group)
+        if dist.get_backend(_group) == "nccl":     # name the device: no guessing from the rank
+            dist.barrier(group=_group, device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier(group=_group)
 
 
 def max_over_ranks(value: float, device) -> float:
