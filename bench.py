@@ -168,7 +168,7 @@ def main():
 
     from gaussianavatar_amd import fused, rasterizer
     from gaussianavatar_amd.avatar_model import AvatarModel, collate_frames, default_params
-    from gaussianavatar_amd.losses import l1_loss_w, ssim
+    from gaussianavatar_amd.losses import l1_loss_w, ssim, weighted_sum
 
     torch.manual_seed(0)      # identical init on every rank (replicas must start identical)
     B = args.frames_per_gpu
@@ -202,14 +202,16 @@ def main():
         batch = batches[i % len(batches)]
         if args.stage == 1:            # /root/reference/train.py:68-76
             image, points, offset_loss, geo_loss, scale_loss = model.train_stage1(batch, iteration)
-            Ll1 = (1.0 - op.lambda_dssim) * l1_loss_w(image, gt)
-            ssim_loss = op.lambda_dssim * (1.0 - ssim(image, gt))
-            loss = op.lambda_scale * scale_loss + op.lambda_rgl * offset_loss + Ll1 + ssim_loss + geo_loss
+            # loss = lambda_scale*scale + lambda_rgl*offset + (1-l)*L1 + l*(1 - SSIM) + geo, composed in one
+            # launch (losses.weighted_sum) instead of one zero-dimensional kernel per operator
+            l = op.lambda_dssim
+            loss = weighted_sum([scale_loss, offset_loss, l1_loss_w(image, gt), ssim(image, gt), geo_loss],
+                                [op.lambda_scale, op.lambda_rgl, 1.0 - l, -l, 1.0], bias=l)
         else:                          # /root/reference/train.py:78-86
             image, points, pose_loss, offset_loss = model.train_stage2(batch, iteration)
-            Ll1 = (1.0 - op.lambda_dssim) * l1_loss_w(image, gt)
-            ssim_loss = op.lambda_dssim * (1.0 - ssim(image, gt))
-            loss = op.lambda_rgl * offset_loss + Ll1 + ssim_loss + pose_loss * 10
+            l = op.lambda_dssim
+            loss = weighted_sum([offset_loss, l1_loss_w(image, gt), ssim(image, gt), pose_loss],
+                                [op.lambda_rgl, 1.0 - l, -l, 10.0], bias=l)
         model.zero_grad(epoch)
         loss.backward()
         model.step(epoch)

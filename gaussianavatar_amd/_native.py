@@ -145,7 +145,7 @@ GANET_SYMBOLS = ["ganet_linear_wgrad_workspace", "ganet_linear_wgrad", "ganet_bn
                  "ganet_mlp_stats_floats", "ganet_mlp_fwd", "ganet_mlp_stats",
                  "ganet_wgrad_act_workspace", "ganet_wgrad_act", "ganet_mlp_bwd_data_parts",
                  "ganet_mlp_head_bwd_parts", "ganet_mlp_bwd_data", "ganet_mlp_head_bwd", "ganet_mlp_bwd_stats",
-                 "ganet_decode_pack_fwd", "ganet_decode_pack_bwd", "ganet_upsample_cat_fwd", "ganet_upsample_cat_bwd", "ganet_profile_enable", "ganet_profile_count", "ganet_profile_read", "ganet_profile_kernel_name",
+                 "ganet_decode_pack_fwd", "ganet_decode_pack_bwd", "ganet_mean_sq_fwd", "ganet_mean_sq_bwd", "ganet_weighted_sum_fwd", "ganet_weighted_sum_bwd", "ganet_upsample_cat_fwd", "ganet_upsample_cat_bwd", "ganet_profile_enable", "ganet_profile_count", "ganet_profile_read", "ganet_profile_kernel_name",
                  "ganet_last_error", "ganet_abi_version"]
 
 
@@ -166,9 +166,9 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_bn_act_bwd.restype = c_int
         lib.ganet_bn_act_bwd.argtypes = [c_int64, c_int32, P, P, P, P, P, c_int32, P, P, P, P, P, c_size_t, P]
         lib.ganet_ssim_fwd.restype = c_int
-        lib.ganet_ssim_fwd.argtypes = [c_int32, c_int32, c_int32, P, P, P, P, P]
+        lib.ganet_ssim_fwd.argtypes = [c_int32, c_int32, c_int32, P, P, c_float, P, P, P]
         lib.ganet_ssim_bwd.restype = c_int
-        lib.ganet_ssim_bwd.argtypes = [c_int32, c_int32, c_int32, P, P, P, P, P, P]
+        lib.ganet_ssim_bwd.argtypes = [c_int32, c_int32, c_int32, P, P, P, c_float, P, P, P, P]
         lib.ganet_mlp_stats_floats.restype = c_size_t
         lib.ganet_mlp_stats_floats.argtypes = [c_int32]
         lib.ganet_mlp_fwd.restype = c_int
@@ -191,9 +191,17 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_mlp_bwd_stats.restype = c_int
         lib.ganet_mlp_bwd_stats.argtypes = [c_int64, c_int32, P, P, P, P, P, P, P, P]
         lib.ganet_decode_pack_fwd.restype = c_int
-        lib.ganet_decode_pack_fwd.argtypes = [c_int32, c_int64, c_int64, P, P, P, P, c_float, c_float, P, P, P]
+        lib.ganet_decode_pack_fwd.argtypes = [c_int32, c_int64, c_int64, P, P, P, P, c_float, c_float, c_float, c_float, P, P, P]
         lib.ganet_decode_pack_bwd.restype = c_int
-        lib.ganet_decode_pack_bwd.argtypes = [c_int32, c_int64, c_int64, P, P, P, P, c_float, c_float, P, P, P, P, P, P]
+        lib.ganet_decode_pack_bwd.argtypes = [c_int32, c_int64, c_int64, P, P, P, P, c_float, c_float, c_float, c_float, P, P, P, P, P, P, P]
+        lib.ganet_mean_sq_fwd.restype = c_int
+        lib.ganet_mean_sq_fwd.argtypes = [c_int64, P, c_float, P, P]
+        lib.ganet_mean_sq_bwd.restype = c_int
+        lib.ganet_mean_sq_bwd.argtypes = [c_int64, P, c_float, P, P, P]
+        lib.ganet_weighted_sum_fwd.restype = c_int
+        lib.ganet_weighted_sum_fwd.argtypes = [c_int32, P, P, c_float, P, P]
+        lib.ganet_weighted_sum_bwd.restype = c_int
+        lib.ganet_weighted_sum_bwd.argtypes = [c_int32, P, P, P, P]
         lib.ganet_upsample_cat_fwd.restype = c_int
         lib.ganet_upsample_cat_fwd.argtypes = [c_int32, c_int32, c_int32, c_int32, P, P, P, P, P, P, P, c_int64, P]
         lib.ganet_upsample_cat_bwd.restype = c_int
@@ -205,7 +213,7 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_profile_kernel_name.argtypes = [c_int]
         lib.ganet_last_error.restype = c_char_p
         lib.ganet_abi_version.restype = c_int
-        if lib.ganet_abi_version() != 2:
+        if lib.ganet_abi_version() != 3:
             raise RuntimeError("libganet_hip.so ABI version mismatch; rebuild")
         _ganet = lib
     return _ganet

@@ -71,24 +71,6 @@ def default_params(**overrides):
     return model, net, opt
 
 
-class _UnpackRecords(torch.autograd.Function):
-    """packed [B,N,7] -> views (residual [B,N,3], scale repeated to [B,N,3], colour [B,N,3]). The
-    backward assembles the record gradient with one reduction + one cat instead of autograd's three
-    zero-filled slice_backward tensors, their sums and the expand reduction."""
-
-    @staticmethod
-    def forward(ctx, packed):
-        return packed[..., 0:3], packed[..., 3:4].expand(-1, -1, 3), packed[..., 4:7]
-
-    @staticmethod
-    def backward(ctx, g_res, g_scale, g_col):
-        ref = next(g for g in (g_res, g_scale, g_col) if g is not None)
-        z = lambda c: ref.new_zeros(ref.shape[:-1] + (c,))
-        return torch.cat([g_res if g_res is not None else z(3),
-                          g_scale.sum(-1, keepdim=True) if g_scale is not None else z(1),
-                          g_col if g_col is not None else z(3)], dim=-1)
-
-
 class SyntheticFrames(torch.utils.data.Dataset):
     """Dataset items with the keys of MonoDataset_train.__getitem__
     (/root/reference/scene/dataset_mono.py:224-257). Camera scalars are python numbers."""
@@ -362,42 +344,43 @@ class AvatarModel:
                 betas=self.betas, global_orient=pose[:, :3], transl=transl, body_pose=pose[:, 3:66],
                 jaw_pose=rest_pose[:, :3], leye_pose=rest_pose[:, 3:6], reye_pose=rest_pose[:, 6:9],
                 left_hand_pose=rest_pose[:, 9:54], right_hand_pose=rest_pose[:, 54:], inv_mats=inv)
-        return self.smpl_model.forward(betas=self.betas, global_orient=pose[:, :3], transl=transl,
-                                       body_pose=pose[:, 3:], inv_mats=inv)
+        # SMPL: the embedding row is global_orient | body_pose already (avatar_model.py:280-285)
+        return self.smpl_model.forward(betas=self.betas, transl=transl, full_pose=pose, inv_mats=inv)
 
     def _decode(self, B, pose_featmap, iteration, warmup: bool):
         """Net -> per-Gaussian residuals/scales/colours on the valid texels.
-        Returns (offset_loss = mean((0.02 pred_res)^2) over all texels, point_res [B,N,3], scales [B,N,3],
-        colours [B,N,3])."""
-        S_in = self.model_parms.inp_posmap_size
-        geom = self.geo_feature.expand(B, -1, S_in, S_in)                 # broadcast view: dedup in stage 1
-        uv = self.uv_coord_map[None].expand(B, -1, -1)
+        Returns (offset_loss = mean((0.02 pred_res)^2) over all texels, scale_loss = mean(scales),
+        point_res [B,N,3], scales [B,N,3], colours [B,N,3])."""
+        # geo_feature and the uv map are batch-invariant: they enter with batch size 1 (the convs run
+        # once; in stage 2 the pose features broadcast against them), and in stage 1 the whole net runs
+        # once for the batch (duplicating rows does not change BatchNorm's batch statistics)
+        uv = self.uv_coord_map[None]
         scale_mult = 1e-3 * iteration if (warmup and iteration < 1000) else 1.0
-        if geom.is_cuda:
-            # decoder heads (logits) -> packed [b,N,7] + offset-regulariser sum in one kernel
-            res, s_logit, c_logit = self.net.forward_points(pose_featmap, geom, uv, raw_heads=True)
-            shared = res.shape[0] > 1 and res.stride(0) == 0
-            if shared:
-                res, s_logit, c_logit = res[:1], s_logit[:1], c_logit[:1]
-            packed, sq_sum = fused.decode_pack(res, s_logit, c_logit, self.valid_index, self.inv_index, 0.02, scale_mult)
-            offset_loss = sq_sum / float(res.shape[0] * res.shape[1] * 3)
+        N = self.valid_index.shape[0]
+        if self.geo_feature.is_cuda:
+            # decoder heads (logits) -> per-Gaussian records + both regulariser means in one kernel
+            res, s_logit, c_logit = self.net.forward_points(pose_featmap, self.geo_feature, uv, raw_heads=True)
+            b = res.shape[0]
+            flat, offset_loss, scale_loss = fused.decode_pack(res, s_logit, c_logit, self.valid_index,
+                                                              self.inv_index, 0.02, scale_mult)
         else:
-            res, scales, shs = self.net.forward_points(pose_featmap, geom, uv)
-            shared = res.shape[0] > 1 and res.stride(0) == 0
-            if shared:
-                res, scales, shs = res[:1], scales[:1], shs[:1]
+            res, scales, shs = self.net.forward_points(pose_featmap, self.geo_feature, uv)
+            b = res.shape[0]
             res = res * 0.02
             scales = scales * scale_mult if scale_mult != 1.0 else scales
             offset_loss = torch.mean(res ** 2)
-            # gather the valid texels on the single copy; one concatenated [b,N,7] tensor is the DP
-            # exchange point (parallel.exchange_output_grads is the identity on one rank)
-            packed = torch.cat([res, scales, shs], dim=2).index_select(1, self.valid_index)
+            pick = lambda t: t.index_select(1, self.valid_index)
+            scale_loss = torch.mean(pick(scales))
+            flat = torch.cat([pick(res).reshape(-1), pick(scales).reshape(-1), pick(shs).reshape(-1)])
+        shared = b == 1 and B > 1
         if shared or self.model_parms.train_stage == 1:
-            packed = parallel.exchange_output_grads(packed)
+            # one flat tensor (residual | scale | colour segments) is the DP exchange point
+            # (parallel.exchange_output_grads is the identity on one rank)
+            flat = parallel.exchange_output_grads(flat)
+        point_res, scale1, pshs = fused.split_records(flat, b, N)
         if shared:
-            packed = packed.expand(B, -1, -1)
-        point_res, scales3, pshs = _UnpackRecords.apply(packed)
-        return offset_loss, point_res, scales3, pshs
+            point_res, scale1, pshs = (t.expand(B, -1, -1) for t in (point_res, scale1, pshs))
+        return offset_loss, scale_loss, point_res, scale1.expand(-1, -1, 3), pshs
 
     def _render_frames(self, batch_data, full_pred, colors, scales):
         """The reference renders the frames one by one (avatar_model.py:332-365); here the whole
@@ -414,24 +397,23 @@ class AvatarModel:
     def _forward(self, batch_data, iteration, pose, transl, pose_featmap, warmup):
         B = pose.shape[0]
         live = self._body(pose, transl, batch_data.get("rest_pose"))
-        offset_loss, point_res, scales, colors = self._decode(B, pose_featmap, iteration, warmup)
+        offset_loss, scale_loss, point_res, scales, colors = self._decode(B, pose_featmap, iteration, warmup)
         full_pred = skin(self.query_points[:B] if self.query_points.shape[0] >= B else self.query_points[:1].expand(B, -1, -1),
                          point_res, self.query_lbs[0], live.cano2live)
         image = self._render_frames(batch_data, full_pred, colors, scales)
-        return image, full_pred, offset_loss, scales
+        return image, full_pred, offset_loss, scale_loss
 
     def train_stage1(self, batch_data, iteration):
         idx = batch_data["pose_idx"]
-        image, full_pred, offset_loss, scales = self._forward(
+        image, full_pred, offset_loss, scale_loss = self._forward(
             batch_data, iteration, self.pose(idx), self.transl(idx), None, warmup=True)
-        geo_loss = torch.mean(self.geo_feature ** 2)
-        scale_loss = torch.mean(scales)
+        geo_loss = fused.mean_sq(self.geo_feature) if self.geo_feature.is_cuda else torch.mean(self.geo_feature ** 2)
         return image, full_pred, offset_loss, geo_loss, scale_loss
 
     def train_stage2(self, batch_data, iteration):
         idx = batch_data["pose_idx"]
         pose_featmap = self.pose_encoder(batch_data["inp_pos_map"])
-        image, full_pred, offset_loss, scales = self._forward(
+        image, full_pred, offset_loss, _scale_loss = self._forward(
             batch_data, iteration, self.pose(idx), self.transl(idx), pose_featmap, warmup=False)
         pose_loss = torch.mean(pose_featmap ** 2)
         return image, full_pred, pose_loss, offset_loss,

@@ -5,8 +5,11 @@
 //   repeat of the scale to 3 channels, and mean(pred_res^2) for the offset regulariser
 // (/root/reference/model/avatar_model.py:298-324, model/network.py:69-81) — about twenty element-wise
 // launches with their autograd mirrors. Here: one forward kernel that reads the heads' logits and
-// writes the packed per-Gaussian record [N,7] = (residual 3, scale 1, colour 3) plus the sum of
-// squared residuals, and one backward kernel that writes the three logit gradients in full.
+// writes the per-Gaussian residual / scale / colour arrays (three segments of one buffer) plus the two
+// regulariser means (squared residuals over all texels, scales over the valid ones), and one backward
+// kernel that writes the three logit gradients in full. Also here: the geometry-feature regulariser
+// mean(x^2) and the weighted sum that composes the scalar objective — the zero-dimensional glue of the
+// training loop as single launches.
 #include <cstdint>
 
 #include "ganet.h"
@@ -21,25 +24,34 @@ __device__ __forceinline__ float sigmoid_f(float v) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-v * 1.4426950408889634f));
 }
 
+// out: residual [frames,N,3] | scale [frames,N] | colour [frames,N,3] — three contiguous segments of
+// one buffer (one all-reduce in the data-parallel exchange, contiguous views for the consumers).
+// sums[0] += sq_norm * sum over ALL texels of (res_scale * res)^2 ; sums[1] += scale_norm * sum of the
+// valid texels' scales.
 __global__ void __launch_bounds__(256)
 decode_pack_fwd_kernel(int64_t HW, int64_t N, const float* __restrict__ res,
                        const float* __restrict__ scale_logit, const float* __restrict__ colour_logit,
                        const int64_t* __restrict__ valid_index, float res_scale, float scale_mult,
-                       float* __restrict__ packed, float* __restrict__ res_sq_sum) {
-  const int64_t f = blockIdx.y;
-  res += f * HW * 3; scale_logit += f * HW; colour_logit += f * HW * 3; packed += f * N * 7;
+                       float sq_norm, float scale_norm, float* __restrict__ out, float* __restrict__ sums) {
+  const int64_t f = blockIdx.y, F = gridDim.y;
+  res += f * HW * 3; scale_logit += f * HW; colour_logit += f * HW * 3;
+  float* o_res = out + f * N * 3;
+  float* o_scale = out + F * N * 3 + f * N;
+  float* o_col = out + F * N * 4 + f * N * 3;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float sc = 0.f;
   for (int64_t n = t0; n < N; n += stride) {
     const int64_t m = valid_index[n];
-    float* o = packed + n * 7;
-    o[0] = res[3 * m] * res_scale;
-    o[1] = res[3 * m + 1] * res_scale;
-    o[2] = res[3 * m + 2] * res_scale;
-    o[3] = sigmoid_f(scale_logit[m]) * scale_mult;
-    o[4] = sigmoid_f(colour_logit[3 * m]);
-    o[5] = sigmoid_f(colour_logit[3 * m + 1]);
-    o[6] = sigmoid_f(colour_logit[3 * m + 2]);
+    o_res[3 * n] = res[3 * m] * res_scale;
+    o_res[3 * n + 1] = res[3 * m + 1] * res_scale;
+    o_res[3 * n + 2] = res[3 * m + 2] * res_scale;
+    const float sv = sigmoid_f(scale_logit[m]) * scale_mult;
+    o_scale[n] = sv;
+    sc += sv;
+    o_col[3 * n] = sigmoid_f(colour_logit[3 * m]);
+    o_col[3 * n + 1] = sigmoid_f(colour_logit[3 * m + 1]);
+    o_col[3 * n + 2] = sigmoid_f(colour_logit[3 * m + 2]);
   }
   // sum over ALL texels of (res_scale * res)^2
   float s = 0.f;
@@ -48,31 +60,46 @@ decode_pack_fwd_kernel(int64_t HW, int64_t N, const float* __restrict__ res,
     s = fmaf(v, v, s);
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  __shared__ float s_red[4];
-  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = s;
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    sc += __shfl_xor(sc, o);
+  }
+  __shared__ float s_red[2][4];
+  if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = s; s_red[1][threadIdx.x >> 6] = sc; }
   __syncthreads();
-  if (threadIdx.x == 0) unsafeAtomicAdd(res_sq_sum, (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+  if (threadIdx.x < 2) {
+    const float* r = s_red[threadIdx.x];
+    unsafeAtomicAdd(sums + threadIdx.x, ((r[0] + r[1]) + (r[2] + r[3])) * (threadIdx.x ? scale_norm : sq_norm));
+  }
 }
 
 __global__ void __launch_bounds__(256)
 decode_pack_bwd_kernel(int64_t HW, int64_t N, const float* __restrict__ res,
                        const float* __restrict__ scale_logit, const float* __restrict__ colour_logit,
                        const int64_t* __restrict__ inv_index, float res_scale, float scale_mult,
-                       const float* __restrict__ d_packed, const float* __restrict__ d_sq_sum,
+                       float sq_norm, float scale_norm, const float* __restrict__ d_out,
+                       const float* __restrict__ d_sq, const float* __restrict__ d_scale_sum,
                        float* __restrict__ d_res, float* __restrict__ d_scale_logit,
                        float* __restrict__ d_colour_logit) {
-  const int64_t f = blockIdx.y;
-  res += f * HW * 3; scale_logit += f * HW; colour_logit += f * HW * 3; d_packed += f * N * 7;
+  const int64_t f = blockIdx.y, F = gridDim.y;
+  res += f * HW * 3; scale_logit += f * HW; colour_logit += f * HW * 3;
+  const float* g_res = d_out ? d_out + f * N * 3 : nullptr;
+  const float* g_scale = d_out ? d_out + F * N * 3 + f * N : nullptr;
+  const float* g_col = d_out ? d_out + F * N * 4 + f * N * 3 : nullptr;
   d_res += f * HW * 3; d_scale_logit += f * HW; d_colour_logit += f * HW * 3;
-  const float k = d_sq_sum ? 2.0f * res_scale * res_scale * d_sq_sum[0] : 0.f;
+  const float k = d_sq ? 2.0f * res_scale * res_scale * sq_norm * d_sq[0] : 0.f;
+  const float ks = d_scale_sum ? scale_norm * d_scale_sum[0] : 0.f;
   for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < HW;
        m += (int64_t)gridDim.x * blockDim.x) {
     const int64_t n = inv_index[m];
     float g[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (n >= 0) {
+      if (g_res) {
 #pragma unroll
-      for (int c = 0; c < 7; ++c) g[c] = d_packed[n * 7 + c];
+        for (int c = 0; c < 3; ++c) { g[c] = g_res[3 * n + c]; g[4 + c] = g_col[3 * n + c]; }
+        g[3] = g_scale[n];
+      }
+      g[3] += ks;
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) d_res[3 * m + c] = fmaf(k, res[3 * m + c], g[c] * res_scale);
@@ -86,6 +113,53 @@ decode_pack_bwd_kernel(int64_t HW, int64_t N, const float* __restrict__ res,
   }
 }
 
+// out[0] += norm * sum x^2   (geometry-feature regulariser, /root/reference/model/avatar_model.py:367)
+__global__ void __launch_bounds__(256)
+mean_sq_fwd_kernel(int64_t n, const float* __restrict__ x, float norm, float* __restrict__ out) {
+  float s = 0.f;
+  const int64_t n4 = n >> 2;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = x4[i];
+    s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = x[4 * n4 + threadIdx.x]; s = fmaf(v, v, s); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  __shared__ float s_red[4];
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(out, ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) * norm);
+}
+
+__global__ void __launch_bounds__(256)
+mean_sq_bwd_kernel(int64_t n, const float* __restrict__ x, float norm, const float* __restrict__ d_out,
+                   float* __restrict__ dx) {
+  const float k = 2.0f * norm * d_out[0];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dx[i] = k * x[i];
+}
+
+// The scalar objective of the training loop as ONE launch: out = bias + sum_i w_i * term_i
+// (/root/reference/train.py:70-82 composes it with ~9 zero-dimensional kernels forward, ~7 backward).
+struct Terms {
+  const float* p[GANET_MAX_TERMS];
+  float w[GANET_MAX_TERMS];
+};
+
+__global__ void weighted_sum_kernel(int n, Terms t, float bias, float* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    float s = bias;
+    for (int i = 0; i < n; ++i) s = fmaf(t.w[i], t.p[i][0], s);
+    out[0] = s;
+  }
+}
+
+__global__ void weighted_sum_bwd_kernel(int n, Terms t, const float* __restrict__ d_out,
+                                        float* __restrict__ d_terms) {
+  if ((int)threadIdx.x < n) d_terms[threadIdx.x] = t.w[threadIdx.x] * d_out[0];
+}
+
 }  // namespace
 
 }  // namespace ganet
@@ -96,37 +170,93 @@ extern "C" {
 
 int ganet_decode_pack_fwd(int32_t frames, int64_t HW, int64_t N, const float* res,
                           const float* scale_logit, const float* colour_logit,
-                          const int64_t* valid_index, float res_scale, float scale_mult, float* packed,
-                          float* res_sq_sum, void* stream_) {
+                          const int64_t* valid_index, float res_scale, float scale_mult, float sq_norm,
+                          float scale_norm, float* out, float* sums, void* stream_) {
   if (frames <= 0 || HW <= 0 || N < 0 || N > HW || !res || !scale_logit || !colour_logit ||
-      (N > 0 && (!valid_index || !packed)) || !res_sq_sum) {
+      (N > 0 && (!valid_index || !out)) || !sums) {
     set_error("ganet_decode_pack_fwd: invalid arguments");
     return 1;
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  int rc = check_hip(hipMemsetAsync(res_sq_sum, 0, sizeof(float), stream), "memset res_sq_sum");
+  int rc = check_hip(hipMemsetAsync(sums, 0, 2 * sizeof(float), stream), "memset sums");
   if (rc) return rc;
   const int blocks = (int)((HW * 3 / 4 + 255) / 256 < 2048 ? (HW * 3 / 4 + 255) / 256 : 2048);
   hipLaunchKernelGGL(decode_pack_fwd_kernel, dim3(blocks > 0 ? blocks : 1, frames), dim3(256), 0, stream, HW, N,
-                     res, scale_logit, colour_logit, valid_index, res_scale, scale_mult, packed, res_sq_sum);
+                     res, scale_logit, colour_logit, valid_index, res_scale, scale_mult, sq_norm, scale_norm,
+                     out, sums);
   return check_hip(hipGetLastError(), "decode_pack_fwd_kernel");
 }
 
 int ganet_decode_pack_bwd(int32_t frames, int64_t HW, int64_t N, const float* res,
                           const float* scale_logit, const float* colour_logit,
-                          const int64_t* inv_index, float res_scale, float scale_mult,
-                          const float* d_packed, const float* d_sq_sum, float* d_res,
-                          float* d_scale_logit, float* d_colour_logit, void* stream_) {
+                          const int64_t* inv_index, float res_scale, float scale_mult, float sq_norm,
+                          float scale_norm, const float* d_out, const float* d_sq,
+                          const float* d_scale_sum, float* d_res, float* d_scale_logit,
+                          float* d_colour_logit, void* stream_) {
   if (frames <= 0 || HW <= 0 || N < 0 || !res || !scale_logit || !colour_logit || !inv_index ||
-      (N > 0 && !d_packed) || !d_res || !d_scale_logit || !d_colour_logit) {
+      !d_res || !d_scale_logit || !d_colour_logit) {
     set_error("ganet_decode_pack_bwd: invalid arguments");
     return 1;
   }
   const int blocks = (int)((HW + 255) / 256 < 4096 ? (HW + 255) / 256 : 4096);
   hipLaunchKernelGGL(decode_pack_bwd_kernel, dim3(blocks, frames), dim3(256), 0,
                      static_cast<hipStream_t>(stream_), HW, N, res, scale_logit, colour_logit, inv_index,
-                     res_scale, scale_mult, d_packed, d_sq_sum, d_res, d_scale_logit, d_colour_logit);
+                     res_scale, scale_mult, sq_norm, scale_norm, d_out, d_sq, d_scale_sum, d_res,
+                     d_scale_logit, d_colour_logit);
   return check_hip(hipGetLastError(), "decode_pack_bwd_kernel");
+}
+
+int ganet_mean_sq_fwd(int64_t n, const float* x, float norm, float* out, void* stream_) {
+  if (n <= 0 || !x || !out || (reinterpret_cast<uintptr_t>(x) & 15)) {
+    set_error("ganet_mean_sq_fwd: invalid arguments (x must be 16-byte aligned)");
+    return 1;
+  }
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  int rc = check_hip(hipMemsetAsync(out, 0, sizeof(float), stream), "memset mean_sq");
+  if (rc) return rc;
+  const int blocks = (int)((n / 4 + 255) / 256 < 1024 ? (n / 4 + 255) / 256 : 1024);
+  hipLaunchKernelGGL(mean_sq_fwd_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, stream, n, x, norm, out);
+  return check_hip(hipGetLastError(), "mean_sq_fwd_kernel");
+}
+
+int ganet_mean_sq_bwd(int64_t n, const float* x, float norm, const float* d_out, float* dx, void* stream_) {
+  if (n <= 0 || !x || !d_out || !dx) {
+    set_error("ganet_mean_sq_bwd: invalid arguments");
+    return 1;
+  }
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(mean_sq_bwd_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_), n, x,
+                     norm, d_out, dx);
+  return check_hip(hipGetLastError(), "mean_sq_bwd_kernel");
+}
+
+int ganet_weighted_sum_fwd(int32_t n, const float* const* terms, const float* weights, float bias,
+                           float* out, void* stream_) {
+  if (n <= 0 || n > GANET_MAX_TERMS || !terms || !weights || !out) {
+    set_error("ganet_weighted_sum_fwd: invalid arguments (1 <= n <= %d)", GANET_MAX_TERMS);
+    return 1;
+  }
+  Terms t{};
+  for (int i = 0; i < n; ++i) {
+    if (!terms[i]) { set_error("ganet_weighted_sum_fwd: term %d is NULL", i); return 1; }
+    t.p[i] = terms[i];
+    t.w[i] = weights[i];
+  }
+  hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream_), n, t, bias, out);
+  return check_hip(hipGetLastError(), "weighted_sum_kernel");
+}
+
+int ganet_weighted_sum_bwd(int32_t n, const float* weights, const float* d_out, float* d_terms,
+                           void* stream_) {
+  if (n <= 0 || n > GANET_MAX_TERMS || !weights || !d_out || !d_terms) {
+    set_error("ganet_weighted_sum_bwd: invalid arguments");
+    return 1;
+  }
+  Terms t{};
+  for (int i = 0; i < n; ++i) t.w[i] = weights[i];
+  hipLaunchKernelGGL(weighted_sum_bwd_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream_), n, t,
+                     d_out, d_terms);
+  return check_hip(hipGetLastError(), "weighted_sum_bwd_kernel");
 }
 
 }  // extern "C"

@@ -8,6 +8,8 @@
 // goes through a per-wave LDS line, every lane takes the 11 horizontal taps of its column, and the
 // vertical pass is a ring of 11 partially accumulated output rows held in registers (each new input
 // row is scattered into the 11 output rows it contributes to; the oldest one is then complete).
+// The L1 loss between the same two images rides along (forward: |x1 - x2| of the strip's own pixels;
+// backward: its sign term is added to the SSIM gradient), so the loop's two image losses cost one pass.
 // Forward evaluates the SSIM map and — because the loss is always differentiated — the three partial
 // derivatives dS/dmu1, dS/dE[x1^2], dS/dE[x1 x2] in the same pass; backward convolves those three maps
 // with the (symmetric) window and combines
@@ -40,9 +42,10 @@ Window make_window() {
   return k;
 }
 
-// Streams the rows ys-5 .. ys+STRIP+4 of NIN input maps through the wave. `horiz(taps, h)` turns the
-// 11 taps of every input map at this lane's column into NQ horizontally filtered values; `emit(y, v)`
-// receives the NQ fully filtered values of output row y (only rows of the strip that exist).
+// Streams the rows ys-5 .. ys+STRIP+4 of NIN input maps through the wave. `horiz(taps, h, own)` turns
+// the 11 taps of every input map at this lane's column into NQ horizontally filtered values (`own`: the
+// input row belongs to this wave's strip, i.e. taps[.][5] is a pixel no other wave visits as a centre);
+// `emit(y, v)` receives the NQ fully filtered values of output row y (only rows of the strip that exist).
 template <int NIN, int NQ, class Horiz, class Emit>
 __device__ __forceinline__ void stream_strip(const float* const* src, int H, int W, int x0, int ys,
                                              float* line, const Window& k, Horiz horiz, Emit emit) {
@@ -86,7 +89,7 @@ __device__ __forceinline__ void stream_strip(const float* const* src, int H, int
 #pragma unroll
         for (int t = 0; t < WIN; ++t) taps[q][t] = line[q * LINE + lane + t];
       float h[NQ];
-      horiz(taps, h);
+      horiz(taps, h, r >= 0 && r < STRIP && y < H);
       // scatter into the output rows r-5 .. r+5 (ring slots (j + d) mod 11), weight w[5 - d]
 #pragma unroll
       for (int d = -R; d <= R; ++d) {
@@ -106,7 +109,7 @@ __device__ __forceinline__ void stream_strip(const float* const* src, int H, int
 
 __global__ void __launch_bounds__(64 * WAVES)
 ssim_fwd_kernel(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
-                float* __restrict__ ssim_sum, float* __restrict__ partials, size_t map_stride,
+                float norm, float* __restrict__ sums, float* __restrict__ partials, size_t map_stride,
                 Window k) {
   __shared__ float s_line[WAVES][2 * LINE];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -116,8 +119,9 @@ ssim_fwd_kernel(int H, int W, const float* __restrict__ img1, const float* __res
   const size_t poff = (size_t)plane * H * W;
   const float* src[2] = {img1 + poff, img2 + poff};
   const int gx = x0 + lane;
-  float S = 0.f;
-  auto horiz = [&](const float (*taps)[WIN], float* h) {
+  float S = 0.f, L = 0.f;
+  auto horiz = [&](const float (*taps)[WIN], float* h, bool own) {
+    L += (own && gx < W) ? fabsf(taps[0][R] - taps[1][R]) : 0.f;      // L1 rides along
     float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
 #pragma unroll
     for (int t = 0; t < WIN; ++t) {
@@ -145,14 +149,18 @@ ssim_fwd_kernel(int H, int W, const float* __restrict__ img1, const float* __res
   };
   stream_strip<2, 5>(src, H, W, x0, ys, s_line[wave], k, horiz, emit);
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) S += __shfl_xor(S, off);
-  if (lane == 0) atomicAdd(ssim_sum, S);
+  for (int off = 32; off > 0; off >>= 1) {
+    S += __shfl_xor(S, off);
+    L += __shfl_xor(L, off);
+  }
+  if (lane < 2) atomicAdd(sums + lane, (lane ? L : S) * norm);
 }
 
 __global__ void __launch_bounds__(64 * WAVES)
 ssim_bwd_kernel(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
-                const float* __restrict__ partials, size_t map_stride,
-                const float* __restrict__ scale_dev, float* __restrict__ dimg1, Window k) {
+                const float* __restrict__ partials, size_t map_stride, float norm,
+                const float* __restrict__ d_ssim, const float* __restrict__ d_l1,
+                float* __restrict__ dimg1, Window k) {
   __shared__ float s_line[WAVES][3 * LINE];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int plane = blockIdx.z;
@@ -161,8 +169,9 @@ ssim_bwd_kernel(int H, int W, const float* __restrict__ img1, const float* __res
   const size_t poff = (size_t)plane * H * W;
   const float* src[3] = {partials + poff, partials + map_stride + poff, partials + 2 * map_stride + poff};
   const int gx = x0 + lane;
-  const float scale = scale_dev[0];
-  auto horiz = [&](const float (*taps)[WIN], float* h) {
+  const float scale = d_ssim ? norm * d_ssim[0] : 0.f;
+  const float l1s = d_l1 ? norm * d_l1[0] : 0.f;
+  auto horiz = [&](const float (*taps)[WIN], float* h, bool) {
     float a = 0.f, b = 0.f, c = 0.f;
 #pragma unroll
     for (int t = 0; t < WIN; ++t) {
@@ -175,7 +184,9 @@ ssim_bwd_kernel(int H, int W, const float* __restrict__ img1, const float* __res
   auto emit = [&](int y, const float* v) {
     if (gx >= W) return;
     const size_t o = poff + (size_t)y * W + gx;
-    dimg1[o] = scale * (v[0] + 2.f * img1[o] * v[1] + img2[o] * v[2]);
+    const float a = img1[o], b = img2[o];
+    const float sg = (a > b) ? l1s : ((a < b) ? -l1s : 0.f);
+    dimg1[o] = fmaf(scale, v[0] + 2.f * a * v[1] + b * v[2], sg);
   };
   stream_strip<3, 3>(src, H, W, x0, ys, s_line[wave], k, horiz, emit);
 }
@@ -188,25 +199,26 @@ using namespace ganet;
 
 extern "C" {
 
-int ganet_ssim_fwd(int32_t planes, int32_t H, int32_t W, const float* img1, const float* img2,
-                   float* ssim_sum, float* partials, void* stream_) {
-  if (planes <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !ssim_sum || !partials) {
+int ganet_ssim_fwd(int32_t planes, int32_t H, int32_t W, const float* img1, const float* img2, float norm,
+                   float* sums, float* partials, void* stream_) {
+  if (planes <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !sums || !partials) {
     set_error("ganet_ssim_fwd: invalid arguments");
     return 1;
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  int rc = check_hip(hipMemsetAsync(ssim_sum, 0, sizeof(float), stream), "memset ssim_sum");
+  int rc = check_hip(hipMemsetAsync(sums, 0, 2 * sizeof(float), stream), "memset ssim sums");
   if (rc) return rc;
   const dim3 grid((W + 63) / 64, (H + STRIP * WAVES - 1) / (STRIP * WAVES), planes);
   ProfScope prof_(K_SSIM_FWD, stream);
-  hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(64 * WAVES), 0, stream, H, W, img1, img2, ssim_sum,
+  hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(64 * WAVES), 0, stream, H, W, img1, img2, norm, sums,
                      partials, (size_t)planes * H * W, make_window());
   return check_hip(hipGetLastError(), "ssim_fwd_kernel");
 }
 
 int ganet_ssim_bwd(int32_t planes, int32_t H, int32_t W, const float* img1, const float* img2,
-                   const float* partials, const float* scale_dev, float* dimg1, void* stream_) {
-  if (planes <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !partials || !scale_dev || !dimg1) {
+                   const float* partials, float norm, const float* d_ssim, const float* d_l1,
+                   float* dimg1, void* stream_) {
+  if (planes <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !partials || !dimg1) {
     set_error("ganet_ssim_bwd: invalid arguments");
     return 1;
   }
@@ -214,7 +226,7 @@ int ganet_ssim_bwd(int32_t planes, int32_t H, int32_t W, const float* img1, cons
   const dim3 grid((W + 63) / 64, (H + STRIP * WAVES - 1) / (STRIP * WAVES), planes);
   ProfScope prof_(K_SSIM_BWD, stream);
   hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(64 * WAVES), 0, stream, H, W, img1, img2, partials,
-                     (size_t)planes * H * W, scale_dev, dimg1, make_window());
+                     (size_t)planes * H * W, norm, d_ssim, d_l1, dimg1, make_window());
   return check_hip(hipGetLastError(), "ssim_bwd_kernel");
 }
 

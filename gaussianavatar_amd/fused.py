@@ -161,7 +161,9 @@ def batchnorm_act(x, bn: torch.nn.BatchNorm1d, act: str = "softplus"):
     return y
 
 
-class _SsimFn(torch.autograd.Function):
+class _SsimL1Fn(torch.autograd.Function):
+    """(mean SSIM, mean |img1 - img2|) in one pass over the images; one pass backward."""
+
     @staticmethod
     def forward(ctx, img1, img2):
         lib = _native.ganet()
@@ -170,30 +172,91 @@ class _SsimFn(torch.autograd.Function):
         planes = img1.numel() // (H * W)
         a = img1.contiguous().float()
         b = img2.contiguous().float()
-        total = torch.empty(1, dtype=torch.float32, device=a.device)
+        sums = torch.empty(2, dtype=torch.float32, device=a.device)
         partials = torch.empty((3, planes, H, W), dtype=torch.float32, device=a.device)
-        _native.ganet_check(lib.ganet_ssim_fwd(planes, H, W, _ptr(a), _ptr(b), _ptr(total), _ptr(partials),
-                                               _stream(a.device)))
+        _native.ganet_check(lib.ganet_ssim_fwd(planes, H, W, _ptr(a), _ptr(b), 1.0 / float(a.numel()), _ptr(sums),
+                                               _ptr(partials), _stream(a.device)))
         ctx.save_for_backward(a, b, partials)
         ctx.shape = shape
-        return total[0] / float(a.numel())
+        return sums[0], sums[1]
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g_ssim, g_l1):
         lib = _native.ganet()
         a, b, partials = ctx.saved_tensors
         H, W = a.shape[-2], a.shape[-1]
         planes = a.numel() // (H * W)
-        scale = (g / float(a.numel())).reshape(1).float().contiguous()
+        scalar = lambda g: None if g is None else g.reshape(1).float().contiguous()
+        gs, gl = scalar(g_ssim), scalar(g_l1)
         d = torch.empty_like(a)
-        _native.ganet_check(lib.ganet_ssim_bwd(planes, H, W, _ptr(a), _ptr(b), _ptr(partials), _ptr(scale),
-                                               _ptr(d), _stream(a.device)))
+        _native.ganet_check(lib.ganet_ssim_bwd(planes, H, W, _ptr(a), _ptr(b), _ptr(partials), 1.0 / float(a.numel()),
+                                               _ptr(gs), _ptr(gl), _ptr(d), _stream(a.device)))
         return d.reshape(ctx.shape), None
 
 
+def ssim_l1_mean(img1, img2):
+    """(mean SSIM (window 11, sigma 1.5), mean absolute difference) of img1 vs img2 ([..., H, W]);
+    differentiable w.r.t. img1."""
+    return _SsimL1Fn.apply(img1, img2)
+
+
 def ssim_mean(img1, img2):
-    """Mean SSIM (window 11, sigma 1.5) of img1 vs img2 ([..., H, W]); differentiable w.r.t. img1."""
-    return _SsimFn.apply(img1, img2)
+    return _SsimL1Fn.apply(img1, img2)[0]
+
+
+class _MeanSqFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _native.ganet()
+        xc = x.contiguous()
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+        _native.ganet_check(lib.ganet_mean_sq_fwd(xc.numel(), _ptr(xc), 1.0 / float(xc.numel()), _ptr(out),
+                                                  _stream(x.device)))
+        ctx.save_for_backward(xc)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _native.ganet()
+        (xc,) = ctx.saved_tensors
+        dx = torch.empty_like(xc)
+        _native.ganet_check(lib.ganet_mean_sq_bwd(xc.numel(), _ptr(xc), 1.0 / float(xc.numel()),
+                                                  _ptr(g.reshape(1).float().contiguous()), _ptr(dx), _stream(xc.device)))
+        return dx
+
+
+def mean_sq(x):
+    """mean(x ** 2) as one launch each way (float32 CUDA tensors)."""
+    return _MeanSqFn.apply(x)
+
+
+class _WeightedSumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weights, bias, *terms):
+        lib = _native.ganet()
+        n = len(terms)
+        ts = [t.reshape(1) if t.dtype == torch.float32 and t.is_contiguous() else t.reshape(1).float().contiguous()
+              for t in terms]
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+        w = (ctypes.c_float * n)(*[float(v) for v in weights])
+        out = torch.empty(1, dtype=torch.float32, device=ts[0].device)
+        _native.ganet_check(lib.ganet_weighted_sum_fwd(n, ptrs, w, float(bias), _ptr(out), _stream(out.device)))
+        ctx.w, ctx.n = w, n
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _native.ganet()
+        d = torch.empty(ctx.n, dtype=torch.float32, device=g.device)
+        _native.ganet_check(lib.ganet_weighted_sum_bwd(ctx.n, ctx.w, _ptr(g.reshape(1).float().contiguous()), _ptr(d),
+                                                       _stream(g.device)))
+        return (None, None) + tuple(d[i] for i in range(ctx.n))
+
+
+def weighted_sum(terms, weights, bias: float = 0.0):
+    """bias + sum_i weights[i] * terms[i] for zero-dimensional CUDA tensors and python-number weights:
+    one launch forward, one backward."""
+    return _WeightedSumFn.apply(tuple(weights), bias, *terms)
 
 
 def bilinear_taps(Wm: torch.Tensor):
@@ -259,36 +322,61 @@ class _DecodePackFn(torch.autograd.Function):
         b, HW = res.shape[0], res.shape[1]
         N = valid_index.shape[0]
         res, s_logit, c_logit = res.contiguous(), s_logit.contiguous(), c_logit.contiguous()
-        packed = torch.empty((b, N, 7), dtype=torch.float32, device=res.device)
-        sq = torch.empty(1, dtype=torch.float32, device=res.device)
+        flat = torch.empty(b * N * 7, dtype=torch.float32, device=res.device)
+        sums = torch.empty(2, dtype=torch.float32, device=res.device)
+        norms = (1.0 / float(b * HW * 3), 1.0 / float(max(b * N, 1)))
         _native.ganet_check(lib.ganet_decode_pack_fwd(b, HW, N, _ptr(res), _ptr(s_logit), _ptr(c_logit),
                                                       _ptr(valid_index), float(res_scale), float(scale_mult),
-                                                      _ptr(packed), _ptr(sq), _stream(res.device)))
+                                                      norms[0], norms[1], _ptr(flat), _ptr(sums), _stream(res.device)))
         ctx.save_for_backward(res, s_logit, c_logit, inv_index)
-        ctx.consts = (float(res_scale), float(scale_mult), N)
-        return packed, sq[0]
+        ctx.consts = (float(res_scale), float(scale_mult), N, norms)
+        return flat, sums[0], sums[1]
 
     @staticmethod
-    def backward(ctx, d_packed, d_sq):
+    def backward(ctx, d_flat, d_sq, d_scale):
         lib = _native.ganet()
         res, s_logit, c_logit, inv_index = ctx.saved_tensors
-        res_scale, scale_mult, N = ctx.consts
+        res_scale, scale_mult, N, norms = ctx.consts
         b, HW = res.shape[0], res.shape[1]
         d_res, d_s, d_c = torch.empty_like(res), torch.empty_like(s_logit), torch.empty_like(c_logit)
-        if d_packed is None:
-            d_packed = torch.zeros((b, N, 7), dtype=torch.float32, device=res.device)
-        d_sqv = None if d_sq is None else d_sq.reshape(1).float().contiguous()
+        scalar = lambda g: None if g is None else g.reshape(1).float().contiguous()
+        d_sq, d_scale = scalar(d_sq), scalar(d_scale)
+        d_flat = None if d_flat is None else d_flat.contiguous()
         _native.ganet_check(lib.ganet_decode_pack_bwd(b, HW, N, _ptr(res), _ptr(s_logit), _ptr(c_logit), _ptr(inv_index),
-                                                      res_scale, scale_mult, _ptr(d_packed.contiguous()), _ptr(d_sqv),
-                                                      _ptr(d_res), _ptr(d_s), _ptr(d_c), _stream(res.device)))
+                                                      res_scale, scale_mult, norms[0], norms[1], _ptr(d_flat),
+                                                      _ptr(d_sq), _ptr(d_scale), _ptr(d_res), _ptr(d_s), _ptr(d_c),
+                                                      _stream(res.device)))
         return d_res, d_s, d_c, None, None, None, None
 
 
 def decode_pack(res, s_logit, c_logit, valid_index, inv_index, res_scale, scale_mult):
-    """Decoder-head logits ([b,HW,3], [b,HW,1], [b,HW,3]) -> (packed [b,N,7] = residual*res_scale,
-    sigmoid(scale)*scale_mult, sigmoid(colour) on the valid texels; sum over all texels of
-    (res_scale*residual)^2)."""
+    """Decoder-head logits ([b,HW,3], [b,HW,1], [b,HW,3]) -> (flat [b*N*7] = residual*res_scale [b,N,3] |
+    sigmoid(scale)*scale_mult [b,N] | sigmoid(colour) [b,N,3] on the valid texels (split_records gives
+    the views); mean over all texels of (res_scale*residual)^2; mean of the valid texels' scales)."""
     return _DecodePackFn.apply(res, s_logit, c_logit, valid_index, inv_index, res_scale, scale_mult)
+
+
+class _SplitRecords(torch.autograd.Function):
+    """flat [b*N*7] -> contiguous views (residual [b,N,3], scale [b,N,1], colour [b,N,3]). The backward
+    assembles the flat gradient with one cat instead of three zero-filled slice gradients and their sum."""
+
+    @staticmethod
+    def forward(ctx, flat, b, N):
+        ctx.dims = (b, N)
+        return (flat[:b * N * 3].view(b, N, 3), flat[b * N * 3:b * N * 4].view(b, N, 1),
+                flat[b * N * 4:].view(b, N, 3))
+
+    @staticmethod
+    def backward(ctx, g_res, g_scale, g_col):
+        b, N = ctx.dims
+        ref = next(g for g in (g_res, g_scale, g_col) if g is not None)
+        z = lambda c: ref.new_zeros(b * N * c)
+        parts = [g.reshape(-1) if g is not None else z(c) for g, c in ((g_res, 3), (g_scale, 1), (g_col, 3))]
+        return torch.cat(parts), None, None
+
+
+def split_records(flat, b, N):
+    return _SplitRecords.apply(flat, b, N)
 
 
 # ------------------------------------------------------------------------------------------------

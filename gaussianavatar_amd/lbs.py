@@ -183,16 +183,19 @@ class SMPLBody(torch.nn.Module):
         return cls(J, parents)
 
     def forward(self, betas=None, body_pose=None, global_orient=None, transl=None, inv_mats=None,
-                **extra_pose):
+                full_pose=None, **extra_pose):
         """Same keyword surface as smplx's SMPL.forward / SMPLX.forward for the arguments the
         reference passes (avatar_model.py:280-294). SMPL-X extra pose blocks (jaw_pose, leye_pose,
         reye_pose, left_hand_pose, right_hand_pose) are concatenated in the SMPL-X joint order
         (body_models.py:1240-1247)."""
-        parts = [global_orient, body_pose]
-        for k in ("jaw_pose", "leye_pose", "reye_pose", "left_hand_pose", "right_hand_pose"):
-            if extra_pose.get(k) is not None:
-                parts.append(extra_pose[k])
-        full_pose = torch.cat([p.reshape(p.shape[0], -1) for p in parts], dim=1)
+        if full_pose is None:
+            parts = [global_orient, body_pose]
+            for k in ("jaw_pose", "leye_pose", "reye_pose", "left_hand_pose", "right_hand_pose"):
+                if extra_pose.get(k) is not None:
+                    parts.append(extra_pose[k])
+            full_pose = torch.cat([p.reshape(p.shape[0], -1) for p in parts], dim=1)
+        # `full_pose` [B, 3J]: the already concatenated axis-angle vector (skips the split + cat of the
+        # keyword form and their slice/zero-fill/add backward when the caller holds it in one tensor)
         assert full_pose.shape[1] == self.num_joints * 3, (full_pose.shape, self.num_joints)
         if inv_mats is None:
             inv_mats = torch.eye(4, device=full_pose.device).expand(self.num_joints, 4, 4)

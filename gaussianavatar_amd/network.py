@@ -269,8 +269,10 @@ class POP_no_unet(nn.Module):
         uv_res = int(uv_loc.shape[1] ** 0.5)
         b, C = pix.shape[0], pix.shape[1]
         HW = uv_loc.shape[1]
+        mats = self._separable_bilinear(uv_loc, feat_res, uv_res) if (pix.is_cuda and feat_res != uv_res) else None
+        if uv_loc.shape[0] != b:          # one uv map for the whole batch (it is batch-invariant)
+            uv_loc = uv_loc.expand(b, -1, -1)
         if feat_res != uv_res:
-            mats = self._separable_bilinear(uv_loc, feat_res, uv_res) if pix.is_cuda else None
             pad = fused.decoder_input_pad(self.decoder, pix.new_empty(1)) if mats is not None else 0
             if mats is not None and pad and C == 64 and uv_loc.shape[-1] == 2:
                 # separable query grid + fused decoder: one kernel writes the decoder's input rows

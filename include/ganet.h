@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define GANET_ABI_VERSION 2
+#define GANET_ABI_VERSION 3
+#define GANET_MAX_TERMS 8
 
 /* ---- dW[N,K] = sum_m g[m,n] x[m,k] ; db[N] = sum_m g[m,n] (db may be NULL).
  * g: [M,N] row-major with leading dimension ldg, x: [M,K] with ldx. Supported: N <= 128,
@@ -58,15 +59,18 @@ int ganet_bn_act_bwd(int64_t M, int32_t C, const float* x, const float* gamma, c
                      float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                      void* stream);
 
-/* ---- SSIM (window 11, sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2) between img1 and
- * img2, both [planes, H, W] (planes = batch*channels). Forward writes sum over all elements of
- * the SSIM map to ssim_sum[0] (caller divides by planes*H*W) and three partial-derivative maps
- * [3, planes, H, W] into `partials` for the backward pass. Backward: dL/dimg1 = scale *
- * d(ssim_sum)/dimg1 written to dimg1 [planes,H,W]. */
-int ganet_ssim_fwd(int32_t planes, int32_t H, int32_t W, const float* img1, const float* img2,
-                   float* ssim_sum, float* partials, void* stream);
+/* ---- SSIM (window 11, sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2) and L1 between img1 and
+ * img2, both [planes, H, W] (planes = batch*channels), in one pass over the images. Forward writes
+ * sums[0] = norm * sum of the SSIM map and sums[1] = norm * sum |img1 - img2| (norm = 1/(planes*H*W)
+ * gives utils/loss_utils.py's ssim(...) and l1_loss_w(...)), and three partial-derivative maps
+ * [3, planes, H, W] into `partials` for the backward pass. Backward:
+ * dimg1 = norm * (d_ssim[0] * d(sum SSIM)/dimg1 + d_l1[0] * sign(img1 - img2)); d_ssim / d_l1 are device
+ * scalars, either may be NULL (= 0). */
+int ganet_ssim_fwd(int32_t planes, int32_t H, int32_t W, const float* img1, const float* img2, float norm,
+                   float* sums, float* partials, void* stream);
 int ganet_ssim_bwd(int32_t planes, int32_t H, int32_t W, const float* img1, const float* img2,
-                   const float* partials, const float* scale_dev, float* dimg1, void* stream);
+                   const float* partials, float norm, const float* d_ssim, const float* d_l1, float* dimg1,
+                   void* stream);
 
 /* ---- fused decoder-MLP layers (ganet_mlp.hip): tall-skinny fp32-MFMA GEMMs whose A operand is
  * activated on load and whose epilogue produces the BatchNorm statistics of the output ----------
@@ -128,24 +132,42 @@ int ganet_mlp_bwd_stats(int64_t M, int32_t nparts, const float* col_part, const 
                         const float* rstd, const float* scale, float* coef, float* dgamma,
                         float* dbeta, void* stream);
 
-/* ---- decoder heads -> packed per-Gaussian records (ganet_pack.hip) --------------------------------
+/* ---- decoder heads -> per-Gaussian records (ganet_pack.hip) ----------------------------------------
  * One kernel for pred_res * res_scale, the two sigmoid heads (x scale_mult for the scale warm-up), the
- * gather of the N valid texels (valid_index [N], int64, texel index in [0,HW)) and the sum over ALL
- * texels of (res_scale * res)^2 (offset regulariser numerator, accumulated into res_sq_sum[0], which
- * the call zeroes first). res [frames*HW,3], scale_logit [frames*HW,1], colour_logit [frames*HW,3];
- * packed [frames,N,7] = (residual 3, scale 1, colour 3). Replaces the element-wise chain of
- * /root/reference/model/avatar_model.py:298-324 + the sigmoids of model/network.py:79-81.
- * Backward: inv_index [HW] (int64; n for a valid texel, -1 otherwise), d_sq_sum device scalar
- * (may be NULL); every element of the three gradient tensors is written. */
+ * gather of the N valid texels (valid_index [N], int64, texel index in [0,HW)) and the two regulariser
+ * sums: sums[0] = sq_norm * sum over ALL texels of (res_scale * res)^2 (offset regulariser), sums[1] =
+ * scale_norm * sum over the valid texels of the scale (scale regulariser); the call zeroes sums first.
+ * res [frames*HW,3], scale_logit [frames*HW,1], colour_logit [frames*HW,3];
+ * out [frames*N*7] = residual [frames,N,3] | scale [frames,N] | colour [frames,N,3]: three contiguous
+ * segments of one buffer (one all-reduce exchanges their gradient in the data-parallel path). Replaces
+ * the element-wise chain of /root/reference/model/avatar_model.py:298-324,367-368 + the sigmoids of
+ * model/network.py:79-81.
+ * Backward: inv_index [HW] (int64; n for a valid texel, -1 otherwise); d_out laid out like out (may be
+ * NULL = zero), d_sq / d_scale_sum device scalars (may be NULL); every element of the three gradient
+ * tensors is written. */
 int ganet_decode_pack_fwd(int32_t frames, int64_t HW, int64_t N, const float* res,
                           const float* scale_logit, const float* colour_logit,
-                          const int64_t* valid_index, float res_scale, float scale_mult, float* packed,
-                          float* res_sq_sum, void* stream);
+                          const int64_t* valid_index, float res_scale, float scale_mult, float sq_norm,
+                          float scale_norm, float* out, float* sums, void* stream);
 int ganet_decode_pack_bwd(int32_t frames, int64_t HW, int64_t N, const float* res,
                           const float* scale_logit, const float* colour_logit,
-                          const int64_t* inv_index, float res_scale, float scale_mult,
-                          const float* d_packed, const float* d_sq_sum, float* d_res,
-                          float* d_scale_logit, float* d_colour_logit, void* stream);
+                          const int64_t* inv_index, float res_scale, float scale_mult, float sq_norm,
+                          float scale_norm, const float* d_out, const float* d_sq,
+                          const float* d_scale_sum, float* d_res, float* d_scale_logit,
+                          float* d_colour_logit, void* stream);
+
+/* out[0] = norm * sum_i x[i]^2 (x 16-byte aligned; geometry-feature regulariser,
+ * /root/reference/model/avatar_model.py:367); backward dx = 2 * norm * d_out[0] * x. */
+int ganet_mean_sq_fwd(int64_t n, const float* x, float norm, float* out, void* stream);
+int ganet_mean_sq_bwd(int64_t n, const float* x, float norm, const float* d_out, float* dx, void* stream);
+
+/* out[0] = bias + sum_{i<n} weights[i] * terms[i][0]: the scalar objective of the training loop
+ * (/root/reference/train.py:70-82) in one launch. terms: HOST array of n device pointers, weights: HOST
+ * array, n <= GANET_MAX_TERMS. Backward: d_terms[i] = weights[i] * d_out[0] (d_out, d_terms on device). */
+int ganet_weighted_sum_fwd(int32_t n, const float* const* terms, const float* weights, float bias,
+                           float* out, void* stream);
+int ganet_weighted_sum_bwd(int32_t n, const float* weights, const float* d_out, float* d_terms,
+                           void* stream);
 
 /* ---- bilinear up-sampling at the separable UV texel grid + decoder-input assembly (ganet_upsample.hip)
  * x[(i,j), 0:C] = sum_{a,b<2} row_w[i,a] col_w[j,b] feat[row_idx[i,a], col_idx[j,b], :], followed by the two

@@ -376,7 +376,8 @@ def test_mlp_head_bwd_and_stats_match_torch_batchnorm_backward(M, N8):
 @pytest.mark.parametrize("b,HW,N", [(1, 512 * 512, 200000), (2, 4096, 3000), (1, 100, 0)])
 def test_decode_pack_matches_torch_chain(b, HW, N):
     """ganet_decode_pack_fwd/bwd against the reference's element-wise chain: x0.02, sigmoid heads, scale
-    warm-up, gather of the valid texels, sum of squared residuals."""
+    warm-up, gather of the valid texels, the offset regulariser mean((0.02 res)^2) over all texels and
+    the scale regulariser mean(scales) over the valid ones."""
     from gaussianavatar_amd import fused
     torch.manual_seed(HW % 11)
     dev = "cuda"
@@ -386,16 +387,92 @@ def test_decode_pack_matches_torch_chain(b, HW, N):
     mk = lambda c: (torch.randn(b, HW, c, device=dev) * 2).requires_grad_(True)
     r1, s1, c1 = mk(3), mk(1), mk(3)
     r2, s2, c2 = (t.detach().clone().requires_grad_(True) for t in (r1, s1, c1))
-    packed, sq = fused.decode_pack(r1, s1, c1, valid, inv, 0.02, 0.007)
-    ref = torch.cat([r2 * 0.02, torch.sigmoid(s2) * 0.007, torch.sigmoid(c2)], 2).index_select(1, valid)
-    ref_sq = ((r2 * 0.02) ** 2).sum()
-    torch.testing.assert_close(packed, ref, rtol=1e-5, atol=1e-7)
-    torch.testing.assert_close(sq, ref_sq, rtol=1e-4, atol=1e-6)
-    w = torch.randn_like(ref)
-    ((packed * w).sum() + 3.0 * sq).backward()
-    ((ref * w).sum() + 3.0 * ref_sq).backward()
+    flat, sq, sc = fused.decode_pack(r1, s1, c1, valid, inv, 0.02, 0.007)
+    res, scale, col = fused.split_records(flat, b, N)
+    assert res.is_contiguous() and scale.is_contiguous() and col.is_contiguous()
+    pick = lambda t: t.index_select(1, valid)
+    ref_res, ref_scale, ref_col = pick(r2 * 0.02), pick(torch.sigmoid(s2) * 0.007), pick(torch.sigmoid(c2))
+    ref_sq = ((r2 * 0.02) ** 2).mean()
+    ref_sc = ref_scale.mean() if N else ref_scale.sum()
+    torch.testing.assert_close(res, ref_res, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(scale, ref_scale, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(col, ref_col, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(sq, ref_sq, rtol=1e-4, atol=1e-9)
+    torch.testing.assert_close(sc, ref_sc, rtol=1e-4, atol=1e-9)
+    w = [torch.randn_like(t) for t in (ref_res, ref_scale, ref_col)]
+    ((res * w[0]).sum() + (scale.expand(-1, -1, 3) * w[0]).sum() + (col * w[2]).sum() + 3.0 * sq + 0.5 * sc).backward()
+    ((ref_res * w[0]).sum() + (ref_scale.expand(-1, -1, 3) * w[0]).sum() + (ref_col * w[2]).sum()
+     + 3.0 * ref_sq + 0.5 * ref_sc).backward()
     for a, bb in ((r1, r2), (s1, s2), (c1, c2)):
         torch.testing.assert_close(a.grad, bb.grad, rtol=1e-4, atol=1e-7)
+
+
+def test_decode_pack_regularisers_alone_have_gradients():
+    """Only the two regulariser means are differentiated (no gradient reaches the records)."""
+    from gaussianavatar_amd import fused
+    HW, N, dev = 1000, 400, "cuda"
+    valid = torch.arange(0, 2 * N, 2, device=dev)
+    inv = torch.full((HW,), -1, dtype=torch.int64, device=dev)
+    inv[valid] = torch.arange(N, device=dev)
+    r1, s1, c1 = (torch.randn(1, HW, c, device=dev, requires_grad=True) for c in (3, 1, 3))
+    r2, s2 = r1.detach().clone().requires_grad_(True), s1.detach().clone().requires_grad_(True)
+    _flat, sq, sc = fused.decode_pack(r1, s1, c1, valid, inv, 0.02, 1.0)
+    (2.0 * sq + sc).backward()
+    (2.0 * ((r2 * 0.02) ** 2).mean() + torch.sigmoid(s2).index_select(1, valid).mean()).backward()
+    torch.testing.assert_close(r1.grad, r2.grad, rtol=1e-4, atol=1e-9)
+    torch.testing.assert_close(s1.grad, s2.grad, rtol=1e-4, atol=1e-9)
+    assert float(c1.grad.abs().max()) == 0.0
+
+
+def test_l1_and_ssim_share_one_pass():
+    """losses.l1_loss_w + losses.ssim on the same pair: values and the combined gradient against torch;
+    the second call is served from the first one's pass (one autograd node), in either order."""
+    from gaussianavatar_amd import fused, losses
+    torch.manual_seed(2)
+    shape = (2, 3, 75, 130)
+    a = torch.rand(*shape)
+    b = (a + 0.1 * torch.randn(*shape)).clamp(0, 1)
+    ac = a.clone().requires_grad_(True)
+    ref = 0.8 * torch.abs(ac - b).mean() + 0.2 * (1 - losses.ssim(ac, b))
+    ref.backward()
+    for order in ("l1_first", "ssim_first"):
+        ag, bg = a.cuda().requires_grad_(True), b.cuda()
+        fused.profile_enable(["ssim_fwd", "ssim_bwd"]); fused.profile_read(True)
+        if order == "l1_first":
+            l1 = losses.l1_loss_w(ag, bg); s = losses.ssim(ag, bg)
+        else:
+            s = losses.ssim(ag, bg); l1 = losses.l1_loss_w(ag, bg)
+        loss = 0.8 * l1 + 0.2 * (1 - s)
+        loss.backward()
+        prof = fused.profile_read(True); fused.profile_enable(False)
+        assert prof["ssim_fwd"][1] == 1 and prof["ssim_bwd"][1] == 1, prof
+        assert abs(float(loss) - float(ref)) < 2e-6
+        assert float((ag.grad.cpu() - ac.grad).abs().max()) <= 2e-4 * float(ac.grad.abs().max())
+        # a different pair does not hit the parked value
+        other = losses.ssim(ag.detach() * 0.5, bg)
+        assert abs(float(other) - float(s)) > 1e-3
+    # L1 alone (nothing parked is left behind for an unrelated later call)
+    ag = a.cuda().requires_grad_(True)
+    l1 = losses.l1_loss_w(ag, b.cuda())
+    l1.backward()
+    torch.testing.assert_close(ag.grad.cpu(), torch.sign(a - b) / a.numel(), rtol=1e-6, atol=1e-12)
+
+
+def test_mean_sq_and_weighted_sum():
+    from gaussianavatar_amd import fused, losses
+    x = torch.randn(1, 64, 37, 41, device="cuda", requires_grad=True)
+    y = x.detach().clone().requires_grad_(True)
+    m = fused.mean_sq(x)
+    terms_a = [m, (x.sum() * 1e-3), torch.tensor(0.25, device="cuda", requires_grad=True)]
+    terms_b = [(y ** 2).mean(), (y.sum() * 1e-3), terms_a[2].detach().clone().requires_grad_(True)]
+    la = losses.weighted_sum(terms_a, [2.0, -0.5, 3.0], bias=0.2)
+    lb = 0.2 + 2.0 * terms_b[0] - 0.5 * terms_b[1] + 3.0 * terms_b[2]
+    torch.testing.assert_close(la, lb, rtol=1e-5, atol=1e-7)
+    la.backward(); lb.backward()
+    torch.testing.assert_close(x.grad, y.grad, rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(terms_a[2].grad, terms_b[2].grad)
+    # CPU tensors take the plain torch composition
+    assert float(losses.weighted_sum([torch.tensor(2.0), torch.tensor(3.0)], [1.0, -1.0], bias=0.5)) == -0.5
 
 
 @pytest.mark.parametrize("b,feat,S", [(1, 128, 512), (2, 16, 64), (1, 8, 24)])

@@ -29,7 +29,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from gaussianavatar_amd.avatar_model import AvatarModel, collate_frames, default_params  # noqa: E402
 from gaussianavatar_amd.dataset import to_cuda  # noqa: E402
-from gaussianavatar_amd.losses import adjust_loss_weights, l1_loss_w, ssim  # noqa: E402
+from gaussianavatar_amd.losses import adjust_loss_weights, l1_loss_w, ssim, weighted_sum  # noqa: E402
 from gaussianavatar_amd.synthetic import make_assets, make_frames, write_dataset  # noqa: E402
 
 
@@ -75,11 +75,10 @@ def train(model, net, opt, log=print):
             batch_data = to_cuda(batch_data, device=avatarmodel.device)
             gt_image = batch_data["original_image"]
             image, points, offset_loss, geo_loss, scale_loss = avatarmodel.train_stage1(batch_data, first_iter)
-            scale_loss = opt.lambda_scale * scale_loss
-            offset_loss = wdecay_rgl * offset_loss
-            Ll1 = (1.0 - opt.lambda_dssim) * l1_loss_w(image, gt_image)
-            ssim_loss = opt.lambda_dssim * (1.0 - ssim(image, gt_image))
-            loss = scale_loss + offset_loss + Ll1 + ssim_loss + geo_loss
+            # train.py:70-77: lambda_scale*scale + wdecay_rgl*offset + (1-l)*L1 + l*(1 - SSIM) + geo
+            l = opt.lambda_dssim
+            loss = weighted_sum([scale_loss, offset_loss, l1_loss_w(image, gt_image), ssim(image, gt_image), geo_loss],
+                                [opt.lambda_scale, wdecay_rgl, 1.0 - l, -l, 1.0], bias=l)
             avatarmodel.zero_grad(epoch)
             loss.backward(retain_graph=True)
             avatarmodel.step(epoch)
