@@ -143,10 +143,16 @@ _ganet = None
 GANET_SYMBOLS = ["ganet_linear_wgrad_workspace", "ganet_linear_wgrad", "ganet_bn_workspace",
                  "ganet_bn_act_fwd", "ganet_bn_act_bwd", "ganet_ssim_fwd", "ganet_ssim_bwd",
                  "ganet_mlp_stats_floats", "ganet_mlp_fwd", "ganet_mlp_stats",
-                 "ganet_wgrad_act_workspace", "ganet_wgrad_act", "ganet_mlp_bwd_data_parts",
+                 "ganet_wgrad_act_workspace", "ganet_wgrad_act", "ganet_wgrad_reduce_batch", "ganet_mlp_bwd_data_parts",
                  "ganet_mlp_head_bwd_parts", "ganet_mlp_bwd_data", "ganet_mlp_head_bwd", "ganet_mlp_bwd_stats",
                  "ganet_decode_pack_fwd", "ganet_decode_pack_bwd", "ganet_mean_sq_fwd", "ganet_mean_sq_bwd", "ganet_weighted_sum_fwd", "ganet_weighted_sum_bwd", "ganet_upsample_cat_fwd", "ganet_upsample_cat_bwd", "ganet_profile_enable", "ganet_profile_count", "ganet_profile_read", "ganet_profile_kernel_name",
                  "ganet_last_error", "ganet_abi_version"]
+
+
+class GanetWgradJob(ctypes.Structure):
+    """include/ganet.h GanetWgradJob"""
+    _fields_ = [("workspace", ctypes.c_void_p), ("M", ctypes.c_int64), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
+                ("dW", ctypes.c_void_p), ("db", ctypes.c_void_p)]
 
 
 def ganet() -> ctypes.CDLL:
@@ -194,6 +200,8 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_decode_pack_fwd.argtypes = [c_int32, c_int64, c_int64, P, P, P, P, c_float, c_float, c_float, c_float, P, P, P]
         lib.ganet_decode_pack_bwd.restype = c_int
         lib.ganet_decode_pack_bwd.argtypes = [c_int32, c_int64, c_int64, P, P, P, P, c_float, c_float, c_float, c_float, P, P, P, P, P, P, P]
+        lib.ganet_wgrad_reduce_batch.restype = c_int
+        lib.ganet_wgrad_reduce_batch.argtypes = [c_int32, P, P]
         lib.ganet_mean_sq_fwd.restype = c_int
         lib.ganet_mean_sq_fwd.argtypes = [c_int64, P, c_float, P, P]
         lib.ganet_mean_sq_bwd.restype = c_int

@@ -532,6 +532,47 @@ wgrad_act_reduce_kernel(int nblocks, int N, int K, const float* __restrict__ par
   }
 }
 
+// The same reduction for several (layer) jobs in one launch: blockIdx.y = job.
+struct ReduceJobs {
+  const float* partial[GANET_MAX_WGRAD_JOBS];
+  float* dW[GANET_MAX_WGRAD_JOBS];
+  float* db[GANET_MAX_WGRAD_JOBS];
+  int nblocks[GANET_MAX_WGRAD_JOBS], N[GANET_MAX_WGRAD_JOBS], K[GANET_MAX_WGRAD_JOBS];
+};
+__global__ void __launch_bounds__(64 * RED_WALKERS)
+wgrad_act_reduce_batch_kernel(ReduceJobs jobs) {
+  __shared__ float s_part[RED_WALKERS][64];
+  const int j = blockIdx.y;
+  const int N = jobs.N[j], K = jobs.K[j], nblocks = jobs.nblocks[j];
+  const float* __restrict__ partial = jobs.partial[j];
+  const int total = N * K + N;
+  if ((int)blockIdx.x * 64 >= total) return;
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
+  float acc = 0.f;
+  if (e < total) {
+    for (int b0 = part; b0 < nblocks; b0 += RED_WALKERS * 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int b = b0 + u * RED_WALKERS;
+        v[u] = b < nblocks ? partial[(size_t)b * total + e] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc += v[u];
+    }
+  }
+  s_part[part][lane] = acc;
+  __syncthreads();
+  if (part == 0 && e < total) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < RED_WALKERS; ++w) s += s_part[w][lane];
+    if (e < N * K) jobs.dW[j][e] = s;
+    else if (jobs.db[j]) jobs.db[j][e - N * K] = s;
+  }
+}
+
 int plan_wgrad(int64_t M, int64_t* rows_per_wave) {
   const int waves = WG_W / 64;
   int64_t rpw = (M + (int64_t)WGRAD_MAX_BLOCKS * waves - 1) / ((int64_t)WGRAD_MAX_BLOCKS * waves);
@@ -630,7 +671,7 @@ int ganet_wgrad_act(int64_t M, int32_t N, int32_t K, const float* g, int64_t ldg
                     const float* in_scale, const float* in_shift, float* dW, float* db,
                     void* workspace, size_t workspace_bytes, void* stream_) {
   if (M <= 0 || N <= 0 || K <= 0 || !g || !x || ((in_scale == nullptr) != (in_shift == nullptr)) ||
-      ((gz == nullptr) != (gcoef == nullptr)) || (gz && ldgz < N) || !dW || ldg < N || ldx < K) {
+      ((gz == nullptr) != (gcoef == nullptr)) || (gz && ldgz < N) || ldg < N || ldx < K) {
     set_error("ganet_wgrad_act: invalid arguments");
     return 1;
   }
@@ -679,7 +720,7 @@ int ganet_wgrad_act(int64_t M, int32_t N, int32_t K, const float* g, int64_t ldg
   }
 #undef LAUNCH
   int rc = check_hip(hipGetLastError(), "wgrad_act_kernel");
-  if (rc) return rc;
+  if (rc || !dW) return rc;           // dW NULL: partials only, ganet_wgrad_reduce_batch finishes
   const int total = N * K + N;
   {
     ProfScope prof_(K_WGRAD_REDUCE, stream);
@@ -687,6 +728,33 @@ int ganet_wgrad_act(int64_t M, int32_t N, int32_t K, const float* g, int64_t ldg
                        partial, dW, db);
   }
   return check_hip(hipGetLastError(), "wgrad_act_reduce_kernel");
+}
+
+int ganet_wgrad_reduce_batch(int32_t n_jobs, const GanetWgradJob* jobs, void* stream_) {
+  if (n_jobs <= 0 || n_jobs > GANET_MAX_WGRAD_JOBS || !jobs) {
+    set_error("ganet_wgrad_reduce_batch: invalid arguments (1 <= n_jobs <= %d)", GANET_MAX_WGRAD_JOBS);
+    return 1;
+  }
+  ReduceJobs r{};
+  int max_total = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    const GanetWgradJob& q = jobs[j];
+    if (!q.workspace || !q.dW || q.M <= 0 || q.N <= 0 || q.K <= 0 || q.N > 128 || q.K > 128) {
+      set_error("ganet_wgrad_reduce_batch: job %d invalid", j);
+      return 1;
+    }
+    int64_t rpw;
+    r.nblocks[j] = plan_wgrad(q.M, &rpw);
+    r.partial[j] = static_cast<const float*>(q.workspace);
+    r.dW[j] = q.dW; r.db[j] = q.db; r.N[j] = q.N; r.K[j] = q.K;
+    const int total = q.N * q.K + q.N;
+    max_total = total > max_total ? total : max_total;
+  }
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  ProfScope prof_(K_WGRAD_REDUCE, stream);
+  hipLaunchKernelGGL(wgrad_act_reduce_batch_kernel, dim3((max_total + 63) / 64, n_jobs), dim3(64 * RED_WALKERS), 0,
+                     stream, r);
+  return check_hip(hipGetLastError(), "wgrad_act_reduce_batch_kernel");
 }
 
 }  // extern "C"

@@ -518,8 +518,13 @@ class _DecoderFn(torch.autograd.Function):
         st = _stream(dev)
         g_conv_w, g_conv_b, g_gamma, g_beta = [None] * nl, [None] * nl, [None] * nl, [None] * nl
         g_out_w, g_out_b = [None] * 3, [None] * 3
-        wg_bytes = lib.ganet_wgrad_act_workspace(M, 128, 128)
-        wg_ws = torch.empty(wg_bytes, dtype=torch.uint8, device=dev)
+        # every weight gradient leaves its per-workgroup partial sums in its own slice of one
+        # workspace; ONE launch reduces all of them at the end (they are off the dependency chain)
+        wg_bytes = (lib.ganet_wgrad_act_workspace(M, 128, 128) + 255) // 256 * 256
+        max_jobs = 16
+        wg_ws = torch.empty(wg_bytes * max_jobs, dtype=torch.uint8, device=dev)
+        jobs = (_native.GanetWgradJob * max_jobs)()
+        njobs = [0]
         n_data, n_head = lib.ganet_mlp_bwd_data_parts(), lib.ganet_mlp_head_bwd_parts()
         col_part = torch.empty(max(n_data, n_head) * 256, dtype=torch.float32, device=dev)
         f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
@@ -534,10 +539,15 @@ class _DecoderFn(torch.autograd.Function):
             x = xp if src is None else zs[src]
             sc, sh = (None, None) if src is None else stats[src][2:]
             dW, db = f32(N, K), f32(N)
+            j = njobs[0]
+            ws = wg_ws.data_ptr() + j * wg_bytes
             _native.ganet_check(lib.ganet_wgrad_act(
                 M, N, K, _ptr(gt), gt.stride(0), _ptr(gz), 0 if gz is None else gz.stride(0), _ptr(coef),
-                _ptr(x), x.stride(0), _ptr(sc), _ptr(sh), _ptr(dW), _ptr(db), _ptr(wg_ws), wg_bytes, st))
-            return dW, db
+                _ptr(x), x.stride(0), _ptr(sc), _ptr(sh), None, None, ws, wg_bytes, st))
+            jobs[j].workspace, jobs[j].M, jobs[j].N, jobs[j].K = ws, M, N, K
+            jobs[j].dW, jobs[j].db = dW.data_ptr(), db.data_ptr()
+            njobs[0] = j + 1
+            return dW, db          # filled by the batched reduction at the end of backward
 
         def finish(i, nparts):
             """column sums of (G_i, G_i z_i) -> coefficients of layer i, d gamma_i, d beta_i."""
@@ -588,9 +598,8 @@ class _DecoderFn(torch.autograd.Function):
             Gs[4] = G5
             finish(4, n_data)
             w5 = conv_w[4]
-            dWy, db = wgrad(None, 4, 3)
+            dWy, db5 = wgrad(None, 4, 3)
             dWx, _ = wgrad(None, 4, None, _K1_PAD)
-            g_conv_w[4], g_conv_b[4] = torch.cat([dWx[:, :cin], dWy], 1).unsqueeze(-1), db
             need_dx = ctx.needs_input_grad[0]
             if need_dx:
                 # [M, x_cols]: when the caller passed the zero-padded input, the pad columns of its
@@ -608,10 +617,14 @@ class _DecoderFn(torch.autograd.Function):
                 data_grad(i, conv_w[i], Gs[i - 1], False, i - 1)
                 Gs[i] = None
             finish(0, n_data)
-            dW, db = wgrad(None, 0, None, _K1_PAD)
-            g_conv_w[0], g_conv_b[0] = dW[:, :cin].contiguous().unsqueeze(-1), db
+            dW0, db0 = wgrad(None, 0, None, _K1_PAD)
             if need_dx:
                 data_grad(0, conv_w[0], dx, True, None)
+        if njobs[0]:
+            _native.ganet_check(lib.ganet_wgrad_reduce_batch(njobs[0], jobs, st))
+        if heads:
+            g_conv_w[4], g_conv_b[4] = torch.cat([dWx[:, :cin], dWy], 1).unsqueeze(-1), db5
+            g_conv_w[0], g_conv_b[0] = dW0[:, :cin].contiguous().unsqueeze(-1), db0
         grads = []
         for i in range(nl):
             grads += [g_conv_w[i], g_conv_b[i], g_gamma[i], g_beta[i]]

@@ -105,6 +105,18 @@ int ganet_wgrad_act(int64_t M, int32_t N, int32_t K, const float* g, int64_t ldg
                     int64_t ldgz, const float* gcoef, const float* x, int64_t ldx,
                     const float* in_scale, const float* in_shift, float* dW, float* db,
                     void* workspace, size_t workspace_bytes, void* stream);
+/* dW == NULL above leaves the per-workgroup partial sums in `workspace` (which must then stay untouched);
+ * ganet_wgrad_reduce_batch finishes up to GANET_MAX_WGRAD_JOBS such calls with ONE launch (the decoder's
+ * backward has 15 weight gradients; their reductions are off the dependency chain). jobs: HOST array. */
+#define GANET_MAX_WGRAD_JOBS 16
+typedef struct GanetWgradJob {
+  const void* workspace;   /* as passed to ganet_wgrad_act */
+  int64_t M;
+  int32_t N, K;
+  float* dW;               /* [N,K] */
+  float* db;               /* [N] or NULL */
+} GanetWgradJob;
+int ganet_wgrad_reduce_batch(int32_t n_jobs, const GanetWgradJob* jobs, void* stream);
 
 /* ---- input-gradient side with the BatchNorm + softplus backward folded in (ganet_mlp_bwd.hip) ----
  * For a hidden layer with stored pre-activation z, u = scale z + shift, y = softplus(u):
