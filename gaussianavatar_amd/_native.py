@@ -143,7 +143,7 @@ _ganet = None
 GANET_SYMBOLS = ["ganet_linear_wgrad_workspace", "ganet_linear_wgrad", "ganet_bn_workspace",
                  "ganet_bn_act_fwd", "ganet_bn_act_bwd", "ganet_ssim_fwd", "ganet_ssim_bwd",
                  "ganet_mlp_stats_floats", "ganet_mlp_fwd", "ganet_mlp_stats",
-                 "ganet_wgrad_act_workspace", "ganet_wgrad_act", "ganet_wgrad_reduce_batch", "ganet_mlp_bwd_data_parts",
+                 "ganet_wgrad_act_workspace", "ganet_wgrad_act", "ganet_wgrad_reduce_batch", "ganet_adam_step", "ganet_mlp_bwd_data_parts",
                  "ganet_mlp_head_bwd_parts", "ganet_mlp_bwd_data", "ganet_mlp_head_bwd", "ganet_mlp_bwd_stats",
                  "ganet_decode_pack_fwd", "ganet_decode_pack_bwd", "ganet_mean_sq_fwd", "ganet_mean_sq_bwd", "ganet_weighted_sum_fwd", "ganet_weighted_sum_bwd", "ganet_upsample_cat_fwd", "ganet_upsample_cat_bwd", "ganet_profile_enable", "ganet_profile_count", "ganet_profile_read", "ganet_profile_kernel_name",
                  "ganet_last_error", "ganet_abi_version"]
@@ -153,6 +153,13 @@ class GanetWgradJob(ctypes.Structure):
     """include/ganet.h GanetWgradJob"""
     _fields_ = [("workspace", ctypes.c_void_p), ("M", ctypes.c_int64), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
                 ("dW", ctypes.c_void_p), ("db", ctypes.c_void_p)]
+
+
+class GanetAdamTensor(ctypes.Structure):
+    """include/ganet.h GanetAdamTensor"""
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p),
+                ("exp_avg_sq", ctypes.c_void_p), ("n", ctypes.c_int64), ("lr", ctypes.c_float),
+                ("bias_correction1", ctypes.c_float), ("bias_correction2", ctypes.c_float)]
 
 
 def ganet() -> ctypes.CDLL:
@@ -202,6 +209,8 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_decode_pack_bwd.argtypes = [c_int32, c_int64, c_int64, P, P, P, P, c_float, c_float, c_float, c_float, P, P, P, P, P, P, P]
         lib.ganet_wgrad_reduce_batch.restype = c_int
         lib.ganet_wgrad_reduce_batch.argtypes = [c_int32, P, P]
+        lib.ganet_adam_step.restype = c_int
+        lib.ganet_adam_step.argtypes = [c_int32, P, c_float, c_float, c_float, P]
         lib.ganet_mean_sq_fwd.restype = c_int
         lib.ganet_mean_sq_fwd.argtypes = [c_int64, P, c_float, P, P]
         lib.ganet_mean_sq_bwd.restype = c_int

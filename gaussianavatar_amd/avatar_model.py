@@ -230,9 +230,14 @@ class AvatarModel:
             groups = [{"params": self.net.parameters(), "lr": o.lr_net * 0.1},
                       {"params": self.pose_encoder.parameters(), "lr": o.lr_net}]
         # same update rule as the reference's torch.optim.Adam (model/avatar_model.py:152-161); on a HIP
-        # device the fused implementation applies it with one kernel per parameter group
-        fused_ok = self.geo_feature.is_cuda and os.environ.get("GA_FUSED_ADAM", "1") != "0"
-        self.optimizer = torch.optim.Adam(groups, fused=True) if fused_ok else torch.optim.Adam(groups)
+        # device it is applied to every tensor of every group with one launch (optim.Adam;
+        # GA_FUSED_ADAM=torch selects torch's fused implementation, =0 its default one)
+        mode = os.environ.get("GA_FUSED_ADAM", "1") if self.geo_feature.is_cuda else "0"
+        if mode == "1":
+            from .optim import Adam
+            self.optimizer = Adam(groups)
+        else:
+            self.optimizer = torch.optim.Adam(groups, fused=True) if mode == "torch" else torch.optim.Adam(groups)
         self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, o.sched_milestones, gamma=0.1)
 
     # ------------------------------------------------------------------ checkpoints

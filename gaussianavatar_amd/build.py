@@ -44,6 +44,7 @@ LIBS = {
         ("ganet_mlp_bwd.hip", []),
         ("ganet_pack.hip", []),
         ("ganet_upsample.hip", []),
+        ("ganet_optim.hip", []),
     ],
 }
 

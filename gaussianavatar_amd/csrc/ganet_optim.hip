@@ -1,0 +1,91 @@
+// ganet_optim.hip — the Adam update of every parameter tensor of the iteration in ONE launch.
+//
+// The reference steps torch.optim.Adam over the net's ~55 small tensors (+ the geometry feature map)
+// (/root/reference/model/avatar_model.py:152-161,264-266); torch's multi-tensor implementation needs
+// three launches of ~32 us for these 3 M elements. Here a table of (param, grad, exp_avg, exp_avg_sq,
+// size, step size, bias correction) rows travels as the kernel argument; a workgroup owns one
+// 4096-element chunk and finds its tensor with a scan over the table's chunk prefix (scalar loads).
+// Update rule (torch.optim.Adam, amsgrad off, weight decay off, maximize off):
+//   m = b1 m + (1 - b1) g ;  v = b2 v + (1 - b2) g^2 ;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+#include <cstdint>
+
+#include "ganet.h"
+#include "ganet_common.h"
+
+namespace ganet {
+
+namespace {
+
+constexpr int CHUNK = 4096;
+
+struct AdamTable {
+  float* p[GANET_MAX_ADAM_TENSORS];
+  const float* g[GANET_MAX_ADAM_TENSORS];
+  float* m[GANET_MAX_ADAM_TENSORS];
+  float* v[GANET_MAX_ADAM_TENSORS];
+  int chunk_end[GANET_MAX_ADAM_TENSORS];     // exclusive prefix of chunks, per tensor
+  int n[GANET_MAX_ADAM_TENSORS];
+  float step_size[GANET_MAX_ADAM_TENSORS];   // lr / bias_correction1
+  float inv_sqrt_bc2[GANET_MAX_ADAM_TENSORS];
+};
+
+__global__ void __launch_bounds__(256)
+adam_kernel(int nt, AdamTable t, float beta1, float beta2, float eps) {
+  const int c = blockIdx.x;
+  int k = 0;
+  while (k < nt - 1 && c >= t.chunk_end[k]) ++k;          // uniform: scalar loads and branches
+  const int first = k ? t.chunk_end[k - 1] : 0;
+  const int base = (c - first) * CHUNK;
+  const int n = t.n[k];
+  float* __restrict__ p = t.p[k];
+  const float* __restrict__ g = t.g[k];
+  float* __restrict__ m = t.m[k];
+  float* __restrict__ v = t.v[k];
+  const float ss = t.step_size[k], isb = t.inv_sqrt_bc2[k];
+#pragma unroll 4
+  for (int i = base + threadIdx.x; i < min(base + CHUNK, n); i += 256) {
+    const float gi = g[i];
+    const float mi = fmaf(beta1, m[i], (1.0f - beta1) * gi);
+    const float vi = fmaf(beta2, v[i], (1.0f - beta2) * gi * gi);
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= ss * (mi / (sqrtf(vi) * isb + eps));
+  }
+}
+
+}  // namespace
+
+}  // namespace ganet
+
+using namespace ganet;
+
+extern "C" {
+
+int ganet_adam_step(int32_t n_tensors, const GanetAdamTensor* tensors, float beta1, float beta2, float eps,
+                    void* stream_) {
+  if (n_tensors <= 0 || n_tensors > GANET_MAX_ADAM_TENSORS || !tensors) {
+    set_error("ganet_adam_step: invalid arguments (1 <= n_tensors <= %d)", GANET_MAX_ADAM_TENSORS);
+    return 1;
+  }
+  AdamTable t{};
+  int chunks = 0;
+  for (int k = 0; k < n_tensors; ++k) {
+    const GanetAdamTensor& q = tensors[k];
+    if (!q.param || !q.grad || !q.exp_avg || !q.exp_avg_sq || q.n <= 0 || q.n > (int64_t)1 << 30 ||
+        !(q.bias_correction1 > 0.f) || !(q.bias_correction2 > 0.f)) {
+      set_error("ganet_adam_step: tensor %d invalid", k);
+      return 1;
+    }
+    t.p[k] = q.param; t.g[k] = q.grad; t.m[k] = q.exp_avg; t.v[k] = q.exp_avg_sq;
+    t.n[k] = (int)q.n;
+    chunks += (int)((q.n + CHUNK - 1) / CHUNK);
+    t.chunk_end[k] = chunks;
+    t.step_size[k] = q.lr / q.bias_correction1;
+    t.inv_sqrt_bc2[k] = 1.0f / sqrtf(q.bias_correction2);
+  }
+  hipLaunchKernelGGL(adam_kernel, dim3(chunks), dim3(256), 0, static_cast<hipStream_t>(stream_), n_tensors, t,
+                     beta1, beta2, eps);
+  return check_hip(hipGetLastError(), "adam_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,107 @@
+"""`Adam` — torch.optim.Adam (the reference's optimiser, /root/reference/model/avatar_model.py:152-161)
+whose `step()` is ONE HIP launch over every parameter tensor of every group (ganet_adam_step,
+gaussianavatar_amd/csrc/ganet_optim.hip) instead of torch's per-group multi-tensor launches.
+
+Same hyper-parameters, same per-parameter state keys (`step`, `exp_avg`, `exp_avg_sq`) and therefore
+the same `state_dict()` layout: checkpoints written by either load into the other (`step` is kept as
+torch's default flavour keeps it, a float32 CPU scalar tensor; a device-side `step` from a fused-Adam
+checkpoint is accepted). Supported configuration = the one the reference uses: amsgrad, weight decay,
+maximize, capturable and differentiable off; float32 CUDA parameters with dense gradients.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import torch
+
+from . import _native
+
+
+class Adam(torch.optim.Adam):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, foreach=False,
+                         fused=False)
+        self._table = (_native.GanetAdamTensor * 64)()
+
+    def _group_step(self, group) -> int:
+        """Advance the group's step counter: one shared CPU tensor referenced from every parameter's
+        state (torch keeps one per parameter; they always agree)."""
+        shared = group.get("_shared_step")
+        if shared is None:
+            first = next((self.state[p]["step"] for p in group["params"] if "step" in self.state[p]), None)
+            shared = torch.tensor(float(first) if first is not None else 0.0, dtype=torch.float32)
+            group["_shared_step"] = shared
+        shared += 1
+        return int(shared)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _native.ganet()
+        table, n, stream = self._table, 0, None
+        flush_args = None
+        for group in self.param_groups:
+            params = [p for p in group["params"] if p.grad is not None]
+            if not params:
+                continue
+            if group["amsgrad"] or group["weight_decay"] != 0 or group["maximize"]:
+                raise RuntimeError("gaussianavatar_amd.optim.Adam: amsgrad / weight_decay / maximize are not supported")
+            beta1, beta2 = group["betas"]
+            args = (float(beta1), float(beta2), float(group["eps"]))
+            if flush_args is not None and args != flush_args and n:
+                _native.ganet_check(lib.ganet_adam_step(n, table, *flush_args, stream))
+                n = 0
+            flush_args = args
+            t = self._group_step(group)
+            shared = group["_shared_step"]
+            bc1, bc2 = 1.0 - beta1 ** t, 1.0 - beta2 ** t
+            lr = float(group["lr"])
+            for p in params:
+                g = p.grad
+                if g.is_sparse or not p.is_cuda or p.dtype != torch.float32:
+                    raise RuntimeError("gaussianavatar_amd.optim.Adam: dense float32 CUDA parameters only")
+                st = self.state[p]
+                if "exp_avg" not in st:
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] = shared
+                if not p.is_contiguous():
+                    raise RuntimeError("gaussianavatar_amd.optim.Adam: parameters must be contiguous")
+                if not g.is_contiguous():
+                    g = g.contiguous()
+                    p.grad = g
+                if stream is None:
+                    stream = torch.cuda.current_stream(p.device).cuda_stream
+                row = table[n]
+                row.param, row.grad = p.data_ptr(), g.data_ptr()
+                row.exp_avg, row.exp_avg_sq = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                row.n, row.lr, row.bias_correction1, row.bias_correction2 = p.numel(), lr, bc1, bc2
+                n += 1
+                if n == 64:
+                    _native.ganet_check(lib.ganet_adam_step(n, table, *args, stream))
+                    n = 0
+        if n:
+            _native.ganet_check(lib.ganet_adam_step(n, table, *flush_args, stream))
+        return loss
+
+    def state_dict(self):
+        sd = super().state_dict()
+        for g in sd["param_groups"]:
+            g.pop("_shared_step", None)
+        # one independent `step` tensor per parameter, as torch writes them
+        for st in sd["state"].values():
+            if "step" in st:
+                st["step"] = st["step"].detach().clone()
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for group in self.param_groups:
+            group.pop("_shared_step", None)
+        for st in self.state.values():
+            if "step" in st and torch.is_tensor(st["step"]):
+                st["step"] = st["step"].detach().to("cpu", torch.float32)

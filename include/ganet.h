@@ -173,6 +173,23 @@ int ganet_decode_pack_bwd(int32_t frames, int64_t HW, int64_t N, const float* re
 int ganet_mean_sq_fwd(int64_t n, const float* x, float norm, float* out, void* stream);
 int ganet_mean_sq_bwd(int64_t n, const float* x, float norm, const float* d_out, float* dx, void* stream);
 
+/* ---- Adam over a list of tensors in one launch (ganet_optim.hip): torch.optim.Adam's rule with amsgrad,
+ * weight decay and maximize off — m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ * p -= (lr / bias_correction1) * m / (sqrt(v) / sqrt(bias_correction2) + eps) — for the optimiser step of
+ * /root/reference/model/avatar_model.py:152-161,264-266. tensors: HOST array, n_tensors <=
+ * GANET_MAX_ADAM_TENSORS; all pointers device float32, n elements each, contiguous. */
+#define GANET_MAX_ADAM_TENSORS 64
+typedef struct GanetAdamTensor {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t n;
+  float lr, bias_correction1, bias_correction2;
+} GanetAdamTensor;
+int ganet_adam_step(int32_t n_tensors, const GanetAdamTensor* tensors, float beta1, float beta2, float eps,
+                    void* stream);
+
 /* out[0] = bias + sum_{i<n} weights[i] * terms[i][0]: the scalar objective of the training loop
  * (/root/reference/train.py:70-82) in one launch. terms: HOST array of n device pointers, weights: HOST
  * array, n <= GANET_MAX_TERMS. Backward: d_terms[i] = weights[i] * d_out[0] (d_out, d_terms on device). */

@@ -498,3 +498,56 @@ def test_upsample_cat_matches_grid_sample(b, feat, S):
     (x * w).sum().backward()
     (ref * w).sum().backward()
     torch.testing.assert_close(pix1.grad, pix2.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_one_launch_adam_matches_torch_adam():
+    """optim.Adam (ganet_adam_step) against torch.optim.Adam: two groups with different learning rates,
+    more tensors than one launch's table holds, a scheduler step in between, and state_dict interchange
+    in both directions."""
+    from gaussianavatar_amd.optim import Adam
+    torch.manual_seed(5)
+    shapes = [(128, 66, 1), (128,), (3, 128, 1), (1, 64, 33, 31), (7,)] + [(5, 3)] * 70
+    mk = lambda: [torch.nn.Parameter(torch.randn(*s, device="cuda")) for s in shapes]
+    pa = mk()
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    groups = lambda ps: [{"params": ps[:3], "lr": 3e-3}, {"params": ps[3:], "lr": 5e-4}]
+    oa, ob = Adam(groups(pa)), torch.optim.Adam(groups(pb))
+    sa = torch.optim.lr_scheduler.MultiStepLR(oa, [3], gamma=0.1)
+    sb = torch.optim.lr_scheduler.MultiStepLR(ob, [3], gamma=0.1)
+
+    def run(o, s, ps, steps, seed):
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        for _ in range(steps):
+            o.zero_grad()
+            for i, p in enumerate(ps):
+                if i != 4:                               # a parameter that never gets a gradient
+                    p.grad = torch.randn(p.shape, device="cuda", generator=g) * (1 + i % 3)
+            o.step()
+            s.step()
+
+    run(oa, sa, pa, 6, 1); run(ob, sb, pb, 6, 1)
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(a, b, rtol=2e-6, atol=2e-7)
+    assert torch.equal(pa[4], pb[4])
+    # interchange: continue each optimiser from the OTHER one's state
+    sda, sdb = oa.state_dict(), ob.state_dict()
+    assert set(sda["state"][0].keys()) == set(sdb["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+    assert float(sda["state"][0]["step"]) == float(sdb["state"][0]["step"]) == 6.0
+    oa2, ob2 = Adam(groups(pa)), torch.optim.Adam(groups(pb))
+    oa2.load_state_dict(sdb); ob2.load_state_dict(sda)
+    sa2 = torch.optim.lr_scheduler.MultiStepLR(oa2, [100]); sb2 = torch.optim.lr_scheduler.MultiStepLR(ob2, [100])
+    run(oa2, sa2, pa, 3, 2); run(ob2, sb2, pb, 3, 2)
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(a, b, rtol=4e-6, atol=4e-7)
+    assert float(oa2.state_dict()["state"][0]["step"]) == 9.0
+    # a fused-Adam checkpoint (device-side step tensors) loads too
+    of = torch.optim.Adam(groups(pb), fused=True)
+    for p in pb:
+        p.grad = torch.ones_like(p)
+    of.step()
+    oa3 = Adam(groups(pa))
+    oa3.load_state_dict(of.state_dict())
+    for p in pa:
+        p.grad = torch.ones_like(p)
+    oa3.step()
+    assert float(oa3.state_dict()["state"][0]["step"]) == 2.0
