@@ -203,14 +203,32 @@ int gsr_workspace_layout(int32_t P, int32_t W, int32_t H, int64_t max_pairs, Gsr
   return GSR_OK;
 }
 
-// hipMemset2DAsync is slow for large rows (65-200 us measured); frames are few, so clear them
-// one by one with the fast 1-D fill.
-static hipError_t memset_frames(void* base, size_t stride, size_t bytes, int frames, hipStream_t stream) {
-  for (int f = 0; f < frames; ++f) {
-    hipError_t e = hipMemsetAsync(static_cast<char*>(base) + (size_t)f * stride, 0, bytes, stream);
-    if (e != hipSuccess) return e;
-  }
-  return hipSuccess;
+// Clears up to two regions of every frame's workspace slice in ONE launch (hipMemset2DAsync is slow
+// for large rows, 65-200 us measured; a 1-D fill per frame and region is a launch each).
+// Regions are 16-byte aligned multiples of 4 bytes; blockIdx.y = frame.
+__global__ void __launch_bounds__(256)
+clear_frames_kernel(char* base, size_t stride, size_t off_a, size_t words_a, size_t off_b, size_t words_b) {
+  char* frame = base + (size_t)blockIdx.y * stride;
+  uint32_t* a = reinterpret_cast<uint32_t*>(frame + off_a);
+  uint32_t* b = reinterpret_cast<uint32_t*>(frame + off_b);
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t quads = words_a >> 2;
+  uint4* a4 = reinterpret_cast<uint4*>(a);
+  for (size_t i = t0; i < quads; i += step) a4[i] = make_uint4(0u, 0u, 0u, 0u);
+  for (size_t i = (quads << 2) + t0; i < words_a; i += step) a[i] = 0u;
+  for (size_t i = t0; i < words_b; i += step) b[i] = 0u;
+}
+
+static hipError_t clear_frames(void* base, size_t stride, int frames, hipStream_t stream, void* region_a,
+                               size_t bytes_a, void* region_b = nullptr, size_t bytes_b = 0) {
+  const size_t off_a = static_cast<char*>(region_a) - static_cast<char*>(base);
+  const size_t off_b = region_b ? static_cast<char*>(region_b) - static_cast<char*>(base) : 0;
+  const size_t quads = bytes_a / 16;
+  const int blocks = (int)((quads + 255) / 256 < 1024 ? (quads + 255) / 256 : 1024);
+  hipLaunchKernelGGL(clear_frames_kernel, dim3(blocks > 0 ? blocks : 1, frames), dim3(256), 0, stream,
+                     static_cast<char*>(base), stride, off_a, bytes_a / 4, off_b, bytes_b / 4);
+  return hipGetLastError();
 }
 
 static int make_batch(const GsrBatch* b, int32_t P, const GsrLayout& L, size_t workspace_bytes,
@@ -261,13 +279,11 @@ int gsr_forward_batch(const GsrSettings* s, const GsrBatch* batch, int32_t P, co
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const Dims d = make_dims(P, s->image_width, s->image_height, max_pairs);
   const Workspace ws = resolve(workspace, L);
-  // tile_count .. tile_cursor are contiguous in the layout: one (2-D) memset clears the
-  // histogram of every frame, a second one the status words
-  if ((rc = check_hip(memset_frames(ws.tile_count, bt.ws_stride, L.tile_cursor - L.tile_count,
-                                    bt.frames, stream), "memset tile_count")))
-    return rc;
-  if ((rc = check_hip(memset_frames(ws.status, bt.ws_stride, 8 * sizeof(int32_t), bt.frames, stream),
-                      "memset status")))
+  // tile_count .. tile_cursor are contiguous in the layout: one launch clears the histogram and the
+  // status words of every frame
+  if ((rc = check_hip(clear_frames(workspace, bt.ws_stride, bt.frames, stream, ws.tile_count,
+                                   L.tile_cursor - L.tile_count, ws.status, 8 * sizeof(int32_t)),
+                      "clear tile_count/status")))
     return rc;
   if ((rc = check_hip(launch_preprocess(*s, d, means3D, colors_precomp, opacities, scales,
                                         rotations, cov3D_precomp, ws, out_radii, bt, stream),
@@ -306,9 +322,9 @@ int gsr_backward_batch(const GsrSettings* s, const GsrBatch* batch, int32_t P, c
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const Dims d = make_dims(P, s->image_width, s->image_height, max_pairs);
   const Workspace ws = resolve(workspace, L);
-  if ((rc = check_hip(memset_frames(ws.grad_acc, bt.ws_stride,
-                                    (size_t)P * GSR_GRAD_STRIDE * sizeof(float), bt.frames, stream),
-                      "memset grad_acc")))
+  if ((rc = check_hip(clear_frames(workspace, bt.ws_stride, bt.frames, stream, ws.grad_acc,
+                                   (size_t)P * GSR_GRAD_STRIDE * sizeof(float)),
+                      "clear grad_acc")))
     return rc;
   if ((rc = check_hip(launch_render_bwd(*s, d, ws, dL_dout_color, bt, stream), "render_bwd")))
     return rc;
