@@ -141,8 +141,8 @@ def _cpu_model() -> str:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--points", type=int, default=200_000)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--frames-per-gpu", type=int, default=2)

@@ -186,19 +186,19 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_mlp_stats_floats.argtypes = [c_int32]
         lib.ganet_mlp_fwd.restype = c_int
         lib.ganet_mlp_fwd.argtypes = [c_int64, c_int32, c_int32, c_int32, P, c_int64, P, c_int64, P, P, P, P, P,
-                                      c_int64, P, P]
+                                      c_int64, P, c_int32, P]
         lib.ganet_mlp_stats.restype = c_int
         lib.ganet_mlp_stats.argtypes = [c_int64, c_int32, P, P, P, c_float, P, P, P, P, P, P, c_float, P, P]
         lib.ganet_wgrad_act_workspace.restype = c_size_t
         lib.ganet_wgrad_act_workspace.argtypes = [c_int64, c_int32, c_int32]
         lib.ganet_wgrad_act.restype = c_int
         lib.ganet_wgrad_act.argtypes = [c_int64, c_int32, c_int32, P, c_int64, P, c_int64, P, P, c_int64, P, P, P,
-                                        P, P, c_size_t, P]
+                                        P, P, c_size_t, c_int32, P]
         lib.ganet_mlp_bwd_data_parts.restype = c_int32
         lib.ganet_mlp_head_bwd_parts.restype = c_int32
         lib.ganet_mlp_bwd_data.restype = c_int
         lib.ganet_mlp_bwd_data.argtypes = [c_int64, c_int32, P, c_int64, P, c_int64, P, P, c_int64, P, c_int64, c_int32,
-                                           P, c_int64, P, P, P, P]
+                                           P, c_int64, P, P, P, c_int32, P]
         lib.ganet_mlp_head_bwd.restype = c_int
         lib.ganet_mlp_head_bwd.argtypes = [c_int64, c_int32, P, P, P, c_int64, P, P, P, c_int64, P, P]
         lib.ganet_mlp_bwd_stats.restype = c_int

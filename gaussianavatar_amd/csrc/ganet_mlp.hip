@@ -53,7 +53,7 @@ mlp_fwd_kernel(int64_t M, int N, const float* __restrict__ x1, int64_t ld1,
                const float* __restrict__ x2, int64_t ld2, const float* __restrict__ in_scale,
                const float* __restrict__ in_shift, const float* __restrict__ W,
                const float* __restrict__ bias, float* __restrict__ z, int64_t ldz,
-               float* __restrict__ col_part) {
+               float* __restrict__ col_part, int reverse) {
   constexpr int KB = K1B + K2B;         // k-blocks of 8
   constexpr int K = 8 * KB;
   constexpr int LDW4 = K / 4 + 1;       // row stride of W in LDS, in float4
@@ -107,8 +107,12 @@ mlp_fwd_kernel(int64_t M, int N, const float* __restrict__ x1, int64_t ld1,
   constexpr int D = (KB % 8 == 0) ? 8 : ((KB % 5 == 0) ? 5 : KB);
   static_assert(KB % D == 0, "ring depth must divide the number of k-blocks");
   const float *p1c = nullptr, *p2c = nullptr, *p1n = nullptr, *p2n = nullptr;
+  // reverse: the slabs are walked from the last row to the first (the caller alternates the direction
+  // from layer to layer so that a kernel starts on the rows the previous one touched last, which are
+  // the ones still resident in the 256 MiB Infinity Cache)
+  auto phys = [&](int64_t slab) { return reverse ? nslab - 1 - slab : slab; };
   auto point_at = [&](int64_t slab, const float*& q1, const float*& q2) {
-    const int64_t row = min(slab * SLAB + col, M - 1);
+    const int64_t row = min(phys(slab) * SLAB + col, M - 1);
     if (K1B > 0) q1 = x1 + row * ld1 + 4 * h;
     if (K2B > 0) q2 = x2 + row * ld2 + 4 * h;
   };
@@ -176,7 +180,7 @@ mlp_fwd_kernel(int64_t M, int N, const float* __restrict__ x1, int64_t ld1,
     p1c = p1n; p2c = p2n;
     // epilogue: + bias, store, column statistics. C/D layout of the 32x32 MFMA: column = lane & 31,
     // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const int64_t row0 = slab * SLAB;
+    const int64_t row0 = phys(slab) * SLAB;
     if (row0 + SLAB <= M && N == NP) {
       float* zr = z + (row0 + 4 * h) * ldz + col;
 #pragma unroll
@@ -297,7 +301,7 @@ wgrad_act_kernel(int64_t M, int N, int K, const float* __restrict__ g, int64_t l
                  const float* __restrict__ gz, int64_t ldgz, const float* __restrict__ gcoef,
                  const float* __restrict__ x, int64_t ldx, const float* __restrict__ in_scale,
                  const float* __restrict__ in_shift, float* __restrict__ partial,
-                 int64_t rows_per_wave) {
+                 int64_t rows_per_wave, int order) {
   constexpr int NP = NTW * 32, KP = KTW * 32;
   extern __shared__ float s_tile[];            // 2 x [NP][KP] + 2 x [NP] (bias)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -429,13 +433,26 @@ wgrad_act_kernel(int64_t M, int N, int K, const float* __restrict__ g, int64_t l
       }
     };
     Group qa, qb;
-    load_fast(qa, r0);
-    for (int64_t m = r0; m < r1; m += 4 * UNROLL) {
+    // Which rows this wave reduces is free (any partition of the M rows works). order 0: one contiguous
+    // range per wave. order 1 / 2 (M = rows_per_wave x waves exactly): the waves sweep the rows as a
+    // common front of 16-row chunks, first-to-last (1) or last-to-first (2) — like the forward and
+    // data-gradient kernels, so that the kernel before / after it meets its rows in the Infinity Cache.
+    const int64_t wave_global = (int64_t)blockIdx.x * (WG_W / 64) + wave;
+    const int64_t total_waves = (int64_t)gridDim.x * (WG_W / 64);
+    const int64_t iters = rows_per_wave / (4 * UNROLL);
+    const bool front = order != 0 && rows_per_wave * total_waves == M;
+    auto chunk = [&](int64_t t) {
+      if (!front) return r0 + t * (4 * UNROLL);
+      return ((order == 2 ? iters - 1 - t : t) * total_waves + wave_global) * (4 * UNROLL);
+    };
+    load_fast(qa, chunk(0));
+    for (int64_t t = 0; t < iters; ++t) {
+      const int64_t m = chunk(t);
       load_fast(qb, m + 2 * UNROLL);
       __builtin_amdgcn_sched_barrier(0);
       compute_fast(qa);
       __builtin_amdgcn_sched_barrier(0);
-      load_fast(qa, m + 4 * UNROLL);
+      load_fast(qa, t + 1 < iters ? chunk(t + 1) : m);
       __builtin_amdgcn_sched_barrier(0);
       compute_fast(qb);
       __builtin_amdgcn_sched_barrier(0);
@@ -599,7 +616,7 @@ size_t ganet_mlp_stats_floats(int32_t N) {
 int ganet_mlp_fwd(int64_t M, int32_t N, int32_t K1, int32_t K2, const float* x1, int64_t ld1,
                   const float* x2, int64_t ld2, const float* in_scale, const float* in_shift,
                   const float* W, const float* bias, float* z, int64_t ldz, float* col_part,
-                  void* stream_) {
+                  int32_t row_order, void* stream_) {
   const bool bad_x1 = K1 > 0 && (!x1 || (ld1 % 4) != 0 || ld1 < K1 || !aligned16(x1));
   const bool bad_x2 = K2 > 0 && (!x2 || (ld2 % 4) != 0 || ld2 < K2 || !aligned16(x2) || !in_scale ||
                                  !in_shift || !aligned16(in_scale) || !aligned16(in_shift));
@@ -625,7 +642,7 @@ int ganet_mlp_fwd(int64_t M, int32_t N, int32_t K1, int32_t K2, const float* x1,
     }                                                                                              \
     ProfScope prof_(K_MLP_FWD, stream);                                                            \
     hipLaunchKernelGGL((mlp_fwd_kernel<A, B, T>), grid, block, lds, stream, M, N, x1, ld1, x2, ld2, \
-                       in_scale, in_shift, W, bias, z, ldz, col_part);                             \
+                       in_scale, in_shift, W, bias, z, ldz, col_part, row_order == 2 ? 1 : 0);     \
   } while (0)
   // the decoder's shapes: input layer (K1 = 72 = 66 padded), hidden layers (K2 = 128), the skip
   // layer (72 + 128) and the 3/1/3-column output heads (one 32-column tile)
@@ -669,7 +686,7 @@ size_t ganet_wgrad_act_workspace(int64_t M, int32_t N, int32_t K) {
 int ganet_wgrad_act(int64_t M, int32_t N, int32_t K, const float* g, int64_t ldg, const float* gz,
                     int64_t ldgz, const float* gcoef, const float* x, int64_t ldx,
                     const float* in_scale, const float* in_shift, float* dW, float* db,
-                    void* workspace, size_t workspace_bytes, void* stream_) {
+                    void* workspace, size_t workspace_bytes, int32_t row_order, void* stream_) {
   if (M <= 0 || N <= 0 || K <= 0 || !g || !x || ((in_scale == nullptr) != (in_shift == nullptr)) ||
       ((gz == nullptr) != (gcoef == nullptr)) || (gz && ldgz < N) || ldg < N || ldx < K) {
     set_error("ganet_wgrad_act: invalid arguments");
@@ -704,7 +721,7 @@ int ganet_wgrad_act(int64_t M, int32_t N, int32_t K, const float* g, int64_t ldg
     }                                                                                              \
     ProfScope prof_(K_WGRAD, stream);                                                              \
     hipLaunchKernelGGL((wgrad_act_kernel<T, KT_, A, G>), grid, block, lds, stream, M, N, K, g, ldg, \
-                       gz, ldgz, gcoef, x, ldx, in_scale, in_shift, partial, rpw);                 \
+                       gz, ldgz, gcoef, x, ldx, in_scale, in_shift, partial, rpw, row_order);      \
   } while (0)
   // instantiated: the decoder's cases (+ the raw-g variants used by tests / generic callers)
   if (nt == 4 && kt == 4 && act && gpro) LAUNCH(4, 4, true, true);

@@ -41,7 +41,7 @@ mlp_bwd_kernel(int64_t M, int O, const float* __restrict__ g, int64_t ldg,
                const float* __restrict__ gz, int64_t ldgz, const float* __restrict__ gcoef,
                const float* __restrict__ W, int64_t ldw, float* __restrict__ out, int64_t ldo,
                const float* __restrict__ src_z, int64_t ld_src, const float* __restrict__ src_scale,
-               const float* __restrict__ src_shift, float* __restrict__ col_part) {
+               const float* __restrict__ src_shift, float* __restrict__ col_part, int reverse) {
   constexpr int KB = 16, K = 128;
   constexpr int LDW4 = K / 4 + 1;
   constexpr int NP = NT * 32;
@@ -94,8 +94,9 @@ mlp_bwd_kernel(int64_t M, int O, const float* __restrict__ g, int64_t ldg,
   const int64_t wave_stride = (int64_t)gridDim.x * WAVES;
 
   const float *pgc, *pzc, *pgn, *pzn;
+  auto phys = [&](int64_t slab) { return reverse ? nslab - 1 - slab : slab; };   // see mlp_fwd_kernel
   auto point_at = [&](int64_t slab, const float*& qg, const float*& qz) {
-    const int64_t row = min(slab * SLAB + col, M - 1);
+    const int64_t row = min(phys(slab) * SLAB + col, M - 1);
     qg = g + row * ldg + 4 * h;
     qz = gz + row * ldgz + 4 * h;
   };
@@ -149,7 +150,7 @@ mlp_bwd_kernel(int64_t M, int O, const float* __restrict__ g, int64_t ldg,
     }
     pgc = pgn; pzc = pzn;
     // epilogue. C/D layout: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const int64_t row0 = slab * SLAB;
+    const int64_t row0 = phys(slab) * SLAB;
     const bool full = row0 + SLAB <= M && O == NP;
     // The source layer's pre-activations are not cached: issue the loads of ALL tiles before the
     // first use, so that a slab pays one memory latency instead of one per tile.
@@ -306,6 +307,9 @@ bwd_stats_kernel(int nparts, int64_t M, const float* __restrict__ col_part,
 
 using namespace ganet;
 
+int g_reverse_bwd = 0;      // EXPERIMENT
+extern "C" void ganet_dev_set_reverse_bwd(int r) { g_reverse_bwd = r; }
+
 extern "C" {
 
 int32_t ganet_mlp_bwd_data_parts(void) { return BWD_BLOCKS; }
@@ -315,7 +319,7 @@ int ganet_mlp_bwd_data(int64_t M, int32_t O, const float* g, int64_t ldg, const 
                        const float* gcoef, const float* W, int64_t ldw, float* out, int64_t ldo,
                        int32_t accumulate,
                        const float* src_z, int64_t ld_src, const float* src_scale,
-                       const float* src_shift, float* col_part, void* stream_) {
+                       const float* src_shift, float* col_part, int32_t row_order, void* stream_) {
   const bool sig = src_z != nullptr;
   if (M <= 0 || O <= 0 || O > 128 || !g || !gz || !gcoef || !W || ldw < O || !out || ldo < O || (ldg % 4) ||
       (ldgz % 4) || ldg < 128 || ldgz < 128 || !aligned16(g) || !aligned16(gz) || !aligned16(gcoef) ||
@@ -338,7 +342,8 @@ int ganet_mlp_bwd_data(int64_t M, int32_t O, const float* g, int64_t ldg, const 
     }                                                                                              \
     ProfScope prof_(K_BWD_DATA, stream);                                                           \
     hipLaunchKernelGGL((mlp_bwd_kernel<T, AC, SG>), grid, block, lds, stream, M, O, g, ldg, gz, ldgz, \
-                       gcoef, W, ldw, out, ldo, src_z, ld_src, src_scale, src_shift, col_part);    \
+                       gcoef, W, ldw, out, ldo, src_z, ld_src, src_scale, src_shift, col_part,     \
+                       g_reverse_bwd);                                                             \
   } while (0)
   const bool acc = accumulate != 0;
   if (nt == 4 && !acc && sig) LAUNCH(4, false, true);

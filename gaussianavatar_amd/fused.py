@@ -8,6 +8,7 @@ exercise), so the two formulations are checked against each other on the GPU box
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 import torch.nn.functional as F
@@ -410,13 +411,30 @@ def _decoder_bn_layers():
     return out
 
 
-def _mlp_fwd(lib, M, N, x1, x2, scale, shift, W, bias, col_part, dev):
+class _RowSweep:
+    """Alternates GANET_ROWS_UP / GANET_ROWS_DOWN between consecutive big launches of a pass (include/ganet.h:
+    each kernel starts on the rows its predecessor touched last, which are still in the Infinity Cache).
+    GA_ROW_SWEEP=0 keeps every kernel's default order (A/B switch)."""
+    enabled = os.environ.get("GA_ROW_SWEEP", "1") != "0"
+
+    def __init__(self):
+        self.k = 0
+
+    def next(self) -> int:
+        if not self.enabled:
+            return 0
+        self.k += 1
+        return 1 if self.k % 2 else 2
+
+
+def _mlp_fwd(lib, M, N, x1, x2, scale, shift, W, bias, col_part, dev, row_order=0):
     z = torch.empty((M, N), dtype=torch.float32, device=dev)
     K1 = 0 if x1 is None else x1.shape[1]
     K2 = 0 if x2 is None else x2.shape[1]
     _native.ganet_check(lib.ganet_mlp_fwd(
         M, N, K1, K2, _ptr(x1), 0 if x1 is None else x1.stride(0), _ptr(x2), 0 if x2 is None else x2.stride(0),
-        _ptr(scale), _ptr(shift), _ptr(W), _ptr(bias), _ptr(z), z.stride(0), _ptr(col_part), _stream(dev)))
+        _ptr(scale), _ptr(shift), _ptr(W), _ptr(bias), _ptr(z), z.stride(0), _ptr(col_part), row_order,
+        _stream(dev)))
     return z
 
 
@@ -449,6 +467,7 @@ class _DecoderFn(torch.autograd.Function):
         col_part = torch.empty(lib.ganet_mlp_stats_floats(128), dtype=torch.float32, device=dev) if training else None
 
         zs, stats = [], []            # per BN layer: pre-activation, (mean, rstd, scale, shift)
+        sweep = _RowSweep()
 
         def bn_stats(i, z):
             bn = getattr(dec, layers[i][1])
@@ -472,7 +491,7 @@ class _DecoderFn(torch.autograd.Function):
             x2 = sc = sh = None
             if src is not None:
                 x2, (_, _, sc, sh) = zs[src], stats[src]
-            z = _mlp_fwd(lib, M, 128, x1, x2, sc, sh, W, conv_b[i], col_part, dev)
+            z = _mlp_fwd(lib, M, 128, x1, x2, sc, sh, W, conv_b[i], col_part, dev, sweep.next())
             zs.append(z)
             stats.append(bn_stats(i, z))
 
@@ -490,7 +509,7 @@ class _DecoderFn(torch.autograd.Function):
             hidden(i7, None, conv_w[i7].contiguous(), i6)
             _, _, sc, sh = stats[i7]
             outs.append(_mlp_fwd(lib, M, out_w[j].shape[0], None, zs[i7], sc, sh, out_w[j].contiguous(),
-                                 out_b[j], None, dev))
+                                 out_b[j], None, dev, sweep.next()))
         ctx.dec = dec
         ctx.cin = cin
         ctx.nl = nl
@@ -525,6 +544,7 @@ class _DecoderFn(torch.autograd.Function):
         wg_ws = torch.empty(wg_bytes * max_jobs, dtype=torch.uint8, device=dev)
         jobs = (_native.GanetWgradJob * max_jobs)()
         njobs = [0]
+        sweep = _RowSweep()
         n_data, n_head = lib.ganet_mlp_bwd_data_parts(), lib.ganet_mlp_head_bwd_parts()
         col_part = torch.empty(max(n_data, n_head) * 256, dtype=torch.float32, device=dev)
         f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
@@ -543,7 +563,7 @@ class _DecoderFn(torch.autograd.Function):
             ws = wg_ws.data_ptr() + j * wg_bytes
             _native.ganet_check(lib.ganet_wgrad_act(
                 M, N, K, _ptr(gt), gt.stride(0), _ptr(gz), 0 if gz is None else gz.stride(0), _ptr(coef),
-                _ptr(x), x.stride(0), _ptr(sc), _ptr(sh), None, None, ws, wg_bytes, st))
+                _ptr(x), x.stride(0), _ptr(sc), _ptr(sh), None, None, ws, wg_bytes, sweep.next(), st))
             jobs[j].workspace, jobs[j].M, jobs[j].N, jobs[j].K = ws, M, N, K
             jobs[j].dW, jobs[j].db = dW.data_ptr(), db.data_ptr()
             njobs[0] = j + 1
@@ -566,7 +586,7 @@ class _DecoderFn(torch.autograd.Function):
             _native.ganet_check(lib.ganet_mlp_bwd_data(
                 M, O, _ptr(Gs[gi]), Gs[gi].stride(0), _ptr(zs[gi]), zs[gi].stride(0), _ptr(coefs[gi]), _ptr(W),
                 W.stride(0), _ptr(out), out.stride(0), int(accumulate), _ptr(sz), 0 if sz is None else sz.stride(0),
-                _ptr(sc), _ptr(sh), _ptr(col_part) if src is not None else None, st))
+                _ptr(sc), _ptr(sh), _ptr(col_part) if src is not None else None, sweep.next(), st))
 
         Gs, coefs = [None] * nl, [None] * nl
         heads = [j for j in range(3) if d_outs[j] is not None]

@@ -88,11 +88,22 @@ int ganet_ssim_bwd(int32_t planes, int32_t H, int32_t W, const float* img1, cons
  * NEXT layer's prologue, and updates the running statistics like F.batch_norm(training=True).
  * ganet_wgrad_act is the matching weight gradient: dW[n,k] = sum_m g[m,n] softplus(in_scale_k
  * x[m,k] + in_shift_k), db[n] = sum_m g[m,n] (N, K <= 128). */
+/* row_order (ganet_mlp_fwd, ganet_wgrad_act, ganet_mlp_bwd_data): the M rows are independent work, so
+ * the order in which the chip sweeps them is free. GANET_ROWS_DEFAULT: the kernel's natural order (forward
+ * / data gradient: a common front over all workgroups from row 0 up; weight gradient: one contiguous
+ * range per wave). GANET_ROWS_UP / GANET_ROWS_DOWN: a common front first-to-last / last-to-first. A
+ * caller that alternates UP and DOWN between consecutive launches over the same activations lets each
+ * kernel start on the rows the previous one touched last, which the 256 MiB Infinity Cache still holds
+ * (4-5 % per launch measured on the decoder's layers). Results do not depend on it beyond the
+ * summation order of the weight gradient / column statistics. */
+#define GANET_ROWS_DEFAULT 0
+#define GANET_ROWS_UP 1
+#define GANET_ROWS_DOWN 2
 size_t ganet_mlp_stats_floats(int32_t N);
 int ganet_mlp_fwd(int64_t M, int32_t N, int32_t K1, int32_t K2, const float* x1, int64_t ld1,
                   const float* x2, int64_t ld2, const float* in_scale, const float* in_shift,
                   const float* W, const float* bias, float* z, int64_t ldz, float* col_part,
-                  void* stream);
+                  int32_t row_order, void* stream);
 int ganet_mlp_stats(int64_t M, int32_t N, const float* col_part, const float* gamma,
                     const float* beta, float eps, float* mean, float* rstd, float* scale,
                     float* shift, float* running_mean, float* running_var, float momentum,
@@ -104,7 +115,7 @@ size_t ganet_wgrad_act_workspace(int64_t M, int32_t N, int32_t K);
 int ganet_wgrad_act(int64_t M, int32_t N, int32_t K, const float* g, int64_t ldg, const float* gz,
                     int64_t ldgz, const float* gcoef, const float* x, int64_t ldx,
                     const float* in_scale, const float* in_shift, float* dW, float* db,
-                    void* workspace, size_t workspace_bytes, void* stream);
+                    void* workspace, size_t workspace_bytes, int32_t row_order, void* stream);
 /* dW == NULL above leaves the per-workgroup partial sums in `workspace` (which must then stay untouched);
  * ganet_wgrad_reduce_batch finishes up to GANET_MAX_WGRAD_JOBS such calls with ONE launch (the decoder's
  * backward has 15 weight gradients; their reductions are off the dependency chain). jobs: HOST array. */
@@ -136,7 +147,7 @@ int ganet_mlp_bwd_data(int64_t M, int32_t O, const float* g, int64_t ldg, const 
                        const float* gcoef, const float* W, int64_t ldw, float* out, int64_t ldo,
                        int32_t accumulate,
                        const float* src_z, int64_t ld_src, const float* src_scale,
-                       const float* src_shift, float* col_part, void* stream);
+                       const float* src_shift, float* col_part, int32_t row_order, void* stream);
 int ganet_mlp_head_bwd(int64_t M, int32_t N8, const float* g, const float* W8, const float* z,
                        int64_t ldz, const float* scale, const float* shift, float* G, int64_t ldG,
                        float* col_part, void* stream);

@@ -165,9 +165,10 @@ def _softplus_bn(z, sc, sh):
     return F.softplus(z.double() * sc.double() + sh.double())
 
 
+@pytest.mark.parametrize("row_order", [0, 2])          # GANET_ROWS_DEFAULT / GANET_ROWS_DOWN
 @pytest.mark.parametrize("M,K1,K2,N", [(262144, 0, 128, 128), (40000, 72, 0, 128), (33333, 72, 128, 128),
                                        (70001, 0, 128, 3), (4100, 0, 128, 1), (31, 0, 128, 128)])
-def test_mlp_fwd_layer_matches_torch(M, K1, K2, N):
+def test_mlp_fwd_layer_matches_torch(M, K1, K2, N, row_order):
     """ganet_mlp_fwd: activation-on-load GEMM + column statistics, incl. ragged M (tail slab),
     the skip layer's two operands and the narrow output heads."""
     from gaussianavatar_amd import _native, fused
@@ -181,7 +182,7 @@ def test_mlp_fwd_layer_matches_torch(M, K1, K2, N):
     W = torch.randn(N, K1 + K2, device=dev) * 0.1
     b = torch.randn(N, device=dev)
     part = torch.zeros(lib.ganet_mlp_stats_floats(N), device=dev)
-    z = fused._mlp_fwd(lib, M, N, x1, x2, sc, sh, W, b, part, dev)
+    z = fused._mlp_fwd(lib, M, N, x1, x2, sc, sh, W, b, part, dev, row_order)
     cols = []
     if K1:
         cols.append(x1.double())
@@ -213,10 +214,11 @@ def test_mlp_fwd_layer_matches_torch(M, K1, K2, N):
         assert int(nbt) == int(bn.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("row_order", [0, 1, 2])       # contiguous ranges / common front up / down
 @pytest.mark.parametrize("M,N,K,act", [(262144, 128, 128, True), (50001, 128, 128, True), (70001, 3, 128, True),
                                          (4097, 1, 128, True), (40000, 128, 72, False), (15, 128, 128, True),
                                          (3000, 20, 70, False)])
-def test_wgrad_act_matches_torch(M, N, K, act):
+def test_wgrad_act_matches_torch(M, N, K, act, row_order):
     from gaussianavatar_amd import _native, fused
     lib = _native.ganet()
     torch.manual_seed(N + M % 13)
@@ -238,7 +240,7 @@ def test_wgrad_act_matches_torch(M, N, K, act):
     _native.ganet_check(lib.ganet_wgrad_act(M, N, K, fused._ptr(g), g.stride(0), fused._ptr(gz),
                                             0 if gz is None else gz.stride(0), fused._ptr(coef), fused._ptr(x),
                                             x.stride(0), fused._ptr(sc), fused._ptr(sh), fused._ptr(dW), fused._ptr(db),
-                                            fused._ptr(ws), nbytes, fused._stream(torch.device(dev))))
+                                            fused._ptr(ws), nbytes, row_order, fused._stream(torch.device(dev))))
     g = gd
     ref = g.double().t() @ (_softplus_bn(x, sc, sh) if act else x.double())
     assert float((dW.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-4
@@ -292,10 +294,11 @@ def test_fused_decoder_equals_per_layer_formulation(M, monkeypatch):
         torch.testing.assert_close(a, b, rtol=1e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize("row_order", [0, 2])
 @pytest.mark.parametrize("M,O,accumulate,sig", [(262144, 128, False, True), (33001, 128, True, True),
                                                 (20000, 128, False, False), (20011, 128, True, False),
                                                 (40000, 72, False, False), (4099, 72, True, False), (17, 128, False, True)])
-def test_mlp_bwd_data_matches_torch(M, O, accumulate, sig):
+def test_mlp_bwd_data_matches_torch(M, O, accumulate, sig, row_order):
     """ganet_mlp_bwd_data: dz assembled on load from (G, z, coef), times W, optional accumulate, optional
     softplus' epilogue of the source layer with its column sums."""
     from gaussianavatar_amd import _native, fused
@@ -318,7 +321,7 @@ def test_mlp_bwd_data_matches_torch(M, O, accumulate, sig):
                                                fused._ptr(Wfull[:, 3:]), Wfull.stride(0), fused._ptr(out), O,
                                                int(accumulate), fused._ptr(src_z),
                                                O if sig else 0, fused._ptr(sc), fused._ptr(sh),
-                                               fused._ptr(part) if sig else None, fused._stream(dev)))
+                                               fused._ptr(part) if sig else None, row_order, fused._stream(dev)))
     dz = coef[0].double() * G.double() + coef[1].double() * z.double() + coef[2].double()
     ref = dz @ Wt.double().t()
     if accumulate:

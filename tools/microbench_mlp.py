@@ -46,15 +46,15 @@ def main():
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
     st = fused._stream(dev)
     P = fused._ptr
-    f = lambda: lib.ganet_wgrad_act(M, 128, 128, P(g), 128, None, 0, None, P(z), 128, P(sc), P(sh), P(dW), P(db), P(ws), nb, st)
+    f = lambda: lib.ganet_wgrad_act(M, 128, 128, P(g), 128, None, 0, None, P(z), 128, P(sc), P(sh), P(dW), P(db), P(ws), nb, 0, st)
     print("wgrad_act raw g            %7.1f us" % timeit(f))
-    f = lambda: lib.ganet_wgrad_act(M, 128, 128, P(g), 128, P(gz), 128, P(coef), P(z), 128, P(sc), P(sh), P(dW), P(db), P(ws), nb, st)
+    f = lambda: lib.ganet_wgrad_act(M, 128, 128, P(g), 128, P(gz), 128, P(coef), P(z), 128, P(sc), P(sh), P(dW), P(db), P(ws), nb, 0, st)
     print("wgrad_act (G,z,coef)       %7.1f us" % timeit(f))
     out = torch.empty(M, 128, device=dev)
     part = torch.zeros(lib.ganet_mlp_bwd_data_parts() * 256, device=dev)
-    f = lambda: lib.ganet_mlp_bwd_data(M, 128, P(g), 128, P(gz), 128, P(coef), P(W), 128, P(out), 128, 0, P(z), 128, P(sc), P(sh), P(part), st)
+    f = lambda: lib.ganet_mlp_bwd_data(M, 128, P(g), 128, P(gz), 128, P(coef), P(W), 128, P(out), 128, 0, P(z), 128, P(sc), P(sh), P(part), 0, st)
     print("mlp_bwd_data sig           %7.1f us" % timeit(f))
-    f = lambda: lib.ganet_mlp_bwd_data(M, 128, P(g), 128, P(gz), 128, P(coef), P(W), 128, P(out), 128, 0, None, 0, None, None, None, st)
+    f = lambda: lib.ganet_mlp_bwd_data(M, 128, P(g), 128, P(gz), 128, P(coef), P(W), 128, P(out), 128, 0, None, 0, None, None, None, 0, st)
     print("mlp_bwd_data raw           %7.1f us" % timeit(f))
     bn = torch.nn.BatchNorm1d(128).cuda().train()
     print("bn+softplus fwd            %7.1f us" % timeit(lambda: fused.batchnorm_act(z, bn, "softplus")))

@@ -17,6 +17,6 @@ for M in MS:
     nb = lib.ganet_wgrad_act_workspace(M, 128, 128); ws = torch.empty(nb, dtype=torch.uint8, device=dev)
     bpart = torch.zeros(lib.ganet_mlp_bwd_data_parts() * 256, device=dev)
     t1 = timeit(lambda: fused._mlp_fwd(lib, M, 128, None, z, sc, sh, W, b, part, dev))
-    t2 = timeit(lambda: lib.ganet_wgrad_act(M, 128, 128, P(g), 128, P(z), 128, P(coef), P(z), 128, P(sc), P(sh), P(dW), P(db), P(ws), nb, st))
-    t3 = timeit(lambda: lib.ganet_mlp_bwd_data(M, 128, P(g), 128, P(z), 128, P(coef), P(W), 128, P(out), 128, 0, P(z), 128, P(sc), P(sh), P(bpart), st))
+    t2 = timeit(lambda: lib.ganet_wgrad_act(M, 128, 128, P(g), 128, P(z), 128, P(coef), P(z), 128, P(sc), P(sh), P(dW), P(db), P(ws), nb, 0, st))
+    t3 = timeit(lambda: lib.ganet_mlp_bwd_data(M, 128, P(g), 128, P(z), 128, P(coef), P(W), 128, P(out), 128, 0, P(z), 128, P(sc), P(sh), P(bpart), 0, st))
     print(f"M={M:7d}  mlp_fwd {t1:7.1f}  wgrad_act {t2:7.1f}  bwd_data(sig) {t3:7.1f} us")
