@@ -152,7 +152,7 @@ GANET_SYMBOLS = ["ganet_linear_wgrad_workspace", "ganet_linear_wgrad", "ganet_bn
 class GanetWgradJob(ctypes.Structure):
     """include/ganet.h GanetWgradJob"""
     _fields_ = [("workspace", ctypes.c_void_p), ("M", ctypes.c_int64), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
-                ("dW", ctypes.c_void_p), ("db", ctypes.c_void_p)]
+                ("dW", ctypes.c_void_p), ("db", ctypes.c_void_p), ("nblocks", ctypes.c_int32)]
 
 
 class GanetAdamTensor(ctypes.Structure):
@@ -200,7 +200,7 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_mlp_bwd_data.argtypes = [c_int64, c_int32, P, c_int64, P, c_int64, P, P, c_int64, P, c_int64, c_int32,
                                            P, c_int64, P, P, P, c_int32, P]
         lib.ganet_mlp_head_bwd.restype = c_int
-        lib.ganet_mlp_head_bwd.argtypes = [c_int64, c_int32, P, P, P, c_int64, P, P, P, c_int64, P, P]
+        lib.ganet_mlp_head_bwd.argtypes = [c_int64, c_int32, P, P, P, c_int64, P, P, P, c_int64, P, P, P]
         lib.ganet_mlp_bwd_stats.restype = c_int
         lib.ganet_mlp_bwd_stats.argtypes = [c_int64, c_int32, P, P, P, P, P, P, P, P]
         lib.ganet_decode_pack_fwd.restype = c_int

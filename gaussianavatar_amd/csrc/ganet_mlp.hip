@@ -761,7 +761,7 @@ int ganet_wgrad_reduce_batch(int32_t n_jobs, const GanetWgradJob* jobs, void* st
       return 1;
     }
     int64_t rpw;
-    r.nblocks[j] = plan_wgrad(q.M, &rpw);
+    r.nblocks[j] = q.nblocks > 0 ? q.nblocks : plan_wgrad(q.M, &rpw);
     r.partial[j] = static_cast<const float*>(q.workspace);
     r.dW[j] = q.dW; r.db[j] = q.db; r.N[j] = q.N; r.K[j] = q.K;
     const int total = q.N * q.K + q.N;

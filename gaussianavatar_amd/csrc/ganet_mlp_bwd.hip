@@ -218,11 +218,15 @@ mlp_bwd_kernel(int64_t M, int O, const float* __restrict__ g, int64_t ldg,
 
 // Output heads (conv8*, N8 <= 4 columns): G[m,k] = (sum_n g[m,n] W8[n,k]) softplus'(scale_k z[m,k] +
 // shift_k) for the 128 columns of the head's last hidden layer, plus the two column sums.
+// WG: the head's own weight gradient rides along (it needs the same g and z rows): per-workgroup
+// partial sums of dW8[n,k] = sum_m g[m,n] softplus(u[m,k]) and db8[n] = sum_m g[m,n], in the layout of
+// ganet_wgrad_act's workspace ([block][N8*128 + N8]) for ganet_wgrad_reduce_batch.
+template <bool WG>
 __global__ void __launch_bounds__(256)
 head_bwd_kernel(int64_t M, int N8, const float* __restrict__ g, const float* __restrict__ W8,
                 const float* __restrict__ z, int64_t ldz, const float* __restrict__ scale,
                 const float* __restrict__ shift, float* __restrict__ G, int64_t ldG,
-                float* __restrict__ col_part) {
+                float* __restrict__ col_part, float* __restrict__ wgrad_part) {
   __shared__ float4 s_red[2][8][32];
   const int cg = threadIdx.x & 31, rsub = threadIdx.x >> 5;
   float4 w[4];
@@ -234,6 +238,10 @@ head_bwd_kernel(int64_t M, int N8, const float* __restrict__ g, const float* __r
   sc.x *= kLog2e; sc.y *= kLog2e; sc.z *= kLog2e; sc.w *= kLog2e;
   sh.x *= kLog2e; sh.y *= kLog2e; sh.z *= kLog2e; sh.w *= kLog2e;
   float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sgz = sg;
+  float4 dw[WG ? 4 : 1];
+  float dbv[WG ? 4 : 1];
+#pragma unroll
+  for (int n = 0; n < (WG ? 4 : 1); ++n) { dw[n] = make_float4(0.f, 0.f, 0.f, 0.f); dbv[n] = 0.f; }
   for (int64_t row = (int64_t)blockIdx.x * 8 + rsub; row < M; row += (int64_t)gridDim.x * 8) {
     float gv[4];
 #pragma unroll
@@ -244,10 +252,31 @@ head_bwd_kernel(int64_t M, int N8, const float* __restrict__ g, const float* __r
     d.y = gv[0] * w[0].y + gv[1] * w[1].y + gv[2] * w[2].y + gv[3] * w[3].y;
     d.z = gv[0] * w[0].z + gv[1] * w[1].z + gv[2] * w[2].z + gv[3] * w[3].z;
     d.w = gv[0] * w[0].w + gv[1] * w[1].w + gv[2] * w[2].w + gv[3] * w[3].w;
-    d.x *= sigmoid_log2(fmaf(sc.x, zv.x, sh.x));
-    d.y *= sigmoid_log2(fmaf(sc.y, zv.y, sh.y));
-    d.z *= sigmoid_log2(fmaf(sc.z, zv.z, sh.z));
-    d.w *= sigmoid_log2(fmaf(sc.w, zv.w, sh.w));
+    if (WG) {
+      // sigmoid and softplus of the same argument share the exponential:
+      // e = 2^-|u|, t = 1 + e: softplus/ln2 = max(u,0) + log2(t); sigmoid = (u >= 0 ? 1 : e) / t
+      float u[4] = {fmaf(sc.x, zv.x, sh.x), fmaf(sc.y, zv.y, sh.y), fmaf(sc.z, zv.z, sh.z), fmaf(sc.w, zv.w, sh.w)};
+      float sp[4], sgm[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float e = __builtin_amdgcn_exp2f(-__builtin_fabsf(u[c]));
+        const float t = 1.0f + e;
+        sp[c] = __builtin_fmaxf(u[c], 0.0f) + __builtin_amdgcn_logf(t);
+        sgm[c] = (u[c] >= 0.f ? 1.0f : e) * __builtin_amdgcn_rcpf(t);
+      }
+      d.x *= sgm[0]; d.y *= sgm[1]; d.z *= sgm[2]; d.w *= sgm[3];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        dw[n].x = fmaf(gv[n], sp[0], dw[n].x); dw[n].y = fmaf(gv[n], sp[1], dw[n].y);
+        dw[n].z = fmaf(gv[n], sp[2], dw[n].z); dw[n].w = fmaf(gv[n], sp[3], dw[n].w);
+        dbv[n] += gv[n];
+      }
+    } else {
+      d.x *= sigmoid_log2(fmaf(sc.x, zv.x, sh.x));
+      d.y *= sigmoid_log2(fmaf(sc.y, zv.y, sh.y));
+      d.z *= sigmoid_log2(fmaf(sc.z, zv.z, sh.z));
+      d.w *= sigmoid_log2(fmaf(sc.w, zv.w, sh.w));
+    }
     *reinterpret_cast<float4*>(G + row * ldG + 4 * cg) = d;
     sg.x += d.x; sg.y += d.y; sg.z += d.z; sg.w += d.w;
     sgz.x = fmaf(d.x, zv.x, sgz.x); sgz.y = fmaf(d.y, zv.y, sgz.y);
@@ -265,6 +294,45 @@ head_bwd_kernel(int64_t M, int N8, const float* __restrict__ g, const float* __r
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
     *reinterpret_cast<float4*>(col_part + (size_t)blockIdx.x * 256 + which * 128 + 4 * cg) = a;
+  }
+  if (WG) {
+    // the 8 row groups of the workgroup combine through LDS, two head rows (n) per round; the softplus
+    // was accumulated in log2 units: ln 2 is applied here
+    float* part = wgrad_part + (size_t)blockIdx.x * (N8 * 128 + N8);
+#pragma unroll
+    for (int n0 = 0; n0 < 4; n0 += 2) {
+      __syncthreads();
+      s_red[0][rsub][cg] = dw[n0];
+      s_red[1][rsub][cg] = dw[n0 + 1];
+      __syncthreads();
+      if (threadIdx.x < 64) {
+        const int which = threadIdx.x >> 5;
+        float4 a = s_red[which][0][cg];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) {
+          const float4 b = s_red[which][r][cg];
+          a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        const int n = n0 + which;
+        if (n < N8) {
+          float* o = part + n * 128 + 4 * cg;      // rows of 128 floats: 16-byte aligned only if N8 % 4 == 0
+          o[0] = a.x * kLn2; o[1] = a.y * kLn2; o[2] = a.z * kLn2; o[3] = a.w * kLn2;
+        }
+      }
+    }
+    __syncthreads();
+    float* s_db = reinterpret_cast<float*>(s_red);
+    if (cg == 0) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) s_db[rsub * 4 + n] = dbv[n];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < N8) {
+      float a = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) a += s_db[r * 4 + threadIdx.x];
+      part[N8 * 128 + threadIdx.x] = a;
+    }
   }
 }
 
@@ -363,7 +431,7 @@ int ganet_mlp_bwd_data(int64_t M, int32_t O, const float* g, int64_t ldg, const 
 
 int ganet_mlp_head_bwd(int64_t M, int32_t N8, const float* g, const float* W8, const float* z,
                        int64_t ldz, const float* scale, const float* shift, float* G, int64_t ldG,
-                       float* col_part, void* stream_) {
+                       float* col_part, float* wgrad_part, void* stream_) {
   if (M <= 0 || N8 <= 0 || N8 > 4 || !g || !W8 || !z || !scale || !shift || !G || !col_part ||
       (ldz % 4) || (ldG % 4) || ldz < 128 || ldG < 128 || !aligned16(W8) || !aligned16(z) ||
       !aligned16(G) || !aligned16(scale) || !aligned16(shift) || !aligned16(col_part)) {
@@ -371,9 +439,14 @@ int ganet_mlp_head_bwd(int64_t M, int32_t N8, const float* g, const float* W8, c
     return 1;
   }
   ProfScope prof_(K_HEAD_BWD, static_cast<hipStream_t>(stream_));
-  hipLaunchKernelGGL(head_bwd_kernel, dim3(HEAD_BLOCKS), dim3(256), 0,
-                     static_cast<hipStream_t>(stream_), M, N8, g, W8, z, ldz, scale, shift, G, ldG,
-                     col_part);
+  if (wgrad_part)
+    hipLaunchKernelGGL(head_bwd_kernel<true>, dim3(HEAD_BLOCKS), dim3(256), 0,
+                       static_cast<hipStream_t>(stream_), M, N8, g, W8, z, ldz, scale, shift, G, ldG,
+                       col_part, wgrad_part);
+  else
+    hipLaunchKernelGGL(head_bwd_kernel<false>, dim3(HEAD_BLOCKS), dim3(256), 0,
+                       static_cast<hipStream_t>(stream_), M, N8, g, W8, z, ldz, scale, shift, G, ldG,
+                       col_part, nullptr);
   return check_hip(hipGetLastError(), "head_bwd_kernel");
 }
 

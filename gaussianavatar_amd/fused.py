@@ -411,6 +411,11 @@ def _decoder_bn_layers():
     return out
 
 
+# measured on MI355X: riding the head weight gradient on head_bwd is ~3 % SLOWER per iteration than the
+# separate ganet_wgrad_act pass (head_bwd turns VALU-bound), so it stays off; GA_HEAD_RIDE=1 selects it
+_HEAD_RIDE = os.environ.get("GA_HEAD_RIDE", "0") == "1"
+
+
 class _RowSweep:
     """Alternates GANET_ROWS_UP / GANET_ROWS_DOWN between consecutive big launches of a pass (include/ganet.h:
     each kernel starts on the rows its predecessor touched last, which are still in the Infinity Cache).
@@ -565,7 +570,7 @@ class _DecoderFn(torch.autograd.Function):
                 M, N, K, _ptr(gt), gt.stride(0), _ptr(gz), 0 if gz is None else gz.stride(0), _ptr(coef),
                 _ptr(x), x.stride(0), _ptr(sc), _ptr(sh), None, None, ws, wg_bytes, sweep.next(), st))
             jobs[j].workspace, jobs[j].M, jobs[j].N, jobs[j].K = ws, M, N, K
-            jobs[j].dW, jobs[j].db = dW.data_ptr(), db.data_ptr()
+            jobs[j].dW, jobs[j].db, jobs[j].nblocks = dW.data_ptr(), db.data_ptr(), 0
             njobs[0] = j + 1
             return dW, db          # filled by the batched reduction at the end of backward
 
@@ -594,13 +599,25 @@ class _DecoderFn(torch.autograd.Function):
         for pos, j in enumerate(heads):
             i6, i7 = 5 + 2 * j, 6 + 2 * j
             g = d_outs[j].contiguous()
-            dW, db = wgrad(g, None, i7)
-            g_out_w[j], g_out_b[j] = dW.unsqueeze(-1), db
+            N8 = g.shape[1]
+            # optional (_HEAD_RIDE): the head's own weight gradient rides on head_bwd (same g and z rows)
+            # and its per-workgroup partials join the batched reduction
             Gs[i7] = f32(M, 128)
             _, _, sc7, sh7 = stats[i7]
-            _native.ganet_check(lib.ganet_mlp_head_bwd(M, g.shape[1], _ptr(g), _ptr(out_w[j].contiguous()), _ptr(zs[i7]),
+            if _HEAD_RIDE:
+                dW, db = f32(N8, 128), f32(N8)
+                jn = njobs[0]
+                ws = wg_ws.data_ptr() + jn * wg_bytes
+                jobs[jn].workspace, jobs[jn].M, jobs[jn].N, jobs[jn].K = ws, M, N8, 128
+                jobs[jn].dW, jobs[jn].db, jobs[jn].nblocks = dW.data_ptr(), db.data_ptr(), n_head
+                njobs[0] = jn + 1
+            else:
+                dW, db = wgrad(g, None, i7)
+                ws = None
+            g_out_w[j], g_out_b[j] = dW.unsqueeze(-1), db
+            _native.ganet_check(lib.ganet_mlp_head_bwd(M, N8, _ptr(g), _ptr(out_w[j].contiguous()), _ptr(zs[i7]),
                                                        zs[i7].stride(0), _ptr(sc7), _ptr(sh7), _ptr(Gs[i7]),
-                                                       Gs[i7].stride(0), _ptr(col_part), st))
+                                                       Gs[i7].stride(0), _ptr(col_part), ws, st))
             finish(i7, n_head)
             dW, db = wgrad(None, i7, i6)
             g_conv_w[i7], g_conv_b[i7] = dW.unsqueeze(-1), db

@@ -126,6 +126,8 @@ typedef struct GanetWgradJob {
   int32_t N, K;
   float* dW;               /* [N,K] */
   float* db;               /* [N] or NULL */
+  int32_t nblocks;         /* 0: the partials of ganet_wgrad_act(M, ...); > 0: that many blocks of N*K+N
+                              floats (ganet_mlp_head_bwd's wgrad_part: ganet_mlp_head_bwd_parts() blocks) */
 } GanetWgradJob;
 int ganet_wgrad_reduce_batch(int32_t n_jobs, const GanetWgradJob* jobs, void* stream);
 
@@ -138,6 +140,10 @@ int ganet_wgrad_reduce_batch(int32_t n_jobs, const GanetWgradJob* jobs, void* st
  *   receives the partial column sums of out and out . src_z.
  * ganet_mlp_head_bwd:  the same for the narrow output heads (g [M,N8], N8 <= 4, W8 [N8,128]):
  *   G[M,128] = (g W8) softplus'(scale z + shift), partial sums [ganet_mlp_head_bwd_parts()][2][128].
+ *   wgrad_part (optional, [ganet_mlp_head_bwd_parts()][N8*128 + N8] floats): the head's own weight
+ *   gradient rides along — per-workgroup partial sums of dW8[n,k] = sum_m g[m,n] softplus(scale_k z[m,k]
+ *   + shift_k) and db8[n] = sum_m g[m,n], finished by ganet_wgrad_reduce_batch (job.nblocks =
+ *   ganet_mlp_head_bwd_parts()); it saves the separate pass of ganet_wgrad_act over z.
  * ganet_mlp_bwd_stats: partial sums -> coef [3][128] = (A, q, p), d gamma, d beta.
  * Together they replace the autograd backward of Conv1d(k=1) -> BatchNorm1d -> Softplus
  * (/root/reference/model/modules.py:554-582) without materialising dz or dL/dy. */
@@ -150,7 +156,7 @@ int ganet_mlp_bwd_data(int64_t M, int32_t O, const float* g, int64_t ldg, const 
                        const float* src_shift, float* col_part, int32_t row_order, void* stream);
 int ganet_mlp_head_bwd(int64_t M, int32_t N8, const float* g, const float* W8, const float* z,
                        int64_t ldz, const float* scale, const float* shift, float* G, int64_t ldG,
-                       float* col_part, void* stream);
+                       float* col_part, float* wgrad_part, void* stream);
 int ganet_mlp_bwd_stats(int64_t M, int32_t nparts, const float* col_part, const float* mean,
                         const float* rstd, const float* scale, float* coef, float* dgamma,
                         float* dbeta, void* stream);

@@ -337,10 +337,12 @@ def test_mlp_bwd_data_matches_torch(M, O, accumulate, sig, row_order):
         assert float((p[1] - r2).abs().max()) <= 1e-4 * float((ref * src_z.double()).abs().sum(0).max()) + 1e-3
 
 
+@pytest.mark.parametrize("ride", [False, True])
 @pytest.mark.parametrize("M,N8", [(262144, 3), (5001, 1), (37, 3)])
-def test_mlp_head_bwd_and_stats_match_torch_batchnorm_backward(M, N8):
+def test_mlp_head_bwd_and_stats_match_torch_batchnorm_backward(M, N8, ride):
     """Head kernel + coefficient kernel: dz = A G + q z + p must equal autograd's gradient of
-    softplus(batch_norm(z)) w.r.t. z; d gamma / d beta likewise."""
+    softplus(batch_norm(z)) w.r.t. z; d gamma / d beta likewise. ride: the head's own weight / bias
+    gradient comes out of the same pass (wgrad_part + ganet_wgrad_reduce_batch)."""
     from gaussianavatar_amd import _native, fused
     lib = _native.ganet()
     torch.manual_seed(N8)
@@ -348,10 +350,11 @@ def test_mlp_head_bwd_and_stats_match_torch_batchnorm_backward(M, N8):
     z = (torch.randn(M, 128, device=dev) * 1.5 + torch.linspace(-2, 2, 128, device=dev)).requires_grad_(True)
     gamma = torch.empty(128, device=dev).uniform_(0.5, 2).requires_grad_(True)
     beta = torch.empty(128, device=dev).uniform_(-1, 1).requires_grad_(True)
-    W8 = torch.randn(N8, 128, device=dev) * 0.3
+    W8 = (torch.randn(N8, 128, device=dev) * 0.3).requires_grad_(True)
+    b8 = torch.zeros(N8, device=dev, requires_grad=True)
     g = torch.randn(M, N8, device=dev)
     y = F.softplus(F.batch_norm(z, None, None, gamma, beta, True, 0.1, 1e-5))
-    (y @ W8.t() * g).sum().backward()
+    ((y @ W8.t() + b8) * g).sum().backward()
     with torch.no_grad():
         mean = z.mean(0)
         rstd = torch.rsqrt(z.var(0, unbiased=False) + 1e-5)
@@ -360,9 +363,18 @@ def test_mlp_head_bwd_and_stats_match_torch_batchnorm_backward(M, N8):
     G = torch.empty(M, 128, device=dev)
     parts = lib.ganet_mlp_head_bwd_parts()
     part = torch.zeros(parts * 256, device=dev)
-    _native.ganet_check(lib.ganet_mlp_head_bwd(M, N8, fused._ptr(g), fused._ptr(W8), fused._ptr(z.detach()), 128,
+    wpart = torch.full((parts * (N8 * 128 + N8),), float("nan"), device=dev) if ride else None
+    _native.ganet_check(lib.ganet_mlp_head_bwd(M, N8, fused._ptr(g), fused._ptr(W8.detach()), fused._ptr(z.detach()), 128,
                                                fused._ptr(sc), fused._ptr(sh), fused._ptr(G), 128, fused._ptr(part),
-                                               fused._stream(dev)))
+                                               fused._ptr(wpart), fused._stream(dev)))
+    if ride:
+        dW8, db8 = torch.empty(N8, 128, device=dev), torch.empty(N8, device=dev)
+        jobs = (_native.GanetWgradJob * 1)()
+        jobs[0].workspace, jobs[0].M, jobs[0].N, jobs[0].K = wpart.data_ptr(), M, N8, 128
+        jobs[0].dW, jobs[0].db, jobs[0].nblocks = dW8.data_ptr(), db8.data_ptr(), parts
+        _native.ganet_check(lib.ganet_wgrad_reduce_batch(1, jobs, fused._stream(dev)))
+        assert float((dW8 - W8.grad).abs().max()) <= 2e-5 * float(W8.grad.abs().max()) + 1e-4
+        assert float((db8 - b8.grad).abs().max()) <= 2e-5 * float(b8.grad.abs().max()) + 1e-4
     coef = torch.empty(3, 128, device=dev)
     dg = torch.empty(128, device=dev)
     db = torch.empty(128, device=dev)
