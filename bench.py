@@ -33,7 +33,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-EVENT_EVERY = 10          # timed steps whose dominant-family launches carry HIP events
+EVENT_EVERY = 10          # timed steps whose dominant-family launches carry HIP events (every 20th for K >= 100)
 MFMA_F32_PEAK_TF = 157.3  # dense fp32-input MFMA peak (same guide; v_mfma_f32_32x32x2_f32)
 
 
@@ -268,11 +268,12 @@ def main():
     dom_family = max(share, key=share.get) if share else None
     dom_lib = rasterizer if dom_family in probe_r else (fused if dom_family in probe_n else None)
     sampled_steps = 0
+    every = EVENT_EVERY * (2 if args.steps >= 100 else 1)
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        sample = dom_lib is not None and i % EVENT_EVERY == 0
+        sample = dom_lib is not None and i % every == 0
         if sample:
             dom_lib.profile_enable([dom_family])
             sampled_steps += 1
