@@ -20,12 +20,12 @@ constexpr int MERGE_ITEMS = 8;        // outputs per thread per merge step
 
 // ------------------------------------------------------------------ K2
 __global__ void __launch_bounds__(SCAN_THREADS)
-tile_scan_kernel(int T, int64_t max_pairs, const uint32_t* __restrict__ tile_count,
+tile_scan_kernel(int T, int64_t max_pairs, uint32_t* __restrict__ tile_count,
                  uint32_t* __restrict__ tile_offset, uint32_t* __restrict__ tile_cursor,
                  int32_t* __restrict__ status, size_t ws_stride) {
   {
     const size_t off = (size_t)blockIdx.y * ws_stride;   // batched launch: this frame's workspace
-    tile_count = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(tile_count) + off);
+    tile_count = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(tile_count) + off);
     tile_offset = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(tile_offset) + off);
     tile_cursor = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(tile_cursor) + off);
     status = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(status) + off);
@@ -74,6 +74,45 @@ tile_scan_kernel(int T, int64_t max_pairs, const uint32_t* __restrict__ tile_cou
     status[1] = ((int64_t)total > max_pairs) ? 1 : 0;
     status[3] = (int32_t)gmax;
   }
+  // The histogram is dead from here on: its buffer is reused for the tile ORDER the sort kernel walks —
+  // tiles by size class (1 + floor(log2 count)), largest class first. The per-tile sort holds 64 KiB of
+  // LDS, so only two of its workgroups fit on a CU and the launch is a list-scheduling problem: with
+  // the long lists of the avatar's interior tiles dispatched first, the short ones fill the gaps instead
+  // of a few long ones forming the tail. Order within a class is arbitrary (it only affects scheduling).
+  constexpr int MAXPER = 8, NCLS = 34;
+  __shared__ uint32_t s_cls[NCLS];
+  uint32_t pos[MAXPER];
+  const bool ordered = per <= MAXPER;
+  if (tid < NCLS) s_cls[tid] = 0;
+  __syncthreads();
+  auto cls_of = [](uint32_t c) { return c ? 32 - __clz(c) : 0; };   // 0 for empty, else 1..32
+  // most tiles are empty (class 0): those are counted / placed once per wave (ballot), the rest per tile
+  auto place = [&](int c, bool on) -> uint32_t {
+    const unsigned long long empt = __ballot(on && c == 0);
+    uint32_t base = 0;
+    if (empt && lane == __ffsll((long long)empt) - 1) base = atomicAdd(&s_cls[0], (uint32_t)__popcll(empt));
+    base = __shfl(base, empt ? __ffsll((long long)empt) - 1 : 0);
+    if (on && c == 0) return base + (uint32_t)__popcll(empt & ((1ull << lane) - 1ull));
+    return on ? atomicAdd(&s_cls[c], 1u) : 0u;
+  };
+  if (ordered)
+    for (int k = 0; k < per; ++k) {                      // uniform trip count: the ballots need every lane
+      const int t = lo + k;
+      place(t < hi ? cls_of(tile_count[t]) : -1, t < hi);
+    }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t run2 = 0;
+    for (int c = NCLS - 1; c >= 0; --c) { const uint32_t v = s_cls[c]; s_cls[c] = run2; run2 += v; }
+  }
+  __syncthreads();
+  if (ordered)
+    for (int k = 0; k < per; ++k) {
+      const int t = lo + k;
+      pos[k] = place(t < hi ? cls_of(tile_count[t]) : -1, t < hi);
+    }
+  __syncthreads();                    // every count has been read: the buffer may be overwritten
+  for (int t = lo, k = 0; t < hi; ++t, ++k) tile_count[ordered ? pos[k] : t] = (uint32_t)t;
 }
 
 // ------------------------------------------------------------------ K3
@@ -172,18 +211,20 @@ __device__ __forceinline__ int merge_split(const uint64_t* A, int na, const uint
 }
 
 __global__ void __launch_bounds__(SORT_THREADS)
-tile_sort_kernel(int64_t max_pairs, const uint32_t* __restrict__ tile_offset,
+tile_sort_kernel(int64_t max_pairs, const uint32_t* __restrict__ tile_order,
+                 const uint32_t* __restrict__ tile_offset,
                  uint64_t* __restrict__ pair_key, uint64_t* __restrict__ pair_tmp,
                  uint32_t* __restrict__ point_list, size_t ws_stride) {
   __shared__ uint64_t s_key[SORT_CAP];
   {
     const size_t off = (size_t)blockIdx.y * ws_stride;
+    tile_order = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(tile_order) + off);
     tile_offset = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(tile_offset) + off);
     pair_key = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(pair_key) + off);
     pair_tmp = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(pair_tmp) + off);
     point_list = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(point_list) + off);
   }
-  const int tile = blockIdx.x;
+  const int tile = (int)tile_order[blockIdx.x];      // largest lists first (tile_scan_kernel)
   const int tid = threadIdx.x;
   const int64_t cap = max_pairs;
   const int64_t start = min((int64_t)tile_offset[tile], cap);
@@ -262,7 +303,7 @@ hipError_t launch_binning(const Dims& d, const Workspace& ws, const Batch& bt, h
     {
       ProfScope prof_(K_SORT, stream);
       hipLaunchKernelGGL(tile_sort_kernel, dim3(d.T, bt.frames), dim3(SORT_THREADS), 0, stream, d.max_pairs,
-                       ws.tile_offset, ws.pair_key, ws.pair_tmp, ws.point_list, bt.ws_stride);
+                       ws.tile_count, ws.tile_offset, ws.pair_key, ws.pair_tmp, ws.point_list, bt.ws_stride);
     }
     e = hipGetLastError();
   }

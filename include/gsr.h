@@ -82,7 +82,7 @@ typedef struct GsrLayout {
   uint64_t tiles_touched;  /* uint32  [P]                                                   */
   uint64_t clamped;        /* uint8   [P,4]  SH clamp flags rgb, pad                        */
   /* per tile, T = ceil(W/16)*ceil(H/16) */
-  uint64_t tile_count;     /* uint32  [T]    number of (tile,Gaussian) pairs per tile       */
+  uint64_t tile_count;     /* uint32  [T]    pairs per tile (histogram); after the scan: tile ids, largest lists first */
   uint64_t tile_offset;    /* uint32  [T+1]  exclusive scan; [T] = total pairs D            */
   uint64_t tile_cursor;    /* uint32  [T]    scatter cursors (scratch)                      */
   /* per (tile,Gaussian) pair, capacity max_pairs */
