@@ -146,9 +146,9 @@ struct WaveGeom {
   bool inside;
 };
 
-__device__ __forceinline__ WaveGeom wave_geometry(int gx, int W, int H) {
+__device__ __forceinline__ WaveGeom wave_geometry(int gx, int W, int H, int tile) {
   WaveGeom g;
-  const int tile = blockIdx.x >> 2, quadrant = blockIdx.x & 3;
+  const int quadrant = blockIdx.x & 3;
   g.wave = threadIdx.x / GSR_WAVE;
   g.lane = threadIdx.x & (GSR_WAVE - 1);
   g.sub = g.lane & (LPP - 1);
@@ -162,7 +162,7 @@ __device__ __forceinline__ WaveGeom wave_geometry(int gx, int W, int H) {
 }
 
 __global__ void __launch_bounds__(GSR_TILE_PIX)
-render_fwd_kernel(int W, int H, int gx, int64_t max_pairs,
+render_fwd_kernel(int W, int H, int gx, int64_t max_pairs, const uint32_t* __restrict__ tile_order,
                   const uint32_t* __restrict__ tile_offset,
                   const uint32_t* __restrict__ point_list, const float2* __restrict__ xy,
                   const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb,
@@ -171,6 +171,7 @@ render_fwd_kernel(int W, int H, int gx, int64_t max_pairs,
                   size_t ws_stride) {
   {   // batched launch: blockIdx.y = frame
     const size_t off = (size_t)blockIdx.y * ws_stride;
+    tile_order = shift(tile_order, off);
     tile_offset = shift(tile_offset, off); point_list = shift(point_list, off); xy = shift(xy, off);
     conic_opacity = shift(conic_opacity, off); rgb = shift(rgb, off);
     final_T = reinterpret_cast<float*>(reinterpret_cast<char*>(final_T) + off);
@@ -181,9 +182,11 @@ render_fwd_kernel(int W, int H, int gx, int64_t max_pairs,
   __shared__ float4 s_co[WAVES][GSR_WAVE + PAD];
   __shared__ float4 s_rgb[WAVES][GSR_WAVE + PAD];
   __shared__ int s_k[WAVES][GSR_WAVE + PAD];
-  const WaveGeom g = wave_geometry(gx, W, H);
+  // blocks walk the tiles in the binning's size order (longest lists first, tile_scan_kernel): the long
+  // per-pixel chains of the avatar's interior start at once instead of forming the launch's tail
+  const int tile = (int)tile_order[blockIdx.x >> 2];
+  const WaveGeom g = wave_geometry(gx, W, H, tile);
   const int wave = g.wave, lane = g.lane, sub = g.sub;
-  const int tile = blockIdx.x >> 2;
   const int64_t start = min((int64_t)tile_offset[tile], max_pairs);
   const int64_t end = min((int64_t)tile_offset[tile + 1], max_pairs);
   const int n = (int)(end - start);
@@ -289,7 +292,7 @@ constexpr int ACC_ROWS = LPP * 9;    // one step parks 4 entries x 9 gradient co
 constexpr int ACC_ROW = 17;          // 16 pixels + 1 pad: column reads by 36 lanes are conflict-free
 
 __global__ void __launch_bounds__(GSR_TILE_PIX)
-render_bwd_kernel(int W, int H, int gx, int64_t max_pairs,
+render_bwd_kernel(int W, int H, int gx, int64_t max_pairs, const uint32_t* __restrict__ tile_order,
                   const uint32_t* __restrict__ tile_offset,
                   const uint32_t* __restrict__ point_list, const float2* __restrict__ xy,
                   const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb,
@@ -298,6 +301,7 @@ render_bwd_kernel(int W, int H, int gx, int64_t max_pairs,
                   float* __restrict__ grad_acc, int flags, size_t ws_stride) {
   {   // batched launch: blockIdx.y = frame
     const size_t off = (size_t)blockIdx.y * ws_stride;
+    tile_order = shift(tile_order, off);
     tile_offset = shift(tile_offset, off); point_list = shift(point_list, off); xy = shift(xy, off);
     conic_opacity = shift(conic_opacity, off); rgb = shift(rgb, off); final_T = shift(final_T, off);
     n_contrib = shift(n_contrib, off);
@@ -310,9 +314,9 @@ render_bwd_kernel(int W, int H, int gx, int64_t max_pairs,
   __shared__ int s_k[WAVES][GSR_WAVE + PAD];
   __shared__ uint32_t s_idx[WAVES][GSR_WAVE + PAD];
   __shared__ float s_acc[WAVES][ACC_ROWS][ACC_ROW];
-  const WaveGeom g = wave_geometry(gx, W, H);
+  const int tile = (int)tile_order[blockIdx.x >> 2];      // size order, as in the forward kernel
+  const WaveGeom g = wave_geometry(gx, W, H, tile);
   const int wave = g.wave, lane = g.lane, sub = g.sub, pixi = g.pix;
-  const int tile = blockIdx.x >> 2;
   const int64_t start = min((int64_t)tile_offset[tile], max_pairs);
   const int64_t end = min((int64_t)tile_offset[tile + 1], max_pairs);
   const int n = (int)(end - start);
@@ -487,8 +491,9 @@ hipError_t launch_render_fwd(const GsrSettings& s, const Dims& d, const Workspac
   {
     ProfScope prof_(K_RENDER_FWD, stream);
     hipLaunchKernelGGL(render_fwd_kernel, dim3(4 * d.T, bt.frames), dim3(GSR_TILE_PIX), 0, stream, d.W,
-                       d.H, d.gx, d.max_pairs, ws.tile_offset, ws.point_list, ws.xy, ws.conic_opacity,
-                       ws.rgb, s.bg, out_color, ws.final_T, ws.n_contrib, ablate_flags(), bt.ws_stride);
+                       d.H, d.gx, d.max_pairs, ws.tile_count, ws.tile_offset, ws.point_list, ws.xy,
+                       ws.conic_opacity, ws.rgb, s.bg, out_color, ws.final_T, ws.n_contrib, ablate_flags(),
+                       bt.ws_stride);
   }
   return hipGetLastError();
 }
@@ -499,9 +504,9 @@ hipError_t launch_render_bwd(const GsrSettings& s, const Dims& d, const Workspac
   {
     ProfScope prof_(K_RENDER_BWD, stream);
     hipLaunchKernelGGL(render_bwd_kernel, dim3(4 * d.T, bt.frames), dim3(GSR_TILE_PIX), 0, stream, d.W,
-                       d.H, d.gx, d.max_pairs, ws.tile_offset, ws.point_list, ws.xy, ws.conic_opacity,
-                       ws.rgb, s.bg, ws.final_T, ws.n_contrib, dL_dout, ws.grad_acc, ablate_flags(),
-                       bt.ws_stride);
+                       d.H, d.gx, d.max_pairs, ws.tile_count, ws.tile_offset, ws.point_list, ws.xy,
+                       ws.conic_opacity, ws.rgb, s.bg, ws.final_T, ws.n_contrib, dL_dout, ws.grad_acc,
+                       ablate_flags(), bt.ws_stride);
   }
   return hipGetLastError();
 }
