@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # torch's own DataLoader pin-memory thread calls Tensor.pin_memory(device) / is_pinned(device), which this
+    # torch deprecates: thousands of identical warnings per run of the disk-dataset loop test
+    config.addinivalue_line("filterwarnings", "ignore:The argument 'device' of Tensor.:DeprecationWarning")
 
 
 @pytest.fixture(scope="session")
