@@ -10,9 +10,6 @@ maximize, capturable and differentiable off; float32 CUDA parameters with dense 
 """
 from __future__ import annotations
 
-import ctypes
-import math
-
 import torch
 
 from . import _native
