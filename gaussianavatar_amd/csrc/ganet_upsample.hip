@@ -79,7 +79,18 @@ upsample_bwd_cols_kernel(int S, int R, const float* __restrict__ dx, int64_t ldx
     const float* row = dx + (int64_t)i * S * ldx + lane;
     float acc = 0.f;
     const int c0 = cptr[q], c1 = cptr[q + 1];
-    for (int ci = c0; ci < c1; ++ci) acc = fmaf(cw[ci], row[(int64_t)csrc[ci] * ldx], acc);
+    // the first 8 taps (all of them for the x4 up-sampling of the reference) as one batch of independent
+    // loads — a run-time loop waits for every 256-byte row before it asks for the next one
+    float v[8], w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int ci = min(c0 + u, c1 - 1);
+      w[u] = (c0 + u < c1) ? cw[ci] : 0.f;
+      v[u] = (c1 > c0) ? row[(int64_t)csrc[max(ci, c0)] * ldx] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = fmaf(w[u], v[u], acc);
+    for (int ci = c0 + 8; ci < c1; ++ci) acc = fmaf(cw[ci], row[(int64_t)csrc[ci] * ldx], acc);
     tmp[(int64_t)t * 64 + lane] = acc;
   }
 }
