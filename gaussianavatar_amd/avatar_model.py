@@ -220,6 +220,7 @@ class AvatarModel:
         if self.model_parms.train_stage == 2:
             self.pose_encoder = UnetNoCond5DS(input_nc=3, output_nc=np_.c_pose, nf=np_.nf,
                                               up_mode=np_.up_mode, use_dropout=False).to(self.device)
+        self.sync_replicas()
 
     def training_setup(self):
         o = self.opt_parms
@@ -269,6 +270,7 @@ class AvatarModel:
             self.optimizer.load_state_dict(saved["optimizer"])
         if self.scheduler is not None:
             self.scheduler.load_state_dict(saved["scheduler"])
+        self.sync_replicas()
 
     def stage_load(self, ckpt_path):
         saved = torch.load(os.path.join(ckpt_path, "net.pth"), map_location=self.device, weights_only=False)
@@ -276,6 +278,7 @@ class AvatarModel:
         self.pose.load_state_dict(saved["pose"], strict=False)
         self.transl.load_state_dict(saved["transl"], strict=False)
         self.geo_feature.data[...] = saved["geo_feature"].data[...]
+        self.sync_replicas()
 
     def stage2_load(self, epoch):
         path = os.path.join(self.model_parms.project_path, self.model_path, "net/iteration_{}".format(epoch))
@@ -285,18 +288,29 @@ class AvatarModel:
         self.transl.load_state_dict(st["transl"], strict=False)
         self.geo_feature.data[...] = st["geo_feature"].data[...]
         self.pose_encoder.load_state_dict(st["pose_encoder"], strict=False)
+        self.sync_replicas()
 
     # ------------------------------------------------------------------ data
     def getTrainDataloader(self):
+        # data parallel: every rank draws the same permutation and keeps its own slice of it (frames are
+        # the sharding unit, parallel.ShardedSampler); a single process shuffles like the reference does
+        sampler = parallel.ShardedSampler(len(self.train_dataset)) if parallel.world_size() > 1 else None
         if self.from_disk:      # image decoding in worker processes (avatar_model.py:238-244)
             workers = int(getattr(self.model_parms, "num_workers", 4))
             loader = torch.utils.data.DataLoader(
-                self.train_dataset, batch_size=self.batch_size, shuffle=True, num_workers=workers, drop_last=True,
-                collate_fn=_host_collate, pin_memory=self.device.type == "cuda", persistent_workers=workers > 0)
+                self.train_dataset, batch_size=self.batch_size, shuffle=sampler is None, sampler=sampler,
+                num_workers=workers, drop_last=True, collate_fn=_host_collate,
+                pin_memory=self.device.type == "cuda", persistent_workers=workers > 0)
             return _DeviceLoader(loader, self.device)
-        return torch.utils.data.DataLoader(self.train_dataset, batch_size=self.batch_size, shuffle=True,
-                                           num_workers=0, drop_last=True,
+        return torch.utils.data.DataLoader(self.train_dataset, batch_size=self.batch_size, shuffle=sampler is None,
+                                           sampler=sampler, num_workers=0, drop_last=True,
                                            collate_fn=lambda items: collate_frames(items, self.device))
+
+    def sync_replicas(self):
+        """Data parallel: all ranks take rank 0's parameters, BatchNorm buffers and pose tables (after
+        construction and after every checkpoint load; a no-op on one rank)."""
+        mods = [self.net, self.pose, self.transl] + ([self.pose_encoder] if hasattr(self, "pose_encoder") else [])
+        parallel.broadcast_state(mods, [self.geo_feature.data])
 
     def _free_dataset(self):
         return SyntheticFrames(self.frames, self.model_parms.train_stage, self.model_parms.inp_posmap_size, test=True)
@@ -429,7 +443,10 @@ class AvatarModel:
         return image
 
     def render_free_stage2(self, batch_data, iteration):
+        # the reference looks the pose up in the learned embeddings here (model/avatar_model.py:555-560),
+        # unlike render_free_stage1 which takes batch['pose_data']
+        idx = batch_data["pose_idx"]
         pose_featmap = self.pose_encoder(batch_data["inp_pos_map"])
-        image, _, _, _ = self._forward(batch_data, iteration, batch_data["pose_data"],
-                                       batch_data["transl_data"], pose_featmap, warmup=False)
+        image, _, _, _ = self._forward(batch_data, iteration, self.pose(idx), self.transl(idx),
+                                       pose_featmap, warmup=False)
         return image

@@ -113,13 +113,18 @@ __device__ __forceinline__ float quad_scan_mul(float x, int sub) {
   return x;
 }
 
-// Development aid: GSR_ABLATE=<bits> disables parts of the render kernels to attribute time
-// (1 no global atomics, 2 no cross-lane reduction, 4 no culling, 8 no blend loop).
-// Results are wrong with any bit set; never set in production.
+// Development aid, compiled in ONLY with -DGSR_ABLATE_BUILD (tools/build_variant.sh): the environment
+// variable GSR_ABLATE=<bits> then disables parts of the render kernels to attribute time (1 no global
+// atomics, 2 no cross-lane reduction, 4 no culling, 8 no blend loop; results are wrong with any bit
+// set). The product library ignores the variable: the flags are the constant 0.
+#ifdef GSR_ABLATE_BUILD
 inline int ablate_flags() {
   static const int v = [] { const char* e = getenv("GSR_ABLATE"); return e ? atoi(e) : 0; }();
   return v;
 }
+#else
+constexpr int ablate_flags() { return 0; }
+#endif
 
 struct Entry {
   float2 xy;

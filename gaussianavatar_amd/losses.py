@@ -28,7 +28,9 @@ def _fusable(img1, img2, window_size=11, size_average=True):
 
 
 def _paired(img1, img2, want: str):
-    key = (id(img1), img1._version, id(img2), img2._version)
+    # grad mode is part of the key: a value parked under no_grad (logging) has no graph and must not
+    # answer a later call that wants gradients
+    key = (id(img1), img1._version, id(img2), img2._version, torch.is_grad_enabled(), img1.requires_grad)
     ent = _pair.get("entry")
     if ent is not None and ent["key"] == key and ent["a"]() is img1 and ent["b"]() is img2 and want in ent["left"]:
         out = ent["left"].pop(want)

@@ -133,6 +133,48 @@ def allgather_sparse_grads(params: List[torch.Tensor]) -> None:
         p.grad = torch.sparse_coo_tensor(ii, vv, g.shape).coalesce()
 
 
+def broadcast_state(modules, tensors=()) -> None:
+    """Every rank takes rank 0's parameters AND buffers (BatchNorm running statistics) of `modules` and the
+    extra `tensors` — one flat broadcast per dtype. Called after construction and after every checkpoint
+    load, so replicas start identical whatever each process's RNG state was."""
+    if world_size() == 1:
+        return
+    items = [t for t in tensors]
+    for m in modules:
+        items += [p.data for p in m.parameters()] + [b for b in m.buffers()]
+    by_dtype = {}
+    for t in items:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for group in by_dtype.values():
+        flat = torch.cat([t.reshape(-1) for t in group])
+        dist.broadcast(flat, src=dist.get_global_rank(_group, 0) if _group is not None else 0, group=_group)
+        off = 0
+        for t in group:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+
+
+class ShardedSampler(torch.utils.data.Sampler):
+    """Frames of an epoch, sharded by rank: every rank draws the SAME seeded permutation (seed + epoch
+    counter, advanced on every __iter__ because the reference's loop never calls set_epoch) and keeps
+    positions rank, rank+R, ... of it, truncated to a common length. On one rank it is a plain seeded
+    shuffle."""
+
+    def __init__(self, n: int, seed: int = 0, shuffle: bool = True):
+        self.n, self.seed, self.shuffle, self.epoch = n, seed, shuffle, 0
+
+    def __len__(self):
+        return self.n // world_size()
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(self.seed + self.epoch)
+        self.epoch += 1
+        order = torch.randperm(self.n, generator=g).tolist() if self.shuffle else list(range(self.n))
+        R, r = world_size(), rank()
+        return iter(order[r:len(self) * R:R])
+
+
 def barrier() -> None:
     if world_size() > 1:
         if dist.get_backend(_group) == "nccl":     # name the device: no guessing from the rank

@@ -57,8 +57,11 @@ class _PairCapacity:
         the 8 status words are copied asynchronously into pinned memory after every forward and
         polled (never waited for) on later calls — so the buffer tracks the scene with a 2x
         margin and only a frame-to-frame doubling of the pair count can overflow it;
-      * an overflow that still happens is detected on a later poll and raises
-        RasterizerOverflow (policy "raise", default) or warns (policy "warn");
+      * an overflow that still happens is detected on a later poll: by default it WARNS (the capacity
+        has already been raised for the following calls, `overflow_events` counts them — a long run is
+        not aborted by one transient spike; upstream simply resizes); policy "raise" turns it into
+        RasterizerOverflow for callers that would rather stop than apply one step computed from
+        truncated tile lists;
       * forwards that nobody can differentiate (evaluation) and settings.debug are always
         checked synchronously and re-rendered when needed.
     """
@@ -68,7 +71,8 @@ class _PairCapacity:
         self.floor = 1 << 16
         self.seen = {}         # (P, W, H) -> largest pair count seen
         self.stamp = {}        # (P, W, H) -> time of the last status seen
-        self.policy = "raise"
+        self.policy = "warn"
+        self.overflow_events = 0
         self.pending = []      # (event, pinned status, capacity, key)
         self.pool = []
         self.last_status = None
@@ -122,6 +126,7 @@ class _PairCapacity:
             self.pending.pop(0)
             needed, overflow = self._account(host, key)
             if overflow:
+                self.overflow_events += 1
                 msg = (f"rasterizer pair buffer overflow: a forward pass needed {needed} "
                        f"(tile,Gaussian) pairs but had room for {cap}; that frame was rendered "
                        f"from truncated tile lists. Capacity is now raised; to avoid this up front "
@@ -161,6 +166,11 @@ def reset_capacity_history() -> None:
 def check_overflow(block: bool = True) -> None:
     """Resolve outstanding overflow checks (block=True waits for the device)."""
     _capacity.poll(block=block)
+
+
+def overflow_events() -> int:
+    """How many steady-state forward passes were rendered from truncated tile lists so far."""
+    return _capacity.overflow_events
 
 
 def pair_statistics(reset: bool = False):

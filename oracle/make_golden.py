@@ -136,6 +136,99 @@ def make_net():
     np.savez_compressed(os.path.join(OUT, "net_golden.npz"), **save)
 
 
+def fill_state(module, seed):
+    """Deterministic parameters that do not depend on any module's init order: every float entry
+    of the state dict, in sorted key order, is drawn from one seeded generator (weights
+    N(0, 1/fan_in)-ish, BatchNorm weight around 1, running_var positive). tests/ uses the same
+    function (imported from here) to rebuild the state the golden outputs belong to."""
+    g = torch.Generator().manual_seed(seed)
+    sd = module.state_dict()
+    for k in sorted(sd):
+        v = sd[k]
+        if not v.is_floating_point():
+            continue
+        r = torch.randn(v.shape, generator=g)
+        if k.endswith("running_var"):
+            v.copy_(0.5 + r.abs())
+        elif v.dim() == 1 and k.endswith("weight"):          # norm scale
+            v.copy_(1.0 + 0.2 * r)
+        elif v.dim() == 1:                                     # biases, norm shift, running_mean
+            v.copy_(0.1 * r)
+        else:
+            fan_in = v[0].numel()
+            v.copy_(r * (1.5 / fan_in ** 0.5))
+    module.load_state_dict(sd)
+    return module
+
+
+def net_full_inputs():
+    """Seeded inputs of make_net_full (regenerated by the tests instead of being stored)."""
+    B, S_in, S_q = 2, 32, 64
+    g = torch.Generator().manual_seed(22)
+    geom = torch.randn(1, 64, S_in, S_in, generator=g) * 0.5
+    posef = torch.randn(B, 64, S_in, S_in, generator=g) * 0.5
+    w = [torch.randn(B, c, S_q * S_q, generator=g) for c in (3, 1, 3)]
+    x = torch.randn(2, 3, 64, 64, generator=g) * 0.3
+    wy = torch.randn(2, 8, 64, 64, generator=g)
+    r, c = torch.meshgrid(torch.arange(S_q), torch.arange(S_q), indexing="ij")
+    uv = (torch.stack([r.reshape(-1), c.reshape(-1)], 1).float() / (S_q - 1))[None].expand(B, -1, -1).contiguous()
+    return dict(B=B, S_in=S_in, S_q=S_q, geom=geom, posef=posef, w=w, unet_x=x, unet_wy=wy, uv=uv)
+
+
+NET_FULL_KEEP = ["decoder.conv1.weight", "decoder.conv5.weight", "decoder.conv4.bias", "decoder.bn3.weight",
+                 "decoder.bn7.bias", "decoder.conv8.weight", "decoder.conv8SH.weight", "decoder.conv8N.weight",
+                 "decoder.conv7SH.weight", "geom_proc_layers.conv1.weight", "geom_proc_layers.conv3.weight"]
+
+
+def make_net_full():
+    """The reference's POP_no_unet / UnetNoCond5DS at the PRODUCTION widths
+    (arguments/__init__.py:101-111: c_geom 64, c_pose 64, hsize 128, nf 32) — the widths that select the
+    fused MFMA decoder and the fused up-sampling here. Outputs and gradients (the large ones subsampled:
+    every 2nd / 4th channel, first 8 output channels of the 5x5 conv weights); weights by fill_state,
+    inputs by net_full_inputs."""
+    from model.network import POP_no_unet
+    from model.modules import UnetNoCond5DS
+    from utils.general_utils import getIdxMap_torch
+    net = fill_state(POP_no_unet(c_geom=64, geom_layer_type='conv', nf=32, hsize=128, up_mode='upconv',
+                                 use_dropout=False, uv_feat_dim=2), seed=21)
+    net.train()
+    inp = net_full_inputs()
+    B, S_q = inp["B"], inp["S_q"]
+    geom = inp["geom"].requires_grad_(True)
+    posef = inp["posef"].requires_grad_(True)
+    uv = getIdxMap_torch(torch.rand(3, S_q, S_q))[None].expand(B, -1, -1).contiguous()
+    assert torch.equal(uv, inp["uv"])
+    w = inp["w"]
+    save = {}
+    for tag, pf in (("s1", None), ("s2", posef)):
+        net.zero_grad()
+        geom.grad = None
+        posef.grad = None
+        outs = net(pf, geom.expand(B, -1, -1, -1).contiguous(), uv)           # avatar_model.py:298-306
+        loss = sum((o * wi).sum() for o, wi in zip(outs, w))
+        loss.backward()
+        for name, o in zip(("res", "scales", "shs"), outs):
+            save[f"{tag}_{name}"] = o.detach().numpy()
+        save[f"{tag}_dgeom"] = geom.grad[:, ::2].numpy().copy()
+        if pf is not None:
+            save[f"{tag}_dposef"] = posef.grad[:, ::4].numpy().copy()
+        params = dict(net.named_parameters())
+        for k in NET_FULL_KEEP:
+            gk = params[k].grad
+            save[f"{tag}_d.{k}"] = (gk[:8] if k.startswith("geom_proc") else gk).numpy().copy()
+    unet = fill_state(UnetNoCond5DS(input_nc=3, output_nc=64, nf=32, up_mode='upconv', use_dropout=False), seed=23)
+    unet.train()
+    y = unet(inp["unet_x"].clone())
+    (y[:, ::8] * inp["unet_wy"]).sum().backward()
+    up = dict(unet.named_parameters())
+    save.update(unet_y=y[:, ::8].detach().numpy())
+    for k in sorted(up):
+        if up[k].numel() <= 20000:
+            save["unet_d." + k] = up[k].grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "net_full_golden.npz"), **save)
+    print("net_full_golden.npz", os.path.getsize(os.path.join(OUT, "net_full_golden.npz")), len(save), "arrays")
+
+
 def make_camera_loss():
     from utils.graphics_utils import getWorld2View2, getProjectionMatrix, focal2fov, geom_transform_points
     from utils.loss_utils import l1_loss_w, ssim
@@ -259,9 +352,13 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["dataset"]:
         make_dataset()
         sys.exit(0)
+    if sys.argv[1:] == ["net_full"]:
+        make_net_full()
+        sys.exit(0)
     lo = make_lbs()
     make_skin(lo)
     make_net()
+    make_net_full()
     make_camera_loss()
     make_raster()
     make_dataset()

@@ -214,3 +214,59 @@ def test_sh_oracle_matches_autograd_restatement(raster_oracle_f64, deg):
     np.testing.assert_allclose(dsh, st.grad.numpy(), rtol=1e-10, atol=1e-12)
     mg = mt.grad.numpy() if mt.grad is not None else np.zeros((P, 3))   # degree 0 is view-independent
     np.testing.assert_allclose(dmean, mg, rtol=1e-9, atol=1e-11)
+
+
+def _net_full(device="cpu"):
+    from gaussianavatar_amd.network import POP_no_unet, UnetNoCond5DS
+    from oracle.make_golden import fill_state, net_full_inputs
+    net = fill_state(POP_no_unet(c_geom=64, geom_layer_type="conv", nf=32, hsize=128), seed=21).to(device)
+    unet = fill_state(UnetNoCond5DS(3, 64, 32), seed=23).to(device)
+    net.train()
+    unet.train()
+    inp = net_full_inputs()
+    mv = lambda v: [t.to(device) for t in v] if isinstance(v, list) else (v.to(device) if torch.is_tensor(v) else v)
+    return net, unet, {k: mv(v) for k, v in inp.items()}, np.load(os.path.join(GOLD, "net_full_golden.npz"))
+
+
+def check_net_full(device, tol_out=2e-5, tol_grad=2e-4):
+    """POP_no_unet / UnetNoCond5DS at the reference's production widths (c_geom 64, hsize 128, nf 32) against
+    outputs AND gradients of the reference's own modules (oracle/make_golden.py:make_net_full). On a HIP
+    device these widths take the fused MFMA decoder + fused up-sampling path."""
+    from oracle.make_golden import NET_FULL_KEEP
+    net, unet, inp, n = _net_full(device)
+    B = inp["B"]
+    rel = lambda got, ref: float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
+    for tag in ("s1", "s2"):
+        geom = inp["geom"].clone().requires_grad_(True)
+        posef = inp["posef"].clone().requires_grad_(True)
+        net.zero_grad()
+        outs = net(posef if tag == "s2" else None, geom.expand(B, -1, -1, -1).contiguous(), inp["uv"])
+        for o, key in zip(outs, ("res", "scales", "shs")):
+            assert rel(o.detach().cpu().numpy(), n[f"{tag}_{key}"]) <= tol_out, (tag, key)
+        sum((o * w).sum() for o, w in zip(outs, inp["w"])).backward()
+        assert rel(geom.grad[:, ::2].cpu().numpy(), n[f"{tag}_dgeom"]) <= tol_grad, tag
+        if tag == "s2":
+            assert rel(posef.grad[:, ::4].cpu().numpy(), n["s2_dposef"]) <= tol_grad
+        params = dict(net.named_parameters())
+        # a conv bias in front of BatchNorm has zero gradient in exact arithmetic: compare those on the
+        # scale of the layer's weight gradient instead of their own (noise) scale
+        for k in NET_FULL_KEEP:
+            g = params[k].grad.detach().cpu().numpy()
+            g = g[:8] if k.startswith("geom_proc") else g
+            ref = n[f"{tag}_d.{k}"]
+            scale = np.abs(ref).max()
+            if k.endswith("conv4.bias"):
+                scale = max(scale, float(params["decoder.conv4.weight"].grad.abs().max()))
+            assert np.abs(g - ref).max() <= tol_grad * scale, (tag, k, np.abs(g - ref).max(), scale)
+    y = unet(inp["unet_x"].clone())
+    assert rel(y[:, ::8].detach().cpu().numpy(), n["unet_y"]) <= tol_out
+    (y[:, ::8] * inp["unet_wy"]).sum().backward()
+    up = dict(unet.named_parameters())
+    for k in n.files:
+        if k.startswith("unet_d."):
+            g = up[k[7:]].grad.detach().cpu().numpy()
+            assert np.abs(g - n[k]).max() <= tol_grad * max(np.abs(n[k]).max(), 1e-3), k
+
+
+def test_production_width_nets_match_reference_outputs_and_grads():
+    check_net_full("cpu")

@@ -86,3 +86,38 @@ def test_two_rank_exchange_equals_single_process_global_batch():
     torch.testing.assert_close(e, r1["emb"])
     assert (e[:4] != 0).all() and (e[4:] == 0).all()
     torch.testing.assert_close(e[0], torch.tensor([0.5, 1.0, 1.5]))
+
+
+def _worker_sync(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from gaussianavatar_amd import parallel
+    from gaussianavatar_amd.network import POP_no_unet
+    parallel.init_from_env(backend="gloo")
+    torch.manual_seed(100 + rank)             # replicas start DIFFERENT (no hand-synchronised seeds)
+    net = POP_no_unet(c_geom=8, hsize=16)
+    with torch.no_grad():
+        net.decoder.bn3.running_mean.add_(rank + 1.0)
+    geo = torch.randn(1, 8, 4, 4)
+    parallel.broadcast_state([net], [geo])
+    sampler = parallel.ShardedSampler(11, seed=3)
+    epochs = [list(sampler) for _ in range(3)]
+    out[rank] = dict(state={k: v.clone() for k, v in net.state_dict().items()}, geo=geo, epochs=epochs, n=len(sampler))
+    parallel.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_replicas_are_synchronised_and_frames_are_sharded():
+    """Advisor finding r1: replicas must not depend on equal seeds, ranks must not draw the same frames."""
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_worker_sync, args=(world, _free_port(), out), nprocs=world, join=True)
+    a, b = out[0], out[1]
+    for k in a["state"]:
+        assert torch.equal(a["state"][k], b["state"][k]), k
+    assert torch.equal(a["geo"], b["geo"])
+    assert a["n"] == b["n"] == 5
+    for e0, e1 in zip(a["epochs"], b["epochs"]):
+        assert len(e0) == len(e1) == 5 and not set(e0) & set(e1)         # disjoint slices of one permutation
+    assert a["epochs"][0] != a["epochs"][1]                               # reshuffled every epoch

@@ -137,8 +137,21 @@ def test_overflow_is_flagged_and_recovered(raster_oracle):
         color, radii = R.GaussianRasterizer(rs)(
             means3D=t["means3D"], means2D=None, opacities=t["opacities"], colors_precomp=t["colors"],
             scales=t["scales"], rotations=t["rotations"])
-        with pytest.raises(R.RasterizerOverflow):
+        n_events = R.overflow_events()
+        with pytest.warns(UserWarning, match="pair buffer overflow"):      # default policy: warn, keep running
             R.check_overflow(block=True)
+        assert R.overflow_events() == n_events + 1
+        # policy "raise" for callers that prefer to stop
+        R._capacity.seen[key] = 10
+        R._capacity.stamp[key] = __import__("time").monotonic()
+        R.set_pair_capacity(on_overflow="raise")
+        try:
+            R.GaussianRasterizer(rs)(means3D=t["means3D"], means2D=None, opacities=t["opacities"],
+                                     colors_precomp=t["colors"], scales=t["scales"], rotations=t["rotations"])
+            with pytest.raises(R.RasterizerOverflow):
+                R.check_overflow(block=True)
+        finally:
+            R.set_pair_capacity(on_overflow="warn")
         # ... after which the capacity has adapted
         color, radii = R.GaussianRasterizer(rs)(
             means3D=t["means3D"], means2D=None, opacities=t["opacities"], colors_precomp=t["colors"],
