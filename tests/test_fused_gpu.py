@@ -566,3 +566,28 @@ def test_one_launch_adam_matches_torch_adam():
         p.grad = torch.ones_like(p)
     oa3.step()
     assert float(oa3.state_dict()["state"][0]["step"]) == 2.0
+
+
+def test_production_width_nets_match_reference_on_the_fused_path():
+    """The reference's own POP_no_unet / UnetNoCond5DS at c_geom 64 / hsize 128 / nf 32 (golden outputs AND
+    gradients, oracle/make_golden.py:make_net_full) against the HIP path these widths select: fused
+    up-sampling + fused fp32-MFMA decoder (stage-1 and stage-2 call patterns)."""
+    from gaussianavatar_amd import fused
+    from gaussianavatar_amd.network import POP_no_unet
+    from tests.test_oracle_golden import check_net_full
+    probe = POP_no_unet(c_geom=64, hsize=128).cuda()
+    assert fused.decoder_supported(probe.decoder, torch.empty(8, 66, device="cuda"))
+    check_net_full("cuda", tol_out=1e-4, tol_grad=2e-3)
+
+
+def test_l1_ssim_pair_cache_respects_grad_mode():
+    """Advisor finding r1: a value parked under no_grad must not answer a call that wants gradients."""
+    from gaussianavatar_amd.losses import l1_loss_w, ssim
+    img = torch.rand(1, 3, 64, 64, device="cuda", requires_grad=True)
+    gt = torch.rand(1, 3, 64, 64, device="cuda")
+    with torch.no_grad():
+        l1_loss_w(img, gt)                      # logging-style call; parks the SSIM value without a graph
+    s = ssim(img, gt)
+    assert s.requires_grad
+    s.backward()
+    assert img.grad is not None and float(img.grad.abs().sum()) > 0
