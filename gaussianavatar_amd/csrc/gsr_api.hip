@@ -81,6 +81,10 @@ int compute_layout(int P, int W, int H, int64_t max_pairs, GsrLayout* out) {
   out->n_contrib = take(npix * 4);
   out->grad_acc = take(Pn * GSR_GRAD_STRIDE * 4);
   out->status = take(8 * 4);
+  out->seg_entries = take((uint64_t)d.seg_cap * GSR_WAVE * 8);
+  out->seg_ckpt = take((uint64_t)d.seg_cap * GSR_SEG_PIX * 16);
+  out->seg_info = take((uint64_t)d.seg_cap * 8);
+  out->pix_accum = take(npix * 16);
   out->total_bytes = off;
   return 0;
 }
@@ -106,6 +110,10 @@ Workspace resolve(void* base, const GsrLayout& L) {
   w.n_contrib = reinterpret_cast<uint32_t*>(b + L.n_contrib);
   w.grad_acc = reinterpret_cast<float*>(b + L.grad_acc);
   w.status = reinterpret_cast<int32_t*>(b + L.status);
+  w.seg_entries = reinterpret_cast<uint2*>(b + L.seg_entries);
+  w.seg_ckpt = reinterpret_cast<float4*>(b + L.seg_ckpt);
+  w.seg_info = reinterpret_cast<uint2*>(b + L.seg_info);
+  w.pix_accum = reinterpret_cast<float4*>(b + L.pix_accum);
   return w;
 }
 
@@ -380,18 +388,18 @@ int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,
 }
 
 namespace {
-// [max pairs of a frame, any overflow, sum of word 2, longest tile list, total pairs, frames, max 6, max 7]
+// [max pairs of a frame, any overflow, max segments of a frame, longest tile list, total pairs, frames, max 6, max 7]
 __global__ void batch_status_kernel(const char* ws, size_t status_off, size_t ws_stride, int frames,
                                     int32_t* out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  int64_t total = 0, s2 = 0;
-  int32_t mx0 = 0, mx1 = 0, mx3 = 0, mx6 = 0, mx7 = 0;
+  int64_t total = 0;
+  int32_t mx0 = 0, mx1 = 0, mx2 = 0, mx3 = 0, mx6 = 0, mx7 = 0;
   for (int f = 0; f < frames; ++f) {
     const int32_t* st = reinterpret_cast<const int32_t*>(ws + (size_t)f * ws_stride + status_off);
-    mx0 = max(mx0, st[0]); mx1 = max(mx1, st[1]); s2 += st[2]; mx3 = max(mx3, st[3]);
+    mx0 = max(mx0, st[0]); mx1 = max(mx1, st[1]); mx2 = max(mx2, st[2]); mx3 = max(mx3, st[3]);
     total += st[0]; mx6 = max(mx6, st[6]); mx7 = max(mx7, st[7]);
   }
-  out[0] = mx0; out[1] = mx1; out[2] = (int32_t)s2; out[3] = mx3;
+  out[0] = mx0; out[1] = mx1; out[2] = mx2; out[3] = mx3;
   out[4] = (int32_t)(total > 0x7fffffff ? 0x7fffffff : total); out[5] = frames; out[6] = mx6; out[7] = mx7;
 }
 }  // namespace

@@ -8,8 +8,9 @@
 //   K3 scatter         per Gaussian : append (depth_bits<<32 | index) to each touched tile
 //   K4 tile_sort       per tile     : sort the tile's keys in LDS (bitonic; merge passes
 //                                     through HBM for lists that do not fit) -> point_list
-//   K5 render_fwd      per tile     : front-to-back alpha compositing, LDS-staged lists
-//   K6 render_bwd      per tile     : back-to-front re-traversal, wave-reduced gradients
+//   K5 render_fwd      per 4x4 block: cull the tile list, blend 64 survivors at a time (entry-parallel,
+//                                     DPP wave scans); records the consumed segments
+//   K6 render_bwd      per segment  : forward-order gradients, per-entry sums in registers
 //   K7 preprocess_bwd  per Gaussian : screen-space grads -> means3D / scales / rotations
 //
 // Behavioural spec: SURVEY.md Appendix A (the reference's rasterizer is the un-vendored
@@ -25,14 +26,26 @@
 
 #define GSR_TILE_PIX (GSR_TILE * GSR_TILE)   // 256 threads per tile = 4 wave64
 #define GSR_WAVE 64
-#define GSR_GRAD_STRIDE 12                   // floats per Gaussian in grad_acc
+#define GSR_GRAD_STRIDE 16                   // floats per Gaussian in grad_acc: one 64-byte line per record, so a
+                                             // wave's 9 atomics on a Gaussian touch exactly one line
+#define GSR_SEG_PIX 16                       // pixels of a render block (4x4) = checkpoints per segment
+#define GSR_BWD_BLOCKS 2048                  // persistent workgroups of render_bwd (256 CUs x 8)
 
 namespace gsr {
 
 struct Dims {
   int P, W, H, gx, gy, T;
   int64_t max_pairs;
+  int seg_cap;        // capacity of the forward pass's segment records (see seg_capacity)
 };
+
+// Segments (64 survivors of one 4x4 block) the forward pass may record: the exact bound is
+// 16*D/64 + 16*T (every Gaussian of a tile surviving in all 16 blocks); sized for ~4 surviving blocks per
+// (tile, Gaussian) pair on average (avatar scenes measure 1.5-2.5), overflow is reported through status[1].
+inline int seg_capacity(int T, int64_t max_pairs) {
+  const int64_t c = max_pairs / 16 + 16 * (int64_t)T;
+  return (int)(c > 0x3fffffff ? 0x3fffffff : c);
+}
 
 inline Dims make_dims(int P, int W, int H, int64_t max_pairs) {
   Dims d;
@@ -41,6 +54,7 @@ inline Dims make_dims(int P, int W, int H, int64_t max_pairs) {
   d.gy = (H + GSR_TILE - 1) / GSR_TILE;
   d.T = d.gx * d.gy;
   d.max_pairs = max_pairs;
+  d.seg_cap = seg_capacity(d.T, max_pairs);
   return d;
 }
 
@@ -64,6 +78,10 @@ struct Workspace {
   uint32_t* n_contrib;
   float* grad_acc;
   int32_t* status;
+  uint2* seg_entries;
+  float4* seg_ckpt;
+  uint2* seg_info;
+  float4* pix_accum;
 };
 
 // Batched launches: blockIdx.y = frame. Element strides between frames (0 = shared by all
@@ -79,6 +97,7 @@ __host__ __device__ inline Workspace frame_ws(Workspace w, size_t bytes) {
   mv(w.depth); mv(w.xy); mv(w.conic_opacity); mv(w.rgb); mv(w.cov3d); mv(w.rect); mv(w.tiles_touched);
   mv(w.clamped); mv(w.tile_count); mv(w.tile_offset); mv(w.tile_cursor); mv(w.pair_key);
   mv(w.point_list); mv(w.pair_tmp); mv(w.final_T); mv(w.n_contrib); mv(w.grad_acc); mv(w.status);
+  mv(w.seg_entries); mv(w.seg_ckpt); mv(w.seg_info); mv(w.pix_accum);
   return w;
 }
 

@@ -109,7 +109,11 @@ class _PairCapacity:
         needed, overflow = int(host[0]), int(host[1])
         self.last_status = host.tolist()
         self.pool.append(host)
-        self.seen[key] = max(self.seen.get(key, 0), needed)
+        # the forward pass also records segments for the backward pass (status[2]; capacity
+        # max_pairs/16 + 16*tiles): express their demand as the pair capacity that would hold them
+        tiles = ((key[1] + 15) // 16) * ((key[2] + 15) // 16)
+        seg_pairs = 16 * max(0, int(host[2]) - 16 * tiles)
+        self.seen[key] = max(self.seen.get(key, 0), needed, seg_pairs)
         self.stamp[key] = time.monotonic()
         frames = int(host[5]) if int(host[5]) > 0 else 1          # batched launches report totals
         self.pairs_sum += int(host[4]) if int(host[5]) > 0 else needed
@@ -248,6 +252,7 @@ def workspace_views(workspace: torch.Tensor, P: int, W: int, H: int, max_pairs: 
     L = _native.GsrLayout()
     _native.gsr_check(lib.gsr_workspace_layout(P, W, H, max_pairs, ctypes.byref(L)))
     T = ((W + 15) // 16) * ((H + 15) // 16)
+    S = max_pairs // 16 + 16 * T                 # segment capacity (gsr_common.h: seg_capacity)
 
     def view(off, nbytes, dtype, shape):
         return workspace[off:off + nbytes].view(dtype).reshape(shape)
@@ -265,8 +270,12 @@ def workspace_views(workspace: torch.Tensor, P: int, W: int, H: int, max_pairs: 
         point_list=view(L.point_list, max_pairs * 4, torch.int32, (max_pairs,)),
         final_T=view(L.final_T, W * H * 4, torch.float32, (H * W,)),
         n_contrib=view(L.n_contrib, W * H * 4, torch.int32, (H * W,)),
-        grad_acc=view(L.grad_acc, P * 48, torch.float32, (P, 12)),
+        grad_acc=view(L.grad_acc, P * 64, torch.float32, (P, 16)),
         status=view(L.status, 32, torch.int32, (8,)),
+        seg_entries=view(L.seg_entries, S * 512, torch.int32, (S, 64, 2)),
+        seg_ckpt=view(L.seg_ckpt, S * 256, torch.float32, (S, 16, 4)),
+        seg_info=view(L.seg_info, S * 8, torch.int32, (S, 2)),
+        pix_accum=view(L.pix_accum, W * H * 16, torch.float32, (H * W, 4)),
     )
 
 

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 2
+#define GSR_ABI_VERSION 3
 #define GSR_TILE 16              /* tile edge in pixels (BLOCK_X = BLOCK_Y = 16)       */
 #define GSR_NUM_CHANNELS 3
 
@@ -93,10 +93,18 @@ typedef struct GsrLayout {
   uint64_t final_T;        /* float   [H*W]                                                 */
   uint64_t n_contrib;      /* uint32  [H*W]                                                 */
   /* backward scratch: per-Gaussian screen-space gradient accumulators */
-  uint64_t grad_acc;       /* float   [P,12] (dxy2, dconic3, dopac1, drgb3, pad3)           */
+  uint64_t grad_acc;       /* float   [P,16] (dxy2, dconic3, dopac1, drgb3, pad7): one 64-byte line each */
   /* status words */
-  uint64_t status;         /* int32   [8]  [0]=pairs needed (D) [1]=overflow flag
-                                           [2]=visible Gaussians [3]=max pairs in one tile  */
+  uint64_t status;         /* int32   [8]  [0]=pairs needed (D) [1]=overflow flag (pairs or segments)
+                                           [2]=segments recorded by the forward pass
+                                           [3]=max pairs in one tile                         */
+  /* what the forward pass consumed, for the segment-parallel backward pass: S = max_pairs/16 + 16*T
+   * segments of up to 64 list entries that survived the cull of one 4x4 pixel block */
+  uint64_t seg_entries;    /* uint32  [S,64,2] (Gaussian index, position in the tile's list)  */
+  uint64_t seg_ckpt;       /* float   [S,16,4] (T, C.rgb) of the block's pixels at the segment's start */
+  uint64_t seg_info;       /* uint32  [S,2]    (block x0 | y0<<16, entries in the segment)    */
+  uint64_t pix_accum;      /* float   [H*W,4]  (C.rgb without background, final T); written for blocks
+                                              with at least one segment                      */
 } GsrLayout;
 
 /* Size in bytes of the workspace for P Gaussians, a W x H image and room for

@@ -16,7 +16,7 @@ m = AvatarModel(mp, npar, op, train=True)
 batch = collate_frames([m.train_dataset[0]], "cuda")
 with torch.no_grad():
     live = m._body(m.pose.weight[:1], m.transl.weight[:1], None)
-    res_all, point_res, scales, colors = m._decode(1, None, 7, True)
+    _off, _scl, point_res, scales, colors = m._decode(1, None, 7, True)
     pts = skin(m.query_points[:1], point_res, m.query_lbs[0], live.cano2live)[0].contiguous()
     scales, colors = scales[0].contiguous(), colors[0].contiguous()
 pts.requires_grad_(True); scales.requires_grad_(True); colors.requires_grad_(True)
