@@ -44,7 +44,7 @@ class GsrBatch(ctypes.Structure):
 _LAYOUT_FIELDS = ["total_bytes", "depth", "xy", "conic_opacity", "rgb", "cov3d", "rect",
                   "tiles_touched", "clamped", "tile_count", "tile_offset", "tile_cursor",
                   "pair_key", "point_list", "pair_tmp", "final_T", "n_contrib", "grad_acc", "status",
-                  "seg_entries", "seg_ckpt", "seg_info", "pix_accum"]
+                  "seg_counters", "xyext", "seg_entries", "seg_ckpt", "seg_info", "pix_accum"]
 
 
 class GsrLayout(ctypes.Structure):

@@ -81,6 +81,8 @@ int compute_layout(int P, int W, int H, int64_t max_pairs, GsrLayout* out) {
   out->n_contrib = take(npix * 4);
   out->grad_acc = take(Pn * GSR_GRAD_STRIDE * 4);
   out->status = take(8 * 4);
+  out->seg_counters = take(GSR_SEG_COUNTERS * GSR_SEG_COUNTER_STRIDE * 4);     // directly behind status: one clear
+  out->xyext = take(Pn * 16);
   out->seg_entries = take((uint64_t)d.seg_cap * GSR_WAVE * 8);
   out->seg_ckpt = take((uint64_t)d.seg_cap * GSR_SEG_PIX * 16);
   out->seg_info = take((uint64_t)d.seg_cap * 8);
@@ -110,6 +112,8 @@ Workspace resolve(void* base, const GsrLayout& L) {
   w.n_contrib = reinterpret_cast<uint32_t*>(b + L.n_contrib);
   w.grad_acc = reinterpret_cast<float*>(b + L.grad_acc);
   w.status = reinterpret_cast<int32_t*>(b + L.status);
+  w.seg_counters = reinterpret_cast<int32_t*>(b + L.seg_counters);
+  w.xyext = reinterpret_cast<float4*>(b + L.xyext);
   w.seg_entries = reinterpret_cast<uint2*>(b + L.seg_entries);
   w.seg_ckpt = reinterpret_cast<float4*>(b + L.seg_ckpt);
   w.seg_info = reinterpret_cast<uint2*>(b + L.seg_info);
@@ -290,7 +294,7 @@ int gsr_forward_batch(const GsrSettings* s, const GsrBatch* batch, int32_t P, co
   // tile_count .. tile_cursor are contiguous in the layout: one launch clears the histogram and the
   // status words of every frame
   if ((rc = check_hip(clear_frames(workspace, bt.ws_stride, bt.frames, stream, ws.tile_count,
-                                   L.tile_cursor - L.tile_count, ws.status, 8 * sizeof(int32_t)),
+                                   L.tile_cursor - L.tile_count, ws.status, (size_t)(L.xyext - L.status)),
                       "clear tile_count/status")))
     return rc;
   if ((rc = check_hip(launch_preprocess(*s, d, means3D, colors_precomp, opacities, scales,

@@ -30,6 +30,10 @@
                                              // wave's 9 atomics on a Gaussian touch exactly one line
 #define GSR_SEG_PIX 16                       // pixels of a render block (4x4) = checkpoints per segment
 #define GSR_BWD_BLOCKS 2048                  // persistent workgroups of render_bwd (256 CUs x 8)
+#define GSR_SEG_COUNTERS 64                  // segment slots are handed out by 64 counters on separate 256-byte
+                                             // lines: 20k returning atomics on ONE address serialise at ~9-11 ns
+                                             // each (measured 200 us per frame), on one LINE barely better
+#define GSR_SEG_COUNTER_STRIDE 64            // int32 words between counters
 
 namespace gsr {
 
@@ -39,9 +43,10 @@ struct Dims {
   int seg_cap;        // capacity of the forward pass's segment records (see seg_capacity)
 };
 
-// Segments (64 survivors of one 4x4 block) the forward pass may record: the exact bound is
-// 16*D/64 + 16*T (every Gaussian of a tile surviving in all 16 blocks); sized for ~4 surviving blocks per
-// (tile, Gaussian) pair on average (avatar scenes measure 1.5-2.5), overflow is reported through status[1].
+// Segment slots (64 survivors of one 4x4 block each) the forward pass may record. The exact bound is
+// 16*D/64 (every list entry surviving in all 16 blocks) plus a partial segment per block; sized for ~4
+// surviving blocks per (tile, Gaussian) pair on average (avatar scenes measure 1.5-2.5); running out is
+// reported through status[1] like a pair-buffer overflow.
 inline int seg_capacity(int T, int64_t max_pairs) {
   const int64_t c = max_pairs / 16 + 16 * (int64_t)T;
   return (int)(c > 0x3fffffff ? 0x3fffffff : c);
@@ -62,6 +67,7 @@ inline Dims make_dims(int P, int W, int H, int64_t max_pairs) {
 struct Workspace {
   float* depth;
   float2* xy;
+  float4* xyext;
   float4* conic_opacity;
   float4* rgb;
   float* cov3d;
@@ -78,6 +84,7 @@ struct Workspace {
   uint32_t* n_contrib;
   float* grad_acc;
   int32_t* status;
+  int32_t* seg_counters;
   uint2* seg_entries;
   float4* seg_ckpt;
   uint2* seg_info;
@@ -94,11 +101,26 @@ struct Batch {
 
 __host__ __device__ inline Workspace frame_ws(Workspace w, size_t bytes) {
   auto mv = [bytes](auto*& p) { p = reinterpret_cast<std::remove_reference_t<decltype(p)>>(reinterpret_cast<char*>(p) + bytes); };
-  mv(w.depth); mv(w.xy); mv(w.conic_opacity); mv(w.rgb); mv(w.cov3d); mv(w.rect); mv(w.tiles_touched);
+  mv(w.depth); mv(w.xy); mv(w.xyext); mv(w.conic_opacity); mv(w.rgb); mv(w.cov3d); mv(w.rect); mv(w.tiles_touched);
   mv(w.clamped); mv(w.tile_count); mv(w.tile_offset); mv(w.tile_cursor); mv(w.pair_key);
-  mv(w.point_list); mv(w.pair_tmp); mv(w.final_T); mv(w.n_contrib); mv(w.grad_acc); mv(w.status);
+  mv(w.point_list); mv(w.pair_tmp); mv(w.final_T); mv(w.n_contrib); mv(w.grad_acc); mv(w.status); mv(w.seg_counters);
   mv(w.seg_entries); mv(w.seg_ckpt); mv(w.seg_info); mv(w.pix_accum);
   return w;
+}
+
+// Half extents of the axis-aligned box around the region where Gaussian (conic A,B,C, opacity o) reaches
+// alpha >= 1/255:  alpha >= 1/255  <=>  d^T Q d <= tau, tau = 2 ln(255 o); the box of that ellipse has
+// half extents sqrt(tau Sigma_xx), sqrt(tau Sigma_yy) with Sigma = Q^-1. Slightly inflated (conservative);
+// a Gaussian that can never reach 1/255 gets a negative extent (outside every box), NaN means "keep".
+// Written once per Gaussian by K1 (xyext = centre + extents), consumed by the render kernels' culling.
+__device__ __forceinline__ float2 alpha_extent(float4 co) {
+  const float tau = 2.0f * logf(255.0f * co.w) + 1e-3f;
+  const float det = co.x * co.z - co.y * co.y;
+  const float inv = 1.0f / det;
+  float hx = sqrtf(tau * co.z * inv) * 1.001f + 0.01f;
+  float hy = sqrtf(tau * co.x * inv) * 1.001f + 0.01f;
+  if (tau < 0.0f) hx = hy = -1e30f;
+  return make_float2(hx, hy);
 }
 
 int compute_layout(int P, int W, int H, int64_t max_pairs, GsrLayout* out);

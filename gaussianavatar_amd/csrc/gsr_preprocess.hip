@@ -171,6 +171,10 @@ preprocess_kernel(int P, int W, int H, int gx, int gy, float tanfovx, float tanf
   ws.depth[i] = depth;
   ws.xy[i] = xy;
   ws.conic_opacity[i] = co;
+  {
+    const float2 ext = alpha_extent(co);
+    ws.xyext[i] = make_float4(xy.x, xy.y, ext.x, ext.y);
+  }
   ws.rect[i] = rc;
   ws.tiles_touched[i] = ntiles;
   // per-tile histogram of pairs (consumed by K2/K3). Neighbouring Gaussians (adjacent UV

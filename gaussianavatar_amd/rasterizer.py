@@ -105,7 +105,7 @@ class _PairCapacity:
         ev.record()
         self.pending.append((ev, host, cap, key))
 
-    def _account(self, host, key):
+    def _account(self, host, key, cap=None):
         needed, overflow = int(host[0]), int(host[1])
         self.last_status = host.tolist()
         self.pool.append(host)
@@ -114,6 +114,10 @@ class _PairCapacity:
         tiles = ((key[1] + 15) // 16) * ((key[2] + 15) // 16)
         seg_pairs = 16 * max(0, int(host[2]) - 16 * tiles)
         self.seen[key] = max(self.seen.get(key, 0), needed, seg_pairs)
+        if overflow and cap is not None:
+            # e.g. one slot range of the segment records ran full while the totals still fit: whatever
+            # overflowed, the next capacity (2 x seen) must be larger than the one that was too small
+            self.seen[key] = max(self.seen[key], int(cap))
         self.stamp[key] = time.monotonic()
         frames = int(host[5]) if int(host[5]) > 0 else 1          # batched launches report totals
         self.pairs_sum += int(host[4]) if int(host[5]) > 0 else needed
@@ -128,7 +132,7 @@ class _PairCapacity:
                 break
             ev.synchronize()
             self.pending.pop(0)
-            needed, overflow = self._account(host, key)
+            needed, overflow = self._account(host, key, cap)
             if overflow:
                 self.overflow_events += 1
                 msg = (f"rasterizer pair buffer overflow: a forward pass needed {needed} "
@@ -143,7 +147,7 @@ class _PairCapacity:
         """Synchronously resolve the newest pending copy WITHOUT raising; returns (needed, overflow)."""
         ev, host, cap, key = self.pending.pop()
         ev.synchronize()
-        return self._account(host, key)
+        return self._account(host, key, cap)
 
 
 _capacity = _PairCapacity()
@@ -252,7 +256,7 @@ def workspace_views(workspace: torch.Tensor, P: int, W: int, H: int, max_pairs: 
     L = _native.GsrLayout()
     _native.gsr_check(lib.gsr_workspace_layout(P, W, H, max_pairs, ctypes.byref(L)))
     T = ((W + 15) // 16) * ((H + 15) // 16)
-    S = max_pairs // 16 + 16 * T                 # segment capacity (gsr_common.h: seg_capacity)
+    S = max_pairs // 16 + 16 * T                 # segment slots (gsr_common.h: seg_capacity)
 
     def view(off, nbytes, dtype, shape):
         return workspace[off:off + nbytes].view(dtype).reshape(shape)

@@ -95,9 +95,11 @@ typedef struct GsrLayout {
   /* backward scratch: per-Gaussian screen-space gradient accumulators */
   uint64_t grad_acc;       /* float   [P,16] (dxy2, dconic3, dopac1, drgb3, pad7): one 64-byte line each */
   /* status words */
-  uint64_t status;         /* int32   [8]  [0]=pairs needed (D) [1]=overflow flag (pairs or segments)
-                                           [2]=segments recorded by the forward pass
-                                           [3]=max pairs in one tile                         */
+  uint64_t status;         /* int32   [8]  [0]=pairs needed (D) [1]=overflow flag (pairs or segment slots)
+                                           [2]=segment slots the forward pass allocated
+                                           [3]=max pairs in one tile                          */
+  uint64_t seg_counters;   /* int32   [64,64] slot counters of the segment records (word 0 of each row)  */
+  uint64_t xyext;          /* float4  [P]    (pixel-space centre, half extents of the alpha>=1/255 box) */
   /* what the forward pass consumed, for the segment-parallel backward pass: S = max_pairs/16 + 16*T
    * segments of up to 64 list entries that survived the cull of one 4x4 pixel block */
   uint64_t seg_entries;    /* uint32  [S,64,2] (Gaussian index, position in the tile's list)  */

@@ -123,7 +123,8 @@ def test_overflow_is_flagged_and_recovered(raster_oracle):
                 means3D=t["means3D"], means2D=None, opacities=t["opacities"], colors_precomp=t["colors"],
                 scales=t["scales"], rotations=t["rotations"])
         assert np.abs(color.cpu().numpy() - ref["color"]).mean() <= IMG_L1_TOL
-        assert R._capacity.seen[key] == ref["D"]
+        # the history holds the pair count, or the pair capacity the recorded segments asked for if larger
+        assert R._capacity.seen[key] >= ref["D"] and R.last_status()[0] == ref["D"]
         # training mode, first call for an unknown shape: also exact (one-time synchronous check)
         R._capacity.seen.pop(key, None)
         t = scene_tensors(sc, requires_grad=True)
