@@ -248,46 +248,63 @@ render_fwd_kernel(int W, int H, int gx, int T, int64_t max_pairs, int seg_cap, c
 
   if (n > 0 && alive) {
     const uint32_t* plist = point_list + start;
-    // software pipeline over batches of 64 list entries: indices two batches ahead, records one ahead
-    uint32_t idx_cur = plist[min(lane, n - 1)];
-    float4 cur_xe = xyext[idx_cur];
-    uint32_t idx_nxt = plist[min(GSR_WAVE + lane, n - 1)];
+    // Software pipeline. Culling walks the list in batches of 64: indices three batches ahead, their
+    // (centre, extent) records two ahead. A segment is FORMED (64 survivors leave the LDS ring, their
+    // records and a record slot are requested) one step before it is BLENDED; the cull of the next batch
+    // runs in between, so neither the gathers nor the returning atomic are waited for.
+    uint32_t idx0 = plist[min(lane, n - 1)];
+    uint32_t idx1 = plist[min(GSR_WAVE + lane, n - 1)];
+    uint32_t idx2 = plist[min(2 * GSR_WAVE + lane, n - 1)];
+    float4 xe0 = xyext[idx0];
+    float4 xe1 = xyext[idx1];
     int b0 = 0, head = 0, count = 0;
-    bool more = true;
-    while (alive && (more || count > 0)) {
-      while (more && count < GSR_WAVE) {
-        const bool keep = (b0 + lane < n) && ((flags & 4) || may_touch(cur_xe, fbx, fby));
+    bool more = true, pending = false;
+    // the pending segment
+    int take = 0, e_k = 0, cidx = 0, cr = 0;
+    uint32_t e_idx = 0;
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f), co = c, col = c, ckpt = c;
+    while (true) {
+      if (!pending && (count >= GSR_WAVE || (!more && count > 0))) {
+        // LDS traffic of one wave is ordered; no workgroup barrier needed for a wave-private slice
+        __builtin_amdgcn_wave_barrier();
+        take = min(count, GSR_WAVE);
+        const int slot_l = (head + lane) & (RING - 1);
+        e_idx = lane < take ? s_idx[wave][slot_l] : 0u;
+        e_k = lane < take ? s_k[wave][slot_l] : 0x7fffffff;
+        c = xyext[e_idx];          // .xy = centre (records of the 64 survivors: L2-resident gathers)
+        co = conic_opacity[e_idx];
+        col = rgb[e_idx];
+        head = (head + take) & (RING - 1);
+        count -= take;
+        __builtin_amdgcn_wave_barrier();
+        // a slot for the segment's record: the returning atomic flies while the next batch is culled
+        cr = seg_counter_of(xcd, wave + recorded + jb);
+        cidx = 0;
+        if (!(flags & 2) && lane == 0) cidx = atomicAdd(seg_counter(seg_counters, cr), 1);
+        ckpt = make_float4(vT, vC0, vC1, vC2);      // the pixels' state at the segment's start
+        pending = true;
+      }
+      if (more && count < GSR_WAVE) {
+        const bool keep = (b0 + lane < n) && ((flags & 4) || may_touch(xe0, fbx, fby));
         const unsigned long long mask = __ballot(keep);
         if (keep) {
           const int pos = (head + count + lane_rank(mask)) & (RING - 1);
-          s_idx[wave][pos] = idx_cur;
+          s_idx[wave][pos] = idx0;
           s_k[wave][pos] = b0 + lane;
         }
         count += __popcll(mask);
         b0 += GSR_WAVE;
         more = b0 < n;
-        idx_cur = idx_nxt;
-        cur_xe = xyext[idx_nxt];
-        idx_nxt = plist[min(b0 + GSR_WAVE + lane, n - 1)];
+        idx0 = idx1; xe0 = xe1;
+        idx1 = idx2; xe1 = xyext[idx2];
+        idx2 = plist[min(b0 + 2 * GSR_WAVE + lane, n - 1)];
       }
-      // LDS traffic of one wave is ordered; no workgroup barrier needed for a wave-private slice
-      __builtin_amdgcn_wave_barrier();
-      const int take = min(count, GSR_WAVE);
+      if (!pending) {
+        if (!more && count == 0) break;
+        continue;
+      }
+      pending = false;
       const bool valid = lane < take;
-      const int slot_l = (head + lane) & (RING - 1);
-      const uint32_t e_idx = valid ? s_idx[wave][slot_l] : 0u;
-      const int e_k = valid ? s_k[wave][slot_l] : 0x7fffffff;
-      const float4 c = xyext[e_idx];          // .xy = centre (records of the 64 survivors: L2-resident gathers)
-      const float4 co = conic_opacity[e_idx];
-      const float4 col = rgb[e_idx];
-      head = (head + take) & (RING - 1);
-      count -= take;
-      __builtin_amdgcn_wave_barrier();
-      // a slot for the segment's record: the returning atomic flies while the pixels are processed
-      int cidx = 0;
-      const int cr = seg_counter_of(xcd, wave + recorded + jb);
-      if (!(flags & 2) && lane == 0) cidx = atomicAdd(seg_counter(seg_counters, cr), 1);
-      const float4 ckpt = make_float4(vT, vC0, vC1, vC2);      // the pixels' state at the segment's start
 #pragma unroll
       for (int p = 0; p < NPIX; ++p) {
         if (flags & 8) break;
@@ -337,6 +354,7 @@ render_fwd_kernel(int W, int H, int gx, int T, int64_t max_pairs, int seg_cap, c
           status[1] = 1;      // the backward pass would miss this segment: report as overflow
         }
       }
+      if (!alive) break;
     }
   }
   if (pix_lane) {
@@ -353,6 +371,11 @@ render_fwd_kernel(int W, int H, int gx, int T, int64_t max_pairs, int seg_cap, c
 
 // ------------------------------------------------------------------------------------ backward
 constexpr int NCOMP = 9;     // dxy2 (scaled by W/2, H/2), dconic3, dopacity1, drgb3
+
+// What a backward wave loads for one segment, in two dependent levels: the record itself (addressed by the
+// slot), then the Gaussians it names and the pixels of its block.
+struct SegRec { uint2 info; uint2 ent; float4 ck; };
+struct SegData { float2 c; float4 co; float4 col; float4 pa; int last; float g0, g1, g2; };
 
 __global__ void __launch_bounds__(GSR_TILE_PIX)
 render_bwd_kernel(int W, int H, int seg_cap, const float2* __restrict__ xy,
@@ -377,39 +400,59 @@ render_bwd_kernel(int W, int H, int seg_cap, const float2* __restrict__ xy,
   const int wave = threadIdx.x / GSR_WAVE;
   const int wave_id = blockIdx.x * WAVES + wave;
   const int nwaves = gridDim.x * WAVES;
-  // slots handed out: count * 64 + r for count < counter r (lane l <-> counter l)
-  const int taken = seg_counters[lane * GSR_SEG_COUNTER_STRIDE];
-  int cmax = taken;
-#pragma unroll
-  for (int off = GSR_WAVE / 2; off > 0; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off));
-  const int nslot = (int)min((int64_t)cmax * GSR_SEG_COUNTERS, (int64_t)seg_cap);
+  // persistent waves (nwaves is a multiple of 64): wave w takes slots w, w + nwaves, ... — all from counter
+  // w % 64, i.e. recorded on the XCD this workgroup runs on. Slot count * 64 + r exists for count < counter r.
+  const int mine = min(seg_counters[(wave_id & (GSR_SEG_COUNTERS - 1)) * GSR_SEG_COUNTER_STRIDE] * GSR_SEG_COUNTERS,
+                       seg_cap);
   const float half_w = 0.5f * (float)W, half_h = 0.5f * (float)H;
   const size_t plane = (size_t)H * W;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-  // persistent waves (nwaves is a multiple of 64): wave w takes slots w, w + nwaves, ... — all from counter
-  // w % 64, i.e. recorded on the XCD this workgroup runs on
-  for (int seg = wave_id; seg < nslot; seg += nwaves) {
-    if ((seg >> 6) >= __builtin_amdgcn_readlane(taken, seg & (GSR_SEG_COUNTERS - 1))) break;   // beyond this counter
-    const uint2 info = seg_info[seg];
-    const int bx0 = (int)(info.x & 0xffffu), by0 = (int)(info.x >> 16), cnt = (int)info.y;
-    const uint2 ent = seg_entries[(size_t)seg * GSR_WAVE + lane];
-    const bool valid = lane < cnt;
-    const uint32_t idx = valid ? ent.x : 0u;
-    const int k = valid ? (int)ent.y : 0x7fffffff;
-    const float2 c = xy[idx];
-    const float4 co = conic_opacity[idx];
-    const float4 col = rgb[idx];
-    // pixel data in lanes 0..15
-    const int p_l = lane & (NPIX - 1);
-    const int ppx = bx0 + (p_l & (SUB - 1)), ppy = by0 + (p_l >> 2);
+  const int p_l = lane & (NPIX - 1);
+
+  auto load_rec = [&](int seg) {
+    SegRec r;
+    r.info = seg_info[seg];
+    r.ent = seg_entries[(size_t)seg * GSR_WAVE + lane];
+    r.ck = seg_ckpt[(size_t)seg * NPIX + p_l];                   // T, C of the block's pixels at the segment's start
+    return r;
+  };
+  auto load_data = [&](const SegRec& r) {
+    SegData d;
+    const uint32_t idx = lane < (int)r.info.y ? r.ent.x : 0u;
+    d.c = xy[idx];
+    d.co = conic_opacity[idx];
+    d.col = rgb[idx];
+    const int ppx = (int)(r.info.x & 0xffffu) + (p_l & (SUB - 1)), ppy = (int)(r.info.x >> 16) + (p_l >> 2);
     const bool inside = ppx < W && ppy < H;
     const size_t pix = inside ? (size_t)ppy * W + ppx : 0;
-    const float4 ck = seg_ckpt[(size_t)seg * NPIX + p_l];         // T, C at the segment's start
-    const float4 pa = pix_accum[pix];                              // C_total, T_final
-    const int vLast = inside ? (int)n_contrib[pix] : 0;
-    const float vg0 = inside ? dL_dout[pix] : 0.f;
-    const float vg1 = inside ? dL_dout[plane + pix] : 0.f;
-    const float vg2 = inside ? dL_dout[2 * plane + pix] : 0.f;
+    d.pa = pix_accum[pix];                                        // C_total, T_final
+    d.last = inside ? (int)n_contrib[pix] : 0;
+    d.g0 = inside ? dL_dout[pix] : 0.f;
+    d.g1 = inside ? dL_dout[plane + pix] : 0.f;
+    d.g2 = inside ? dL_dout[2 * plane + pix] : 0.f;
+    return d;
+  };
+
+  // Two-level software pipeline: a wave's memory latency (record -> Gaussians/pixels, two dependent round
+  // trips of microseconds under load) overlaps with the pixel loop of its previous segment.
+  int seg = wave_id;
+  if (seg >= mine) return;
+  SegRec rec = load_rec(seg);
+  SegData dat = load_data(rec);
+  bool have_next = seg + nwaves < mine;
+  SegRec rec_n = rec;
+  if (have_next) rec_n = load_rec(seg + nwaves);
+  while (true) {
+    const int bx0 = (int)(rec.info.x & 0xffffu), by0 = (int)(rec.info.x >> 16), cnt = (int)rec.info.y;
+    const bool valid = lane < cnt;
+    const uint32_t idx = valid ? rec.ent.x : 0u;
+    const int k = valid ? (int)rec.ent.y : 0x7fffffff;
+    const float2 c = dat.c;
+    const float4 co = dat.co;
+    const float4 col = dat.col;
+    const float4 pa = dat.pa, ck = rec.ck;
+    const int vLast = dat.last;
+    const float vg0 = dat.g0, vg1 = dat.g1, vg2 = dat.g2;
     const float vTs = ck.x;
     // R = (C_total - C_start).g + T_final (bg.g): what lies behind the segment's first entry
     const float vR = (pa.x - ck.y) * vg0 + (pa.y - ck.z) * vg1 + (pa.z - ck.w) * vg2 +
@@ -453,6 +496,9 @@ render_bwd_kernel(int W, int H, int seg_cap, const float2* __restrict__ xy,
         v8 = fmaf(w, g2, v8);
       }
     }
+    // the next segment's record has arrived by now: start its second-level loads
+    SegData dat_n = dat;
+    if (have_next) dat_n = load_data(rec_n);
     // One gradient record = 9 floats in one 64-byte line (GSR_GRAD_STRIDE). Issued lane-per-entry, an atomic
     // instruction would touch 64 lines (measured: 334 of 383 us per frame); transposed through LDS each
     // instruction covers 7 whole records, i.e. ~8 lines: 9x fewer memory-side transactions.
@@ -474,6 +520,12 @@ render_bwd_kernel(int W, int H, int seg_cap, const float2* __restrict__ xy,
       }
     }
     __builtin_amdgcn_wave_barrier();
+    if (!have_next) break;
+    seg += nwaves;
+    rec = rec_n;
+    dat = dat_n;
+    have_next = seg + nwaves < mine;
+    if (have_next) rec_n = load_rec(seg + nwaves);
   }
 }
 
