@@ -150,6 +150,60 @@ def cpu_baseline(N: int, B: int, budget_s: float = 12.0) -> dict:
                       f"CPU: {_cpu_model()}"}
 
 
+def plumbing_config1(budget_s: float = 10.0) -> dict:
+    """BASELINE.json configs[0]: 5k random Gaussians, 256x256, SMPL T-pose, PyTorch-CPU LBS + projection only
+    (no rasterizer), L1 to black, fwd+bwd — the reference's CPU path (restated in
+    oracle/lbs_oracle.py), timed on the host cores. Needs no HIP device."""
+    from oracle import lbs_oracle as O
+    from gaussianavatar_amd.camera import test_pose_camera
+    from gaussianavatar_amd.synthetic import make_assets
+    N, B = 5000, 1
+    cores = os.cpu_count() or 1
+    g = torch.Generator().manual_seed(0)
+    assets = make_assets(num_points=3000, uv_size=64)
+    J = assets["joints_rest"]
+    parents = torch.tensor(assets["parents"], dtype=torch.long)
+    inv = torch.linalg.inv(assets["cano_joint_mat"]).expand(B, -1, -1, -1)
+    pts = (torch.randn(1, N, 3, generator=g) * 0.4).expand(B, -1, -1)
+    w = torch.rand(N, 24, generator=g) ** 8
+    w = (w / w.sum(1, keepdim=True))[None].expand(B, -1, -1).contiguous()
+    full_proj = torch.tensor(test_pose_camera(256)["full_proj_transform"])
+    transl = torch.zeros(B, 3)
+
+    def one():
+        pose = torch.zeros(B, 72, requires_grad=True)            # T-pose
+        res = torch.zeros(B, N, 3, requires_grad=True)
+        return O.cpu_baseline_step(pose, transl, J, parents, inv, pts, res, w, full_proj)
+
+    best = None
+    for nt in sorted({min(cores, c) for c in (1, 4, 8, 16)}):
+        torch.set_num_threads(nt)
+        one()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            one()
+        dt = (time.perf_counter() - t0) / 5
+        if best is None or dt < best[1]:
+            best = (nt, dt)
+    torch.set_num_threads(best[0])
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        loss = one()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 5000:
+            break
+    return {"metric": "config-1 plumbing: PyTorch-CPU LBS + projection fwd+bwd iters/s (no rasterizer)",
+            "value": n / el, "unit": "iters/s", "n_gpus": 0, "steps": n, "warmup": 6, "ms_per_step": 1e3 * el / n,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[0]: 5k Gaussians, 256x256, SMPL T-pose, CPU LBS + skinning + "
+                                   "projection + L1-to-black only", "gaussians": N, "image": [256, 256],
+                       "final_loss": float(loss.detach())},
+            "cpu_baseline": {"value": n / el, "unit": "iters/s", "cores": best[0], "kind": "port",
+                             "sample": f"{n} iterations, {el:.1f} s wall, {best[0]} of {cores} host threads; CPU: {_cpu_model()}"}}
+
+
 def _cpu_model() -> str:
     try:
         with open("/proc/cpuinfo") as f:
@@ -174,10 +228,30 @@ def main():
                     help="2 = stage-2 iteration (pose-encoder UNet on, per-frame decoder input); secondary "
                          "workload of BASELINE.json configs[4], the headline metric is stage 1")
     ap.add_argument("--smpl-type", default="smpl", choices=("smpl", "smplx"))
+    ap.add_argument("--uv", type=int, default=0, help="query UV map edge (default: 512, or 1024 when --points > 262144)")
+    ap.add_argument("--iteration", type=int, default=7,
+                    help="training iteration passed to train_stage1: the scale warm-up (1e-3 x iteration, "
+                         "/root/reference/model/avatar_model.py:316) sets the Gaussians' size at random init — "
+                         "5 / 7 / 14 give ~2.5 / 3.5 / 7 mm, i.e. ~2.8 P / 4 P / 9 P tile pairs (D sensitivity)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="fix the GLOBAL batch (frames per iteration over all GPUs) instead of frames per GPU: "
+                         "strong scaling, BASELINE.json configs[3] = 8")
+    ap.add_argument("--config", type=int, default=0, choices=(0, 1, 2, 3, 4, 5),
+                    help="BASELINE.json configs[N-1]: 1 CPU plumbing (no HIP device needed), 2 100k@512^2, 3 headline, "
+                         "4 headline with a fixed global batch of 8 frames, 5 stage 2 / SMPL-X / 300k / 1920x1080 / global batch 8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket rasterizer kernels with HIP events in the timed region")
     args = ap.parse_args()
+    if args.config == 1:
+        print(json.dumps(plumbing_config1()))
+        return
+    if args.config == 2:
+        args.points, args.size = 100_000, 512
+    elif args.config == 4:
+        args.global_batch = 8
+    elif args.config == 5:
+        args.stage, args.smpl_type, args.points, args.size, args.height, args.global_batch = 2, "smplx", 300_000, 1920, 1080, 8
 
     from gaussianavatar_amd import parallel
     rank, world, local = parallel.init_from_env()
@@ -193,11 +267,15 @@ def main():
     from gaussianavatar_amd.avatar_model import AvatarModel, collate_frames, default_params
     from gaussianavatar_amd.losses import l1_loss_w, ssim, weighted_sum
 
-    torch.manual_seed(0)      # identical init on every rank (replicas must start identical)
+    torch.manual_seed(0)      # (replicas are synchronised from rank 0 anyway: AvatarModel.sync_replicas)
+    if args.global_batch:
+        assert args.global_batch % world == 0, "--global-batch must be a multiple of the GPU count"
+        args.frames_per_gpu = args.global_batch // world
     B = args.frames_per_gpu
+    uv = args.uv or (1024 if args.points > 512 * 512 else 512)
     mp, npar, op = default_params(batch_size=B, num_points=args.points, image_width=args.size,
                                   image_height=args.height or args.size, num_frames=max(16, B * world),
-                                  train_stage=args.stage, smpl_type=args.smpl_type)
+                                  train_stage=args.stage, smpl_type=args.smpl_type, query_posmap_size=uv)
     model = AvatarModel(mp, npar, op, train=True, device=dev)
     model.training_setup()
     model.net.train()
@@ -212,7 +290,7 @@ def main():
     for s in range(4):        # a few distinct batches; rank r takes frames r*B.. of each global batch
         ids = [(s * world * B + rank * B + k) % nf for k in range(B)]
         batches.append(collate_frames([ds[i] for i in ids], dev))
-    epoch, iteration = 1, 7   # iteration 7 < 1000: scale warm-up gives ~3.5 mm Gaussians at init
+    epoch, iteration = 1, args.iteration   # iteration 7 < 1000: scale warm-up gives ~3.5 mm Gaussians at init
     if args.stage == 2:
         # the reference's stage 2 starts from a trained stage-1 checkpoint (no scale warm-up,
         # /root/reference/model/avatar_model.py:416); a random-init scale head would give 0.5 m
@@ -293,18 +371,23 @@ def main():
     if rank != 0:
         return
     N = model.query_points.shape[1]
-    value = world * args.steps / elapsed
+    # weak scaling (default): every GPU renders `frames_per_gpu` frames, value counts reference-sized
+    # iterations (one per GPU and step). --global-batch: the job does ONE iteration of that many frames per
+    # step whatever the GPU count ("strong"): value = steps / time.
+    value = (1 if args.global_batch else world) * args.steps / elapsed
     out = {
         "metric": "train iters/s (fwd+bwd), 200k Gaussians @1024^2, 1/2/4/8 MI355X",
         "value": value, "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "strong" if args.global_batch else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"stage-{args.stage} train iteration (LBS + feature net + skinning + Gaussian rasterizer "
                                f"fwd+bwd + L1/DSSIM + Adam), {N} Gaussians, {W}x{H}, {B} frames per GPU "
                                + ("(BASELINE.json configs[2])" if (args.stage, N, W, H) == (1, 200_000, 1024, 1024)
                                   else "(secondary workload)")
                                + f"; synthetic {args.smpl_type.upper()}-shaped body, random-init net",
-                   "gaussians": N, "image": [H, W], "frames_per_gpu": B, "global_batch": B * world,
+                   "gaussians": N, "image": [H, W], "uv_map": uv, "iteration": iteration, "frames_per_gpu": B,
+                   "global_batch": B * world, "frames_per_s": B * world * args.steps / elapsed,
                    "parallelism": f"frame-sharded dp{world}, one all-reduce of [N,7] output grads",
                    "mean_tile_pairs_per_frame": mean_pairs, "final_loss": final_loss},
     }
