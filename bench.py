@@ -249,9 +249,10 @@ def main():
     if args.config == 2:
         args.points, args.size = 100_000, 512
     elif args.config == 4:
-        args.global_batch = 8
+        args.global_batch = args.global_batch or 8
     elif args.config == 5:
-        args.stage, args.smpl_type, args.points, args.size, args.height, args.global_batch = 2, "smplx", 300_000, 1920, 1080, 8
+        args.stage, args.smpl_type, args.points, args.size, args.height = 2, "smplx", 300_000, 1920, 1080
+        args.global_batch = args.global_batch or 8
 
     from gaussianavatar_amd import parallel
     rank, world, local = parallel.init_from_env()
