@@ -14,8 +14,7 @@ namespace gsr {
 namespace {
 
 constexpr int SCAN_THREADS = 1024;
-constexpr int SORT_THREADS = 1024;
-constexpr int SORT_CAP = 8192;        // keys sorted in LDS at once (64 KiB; avatar tiles reach ~4600)
+constexpr int SORT_CAP = 8192;        // keys sorted in LDS at once by the large class (64 KiB; avatar tiles reach ~4600)
 constexpr int MERGE_ITEMS = 8;        // outputs per thread per merge step
 
 // ------------------------------------------------------------------ K2
@@ -116,12 +115,16 @@ tile_scan_kernel(int T, int64_t max_pairs, uint32_t* __restrict__ tile_count,
 }
 
 // ------------------------------------------------------------------ K3
+// Append (depth_bits << 32 | index) to every tile a Gaussian touches. The workgroup's pairs are counted
+// per tile in LDS (gsr_common.h: TileAgg), ONE returning global atomic per (workgroup, tile) reserves
+// their slots — all of a workgroup's atomics fly in one round instead of one memory round trip per
+// distinct tile and rect step — and the pairs take their positions from LDS cursors.
 __global__ void __launch_bounds__(256)
 scatter_kernel(int P, int gx, int64_t max_pairs, const int4* __restrict__ rect,
                const float* __restrict__ depth, uint32_t* __restrict__ tile_cursor,
                uint64_t* __restrict__ pair_key, size_t ws_stride) {
+  __shared__ TileAgg s_agg;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P) return;
   {
     const size_t off = (size_t)blockIdx.y * ws_stride;
     rect = reinterpret_cast<const int4*>(reinterpret_cast<const char*>(rect) + off);
@@ -129,34 +132,31 @@ scatter_kernel(int P, int gx, int64_t max_pairs, const int4* __restrict__ rect,
     tile_cursor = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(tile_cursor) + off);
     pair_key = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(pair_key) + off);
   }
-  const int lane = threadIdx.x & (GSR_WAVE - 1);
-  const int4 rc = rect[i];
-  const uint64_t key = ((uint64_t)__float_as_uint(depth[i]) << 32) | (uint32_t)i;
-  // wave-aggregated append: lanes that target the same tile share one returning atomic and
-  // write their keys to consecutive slots (see the histogram in K1)
-  int cx = rc.x, cy = rc.y;
-  while (true) {
-    const bool active = cy < rc.w && cx < rc.z;
-    unsigned long long remaining = __ballot(active);
-    if (remaining == 0ull) break;
-    const int tile = active ? cy * gx + cx : -1;
-    while (remaining) {
-      const int leader = __ffsll((long long)remaining) - 1;
-      const int ltile = __shfl(tile, leader);
-      const bool mine = active && tile == ltile;
-      const unsigned long long same = __ballot(mine);
-      uint32_t base = 0;
-      if (lane == leader) base = atomicAdd(&tile_cursor[ltile], (uint32_t)__popcll(same));
-      base = __shfl(base, leader);
-      if (mine) {
-        const uint32_t pos = base + (uint32_t)__builtin_amdgcn_mbcnt_hi(
-            (unsigned)(same >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)same, 0));
-        if ((int64_t)pos < max_pairs) pair_key[pos] = key;
-      }
-      remaining &= ~same;
+  agg_clear(s_agg);
+  const int4 rc = i < P ? rect[i] : make_int4(0, 0, 0, 0);
+  const uint64_t key = i < P ? (((uint64_t)__float_as_uint(depth[i]) << 32) | (uint32_t)i) : 0ull;
+  __syncthreads();
+  for (int cy = rc.y; cy < rc.w; ++cy)
+    for (int cx = rc.x; cx < rc.z; ++cx) {
+      const int slot = agg_claim(s_agg, cy * gx + cx);
+      if (slot >= 0) atomicAdd(&s_agg.cnt[slot], 1u);
     }
-    if (++cx >= rc.z) { cx = rc.x; ++cy; }
-  }
+  __syncthreads();
+  for (int sl = threadIdx.x; sl < GSR_AGG_SLOTS; sl += blockDim.x)
+    if (s_agg.key[sl] >= 0) {
+      s_agg.base[sl] = atomicAdd(&tile_cursor[s_agg.key[sl]], s_agg.cnt[sl]);
+      s_agg.cnt[sl] = 0u;
+    }
+  __syncthreads();
+  for (int cy = rc.y; cy < rc.w; ++cy)
+    for (int cx = rc.x; cx < rc.z; ++cx) {
+      const int tile = cy * gx + cx;
+      const int slot = agg_find(s_agg, tile);
+      // (a tile that found no room in the table — huge Gaussians — takes its slot directly)
+      const uint32_t pos = slot >= 0 ? s_agg.base[slot] + atomicAdd(&s_agg.cnt[slot], 1u)
+                                     : atomicAdd(&tile_cursor[tile], 1u);
+      if ((int64_t)pos < max_pairs) pair_key[pos] = key;
+    }
 }
 
 // ------------------------------------------------------------------ K4
@@ -173,6 +173,7 @@ __device__ __forceinline__ void cmp_swap(uint64_t* s, int t, int j, int k) {
   if ((a > b) == up) { s[i] = b; s[l] = a; }
 }
 
+template <int SORT_THREADS>
 __device__ __forceinline__ void bitonic_sort_lds(uint64_t* s, int n2, int tid) {
   const int half = n2 >> 1;
   for (int k = 2; k <= n2; k <<= 1) {
@@ -210,12 +211,14 @@ __device__ __forceinline__ int merge_split(const uint64_t* A, int na, const uint
   return lo;
 }
 
+// CAP keys fit the LDS image (one class is launched: CAP = SORT_CAP, every list length).
+template <int CAP, int SORT_THREADS>
 __global__ void __launch_bounds__(SORT_THREADS)
 tile_sort_kernel(int64_t max_pairs, const uint32_t* __restrict__ tile_order,
                  const uint32_t* __restrict__ tile_offset,
                  uint64_t* __restrict__ pair_key, uint64_t* __restrict__ pair_tmp,
                  uint32_t* __restrict__ point_list, size_t ws_stride) {
-  __shared__ uint64_t s_key[SORT_CAP];
+  __shared__ uint64_t s_key[CAP];
   {
     const size_t off = (size_t)blockIdx.y * ws_stride;
     tile_order = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(tile_order) + off);
@@ -241,17 +244,18 @@ tile_sort_kernel(int64_t max_pairs, const uint32_t* __restrict__ tile_order,
     const int n2 = next_pow2(n);
     for (int i = tid; i < n2; i += SORT_THREADS) s_key[i] = (i < n) ? keys[i] : ~0ull;
     __syncthreads();
-    bitonic_sort_lds(s_key, n2, tid);
+    bitonic_sort_lds<SORT_THREADS>(s_key, n2, tid);
     for (int i = tid; i < n; i += SORT_THREADS) out[i] = (uint32_t)s_key[i];
     return;
   }
+  if (CAP != SORT_CAP) return;        // (only the large class meets lists beyond its LDS capacity)
   // Oversized list: sort SORT_CAP-sized runs in LDS, then merge runs through HBM.
   for (int c0 = 0; c0 < n; c0 += SORT_CAP) {
     const int m = min(SORT_CAP, n - c0);
     const int m2 = next_pow2(m);
     for (int i = tid; i < m2; i += SORT_THREADS) s_key[i] = (i < m) ? keys[c0 + i] : ~0ull;
     __syncthreads();
-    bitonic_sort_lds(s_key, m2, tid);
+    bitonic_sort_lds<SORT_THREADS>(s_key, m2, tid);
     for (int i = tid; i < m; i += SORT_THREADS) keys[c0 + i] = s_key[i];
     __syncthreads();
   }
@@ -302,7 +306,9 @@ hipError_t launch_binning(const Dims& d, const Workspace& ws, const Batch& bt, h
     if (e != hipSuccess) return e;
     {
       ProfScope prof_(K_SORT, stream);
-      hipLaunchKernelGGL(tile_sort_kernel, dim3(d.T, bt.frames), dim3(SORT_THREADS), 0, stream, d.max_pairs,
+      // (two size classes — 16 KiB / 512 threads for lists <= 2048, the rest as here — were measured: the two
+      // launches serialise and the 46 long lists then run on an empty chip: 100 -> 144 us per 2 frames)
+      hipLaunchKernelGGL((tile_sort_kernel<SORT_CAP, 1024>), dim3(d.T, bt.frames), dim3(1024), 0, stream, d.max_pairs,
                        ws.tile_count, ws.tile_offset, ws.pair_key, ws.pair_tmp, ws.point_list, bt.ws_stride);
     }
     e = hipGetLastError();

@@ -77,8 +77,10 @@ preprocess_kernel(int P, int W, int H, int gx, int gy, float tanfovx, float tanf
                   const float* __restrict__ scales, const float* __restrict__ rotations,
                   const float* __restrict__ cov3D_precomp, Workspace ws,
                   int32_t* __restrict__ radii, Batch bt) {
+  __shared__ TileAgg s_agg;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P) return;
+  const bool in_range = i < P;      // (every thread stays for the workgroup's histogram)
+  agg_clear(s_agg);
   {   // batched launch: select this frame's inputs, workspace and outputs
     const int64_t f = blockIdx.y;
     view += f * bt.view; proj += f * bt.proj; means3D += f * bt.means;
@@ -89,113 +91,109 @@ preprocess_kernel(int P, int W, int H, int gx, int gy, float tanfovx, float tanf
     ws = frame_ws(ws, (size_t)f * bt.ws_stride);
     radii += f * P;
   }
-  float V[16], PV[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) { V[k] = view[k]; PV[k] = proj[k]; }
-
-  // defaults for a Gaussian that is not rendered
-  int rad_i = 0;
-  uint32_t ntiles = 0;
   int4 rc = make_int4(0, 0, 0, 0);
-  float depth = 0.f;
-  float2 xy = make_float2(0.f, 0.f);
-  float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (in_range) {
+    float V[16], PV[16];
+  #pragma unroll
+    for (int k = 0; k < 16; ++k) { V[k] = view[k]; PV[k] = proj[k]; }
 
-  const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
-  float c6[6];
-  if (cov3D_precomp) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * i + k];
-  } else {
-    float Rm[3][3], M[3][3];
-    const float q[4] = {rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2],
-                        rotations[4 * i + 3]};
-    quat_to_rot(q, Rm);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const float sk = scale_modifier * scales[3 * i + k];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) M[k][a] = sk * Rm[a][k];
+    // defaults for a Gaussian that is not rendered
+    int rad_i = 0;
+    uint32_t ntiles = 0;
+    float depth = 0.f;
+    float2 xy = make_float2(0.f, 0.f);
+    float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
+    float c6[6];
+    if (cov3D_precomp) {
+  #pragma unroll
+      for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * i + k];
+    } else {
+      float Rm[3][3], M[3][3];
+      const float q[4] = {rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2],
+                          rotations[4 * i + 3]};
+      quat_to_rot(q, Rm);
+  #pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float sk = scale_modifier * scales[3 * i + k];
+  #pragma unroll
+        for (int a = 0; a < 3; ++a) M[k][a] = sk * Rm[a][k];
+      }
+      int o = 0;
+  #pragma unroll
+      for (int a = 0; a < 3; ++a)
+  #pragma unroll
+        for (int b = a; b < 3; ++b)
+          c6[o++] = M[0][a] * M[0][b] + M[1][a] * M[1][b] + M[2][a] * M[2][b];
     }
-    int o = 0;
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int b = a; b < 3; ++b)
-        c6[o++] = M[0][a] * M[0][b] + M[1][a] * M[1][b] + M[2][a] * M[2][b];
-  }
-#pragma unroll
-  for (int k = 0; k < 6; ++k) ws.cov3d[6 * i + k] = c6[k];
-  // with SH input the colour is filled in by sh_color_kernel (gsr_sh.hip) right after this kernel
-  if (colors) ws.rgb[i] = make_float4(colors[3 * i], colors[3 * i + 1], colors[3 * i + 2], 0.f);
+  #pragma unroll
+    for (int k = 0; k < 6; ++k) ws.cov3d[6 * i + k] = c6[k];
+    // with SH input the colour is filled in by sh_color_kernel (gsr_sh.hip) right after this kernel
+    if (colors) ws.rgb[i] = make_float4(colors[3 * i], colors[3 * i + 1], colors[3 * i + 2], 0.f);
 
-  const float tx = vm(V, 0, 0) * px + vm(V, 0, 1) * py + vm(V, 0, 2) * pz + vm(V, 0, 3);
-  const float ty = vm(V, 1, 0) * px + vm(V, 1, 1) * py + vm(V, 1, 2) * pz + vm(V, 1, 3);
-  const float tz = vm(V, 2, 0) * px + vm(V, 2, 1) * py + vm(V, 2, 2) * pz + vm(V, 2, 3);
-  if (tz > 0.2f) {
-    const float fx = (float)W / (2.0f * tanfovx);
-    const float fy = (float)H / (2.0f * tanfovy);
-    const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
-    const float hx = vm(PV, 0, 0) * px + vm(PV, 0, 1) * py + vm(PV, 0, 2) * pz + vm(PV, 0, 3);
-    const float hy = vm(PV, 1, 0) * px + vm(PV, 1, 1) * py + vm(PV, 1, 2) * pz + vm(PV, 1, 3);
-    const float hw = vm(PV, 3, 0) * px + vm(PV, 3, 1) * py + vm(PV, 3, 2) * pz + vm(PV, 3, 3);
-    const float winv = 1.0f / (hw + 0.0000001f);
-    const float ndcx = hx * winv, ndcy = hy * winv;
-    Ewa e;
-    ewa_project(V, fx, fy, limx, limy, tx, ty, tz, c6, e);
-    const float det = e.a * e.c - e.b * e.b;
-    if (det != 0.0f) {
-      const float det_inv = 1.0f / det;
-      const float mid = 0.5f * (e.a + e.c);
-      const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
-      const float l1 = mid + sq, l2 = mid - sq;
-      const float radf = ceilf(3.0f * sqrtf(fmaxf(l1, l2)));
-      const float pxx = ((ndcx + 1.0f) * (float)W - 1.0f) * 0.5f;
-      const float pyy = ((ndcy + 1.0f) * (float)H - 1.0f) * 0.5f;
-      const int x0 = trunc_clamp((pxx - radf) / (float)GSR_TILE, 0, gx);
-      const int y0 = trunc_clamp((pyy - radf) / (float)GSR_TILE, 0, gy);
-      const int x1 = trunc_clamp((pxx + radf + (float)(GSR_TILE - 1)) / (float)GSR_TILE, 0, gx);
-      const int y1 = trunc_clamp((pyy + radf + (float)(GSR_TILE - 1)) / (float)GSR_TILE, 0, gy);
-      const int nt = (x1 - x0) * (y1 - y0);
-      if (nt > 0) {
-        depth = tz;
-        rad_i = (radf < 2147483520.0f) ? (int)radf : 2147483647;
-        xy = make_float2(pxx, pyy);
-        co = make_float4(e.c * det_inv, -e.b * det_inv, e.a * det_inv, opacities[i]);
-        rc = make_int4(x0, y0, x1, y1);
-        ntiles = (uint32_t)nt;
+    const float tx = vm(V, 0, 0) * px + vm(V, 0, 1) * py + vm(V, 0, 2) * pz + vm(V, 0, 3);
+    const float ty = vm(V, 1, 0) * px + vm(V, 1, 1) * py + vm(V, 1, 2) * pz + vm(V, 1, 3);
+    const float tz = vm(V, 2, 0) * px + vm(V, 2, 1) * py + vm(V, 2, 2) * pz + vm(V, 2, 3);
+    if (tz > 0.2f) {
+      const float fx = (float)W / (2.0f * tanfovx);
+      const float fy = (float)H / (2.0f * tanfovy);
+      const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+      const float hx = vm(PV, 0, 0) * px + vm(PV, 0, 1) * py + vm(PV, 0, 2) * pz + vm(PV, 0, 3);
+      const float hy = vm(PV, 1, 0) * px + vm(PV, 1, 1) * py + vm(PV, 1, 2) * pz + vm(PV, 1, 3);
+      const float hw = vm(PV, 3, 0) * px + vm(PV, 3, 1) * py + vm(PV, 3, 2) * pz + vm(PV, 3, 3);
+      const float winv = 1.0f / (hw + 0.0000001f);
+      const float ndcx = hx * winv, ndcy = hy * winv;
+      Ewa e;
+      ewa_project(V, fx, fy, limx, limy, tx, ty, tz, c6, e);
+      const float det = e.a * e.c - e.b * e.b;
+      if (det != 0.0f) {
+        const float det_inv = 1.0f / det;
+        const float mid = 0.5f * (e.a + e.c);
+        const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+        const float l1 = mid + sq, l2 = mid - sq;
+        const float radf = ceilf(3.0f * sqrtf(fmaxf(l1, l2)));
+        const float pxx = ((ndcx + 1.0f) * (float)W - 1.0f) * 0.5f;
+        const float pyy = ((ndcy + 1.0f) * (float)H - 1.0f) * 0.5f;
+        const int x0 = trunc_clamp((pxx - radf) / (float)GSR_TILE, 0, gx);
+        const int y0 = trunc_clamp((pyy - radf) / (float)GSR_TILE, 0, gy);
+        const int x1 = trunc_clamp((pxx + radf + (float)(GSR_TILE - 1)) / (float)GSR_TILE, 0, gx);
+        const int y1 = trunc_clamp((pyy + radf + (float)(GSR_TILE - 1)) / (float)GSR_TILE, 0, gy);
+        const int nt = (x1 - x0) * (y1 - y0);
+        if (nt > 0) {
+          depth = tz;
+          rad_i = (radf < 2147483520.0f) ? (int)radf : 2147483647;
+          xy = make_float2(pxx, pyy);
+          co = make_float4(e.c * det_inv, -e.b * det_inv, e.a * det_inv, opacities[i]);
+          rc = make_int4(x0, y0, x1, y1);
+          ntiles = (uint32_t)nt;
+        }
       }
     }
-  }
-  radii[i] = rad_i;
-  ws.depth[i] = depth;
-  ws.xy[i] = xy;
-  ws.conic_opacity[i] = co;
-  {
-    const float2 ext = alpha_extent(co);
-    ws.xyext[i] = make_float4(xy.x, xy.y, ext.x, ext.y);
-  }
-  ws.rect[i] = rc;
-  ws.tiles_touched[i] = ntiles;
-  // per-tile histogram of pairs (consumed by K2/K3). Neighbouring Gaussians (adjacent UV
-  // texels) mostly hit the same tiles, so the wave first groups its lanes by tile id and
-  // issues ONE atomic per distinct tile instead of one per lane.
-  int cx = rc.x, cy = rc.y;
-  while (true) {
-    const bool active = cy < rc.w && cx < rc.z;
-    unsigned long long remaining = __ballot(active);
-    if (remaining == 0ull) break;
-    const int tile = active ? cy * gx + cx : -1;
-    while (remaining) {
-      const int leader = __ffsll((long long)remaining) - 1;
-      const int ltile = __shfl(tile, leader);
-      const unsigned long long same = __ballot(active && tile == ltile);
-      if ((int)(threadIdx.x & (GSR_WAVE - 1)) == leader)
-        atomicAdd(&ws.tile_count[ltile], (uint32_t)__popcll(same));
-      remaining &= ~same;
+    radii[i] = rad_i;
+    ws.depth[i] = depth;
+    ws.xy[i] = xy;
+    ws.conic_opacity[i] = co;
+    {
+      const float2 ext = alpha_extent(co);
+      ws.xyext[i] = make_float4(xy.x, xy.y, ext.x, ext.y);
     }
-    if (++cx >= rc.z) { cx = rc.x; ++cy; }
+    ws.rect[i] = rc;
+    ws.tiles_touched[i] = ntiles;
   }
+  // per-tile histogram of pairs (consumed by K2/K3): counted in the workgroup's LDS table first
+  // (gsr_common.h: TileAgg), then one global atomic per (workgroup, tile)
+  __syncthreads();
+  for (int cy = rc.y; cy < rc.w; ++cy)
+    for (int cx = rc.x; cx < rc.z; ++cx) {
+      const int tile = cy * gx + cx;
+      const int slot = agg_claim(s_agg, tile);
+      if (slot >= 0) atomicAdd(&s_agg.cnt[slot], 1u);
+      else atomicAdd(&ws.tile_count[tile], 1u);          // table full (huge Gaussians): direct
+    }
+  __syncthreads();
+  for (int sl = threadIdx.x; sl < GSR_AGG_SLOTS; sl += blockDim.x)
+    if (s_agg.key[sl] >= 0) atomicAdd(&ws.tile_count[s_agg.key[sl]], s_agg.cnt[sl]);
 }
 
 // K7 — Appendix A.5. One thread per Gaussian; reads the screen-space gradient accumulators
