@@ -220,6 +220,10 @@ class AvatarModel:
         if self.model_parms.train_stage == 2:
             self.pose_encoder = UnetNoCond5DS(input_nc=3, output_nc=np_.c_pose, nf=np_.nf,
                                               up_mode=np_.up_mode, use_dropout=False).to(self.device)
+            if parallel.world_size() > 1 and self.device.type == "cuda":
+                # the frames of a batch are spread over the ranks: BatchNorm statistics over the global batch,
+                # as in the single-process reference (state-dict compatible)
+                self.pose_encoder = torch.nn.SyncBatchNorm.convert_sync_batchnorm(self.pose_encoder)
         self.sync_replicas()
 
     def training_setup(self):
@@ -348,6 +352,9 @@ class AvatarModel:
     def step(self, epoch):
         if self.model_parms.train_stage == 2:
             parallel.allreduce_param_grads(list(self.net.parameters()) + list(self.pose_encoder.parameters()))
+        elif parallel.texel_sharding():
+            # every rank back-propagated its slice of the UV map: the parameter gradients are partial sums
+            parallel.allreduce_param_grads(list(self.net.parameters()) + [self.geo_feature], average=False)
         self.optimizer.step()
         self.scheduler.step()
         if self._pose_opt_active(epoch):
@@ -376,9 +383,17 @@ class AvatarModel:
         uv = self.uv_coord_map[None]
         scale_mult = 1e-3 * iteration if (warmup and iteration < 1000) else 1.0
         N = self.valid_index.shape[0]
+        if self.geo_feature.is_cuda and pose_featmap is None and parallel.texel_sharding():
+            return self._decode_texel_sharded(B, uv, scale_mult)
         if self.geo_feature.is_cuda:
-            # decoder heads (logits) -> per-Gaussian records + both regulariser means in one kernel
-            res, s_logit, c_logit = self.net.forward_points(pose_featmap, self.geo_feature, uv, raw_heads=True)
+            # decoder heads (logits) -> per-Gaussian records + both regulariser means in one kernel.
+            # Stage 2 under data parallelism: this rank's frames are a share of the global batch's decoder
+            # rows; BatchNorm statistics are synchronised (the single-process batch's semantics)
+            mg = None
+            if pose_featmap is not None and parallel.world_size() > 1:
+                mg = pose_featmap.shape[0] * self.uv_coord_map.shape[0] * parallel.world_size()
+            res, s_logit, c_logit = self.net.forward_points(pose_featmap, self.geo_feature, uv, raw_heads=True,
+                                                            m_global=mg)
             b = res.shape[0]
             flat, offset_loss, scale_loss = fused.decode_pack(res, s_logit, c_logit, self.valid_index,
                                                               self.inv_index, 0.02, scale_mult)
@@ -399,6 +414,35 @@ class AvatarModel:
         point_res, scale1, pshs = fused.split_records(flat, b, N)
         if shared:
             point_res, scale1, pshs = (t.expand(B, -1, -1) for t in (point_res, scale1, pshs))
+        return offset_loss, scale_loss, point_res, scale1.expand(-1, -1, 3), pshs
+
+    def _decode_texel_sharded(self, B, uv, scale_mult):
+        """Stage 1 with GA_DP_MODE=texels (parallel.py): this rank evaluates the decoder on its slice of the
+        UV map only (BatchNorm statistics synchronised over ranks), packs its valid texels, and the full
+        [N,7] record buffer is assembled on every rank with one all-reduce. Returned losses carry the global
+        values; their gradients reach this rank's slice only (parameter gradients are summed in step())."""
+        HW = self.uv_coord_map.shape[0]
+        N = self.valid_index.shape[0]
+        r0, r1 = parallel.shard_range(HW)
+        if getattr(self, "_shard_key", None) != (r0, r1):
+            vi = self.valid_index
+            sel = (vi >= r0) & (vi < r1)
+            n_local = int(sel.sum())
+            n0 = int((vi < r0).sum())
+            inv = self.inv_index[r0:r1]
+            self._shard = dict(n0=n0, n_local=n_local, valid=(vi[sel] - r0).contiguous(),
+                               inv=torch.where(inv >= 0, inv - n0, inv).contiguous())
+            self._shard_key = (r0, r1)
+        sh = self._shard
+        res, s_logit, c_logit = self.net.forward_points(None, self.geo_feature, uv, raw_heads=True,
+                                                        rows=(r0, r1), m_global=HW)
+        flat_l, off_l, scale_l = fused.decode_pack(res, s_logit, c_logit, sh["valid"], sh["inv"], 0.02, scale_mult)
+        # the local means are over this slice: weight them into the global means
+        offset_loss = parallel.sum_over_ranks(off_l * ((r1 - r0) / float(HW)))
+        scale_loss = parallel.sum_over_ranks(scale_l * (sh["n_local"] / float(N)))
+        flat = parallel.gather_segments(flat_l, sh["n0"], sh["n_local"], N)
+        point_res, scale1, pshs = fused.split_records(flat, 1, N)
+        point_res, scale1, pshs = (t.expand(B, -1, -1) for t in (point_res, scale1, pshs))
         return offset_loss, scale_loss, point_res, scale1.expand(-1, -1, 3), pshs
 
     def _render_frames(self, batch_data, full_pred, colors, scales):
@@ -427,6 +471,8 @@ class AvatarModel:
         image, full_pred, offset_loss, scale_loss = self._forward(
             batch_data, iteration, self.pose(idx), self.transl(idx), None, warmup=True)
         geo_loss = fused.mean_sq(self.geo_feature) if self.geo_feature.is_cuda else torch.mean(self.geo_feature ** 2)
+        if parallel.texel_sharding():
+            geo_loss = parallel.replicated_term(geo_loss)       # every rank computes it; gradients are summed
         return image, full_pred, offset_loss, geo_loss, scale_loss
 
     def train_stage2(self, batch_data, iteration):

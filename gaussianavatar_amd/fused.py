@@ -13,7 +13,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-from . import _native
+from . import _native, parallel
 
 
 def _ptr(t):
@@ -449,10 +449,16 @@ class _DecoderFn(torch.autograd.Function):
     bn.weight, bn.bias; then conv8{tag}.weight, conv8{tag}.bias per head."""
 
     @staticmethod
-    def forward(ctx, x, dec, *params):
+    def forward(ctx, x, dec, m_global, *params):
+        """m_global: None, or the row count of the GLOBAL batch when this rank holds only its share of the
+        rows (texel-sharded stage 1, frame-sharded stage 2): the BatchNorm column sums of every layer are
+        then all-reduced, so statistics (and their backward) are those of the single-process batch."""
         lib = _native.ganet()
         dev = x.device
         M, cin = x.shape[0], dec.in_size
+        sync = m_global is not None and int(m_global) != M
+        Mg = int(m_global) if sync else M
+        ctx.sync, ctx.Mg = sync, Mg
         layers = _decoder_bn_layers()
         nl = len(layers)
         conv_w = [params[4 * i].squeeze(-1) for i in range(nl)]
@@ -479,8 +485,10 @@ class _DecoderFn(torch.autograd.Function):
             if training:
                 mean, rstd, sc, sh = (torch.empty(128, dtype=torch.float32, device=dev) for _ in range(4))
                 track = bn.track_running_stats
+                if sync:
+                    _allreduce_partials(col_part, 256)
                 _native.ganet_check(lib.ganet_mlp_stats(
-                    M, 128, _ptr(col_part), _ptr(gammas[i]), _ptr(betas[i]), float(bn.eps), _ptr(mean), _ptr(rstd),
+                    Mg, 128, _ptr(col_part), _ptr(gammas[i]), _ptr(betas[i]), float(bn.eps), _ptr(mean), _ptr(rstd),
                     _ptr(sc), _ptr(sh), _ptr(bn.running_mean if track else None),
                     _ptr(bn.running_var if track else None), float(bn.momentum),
                     _ptr(bn.num_batches_tracked if track else None), _stream(dev)))
@@ -578,8 +586,15 @@ class _DecoderFn(torch.autograd.Function):
             """column sums of (G_i, G_i z_i) -> coefficients of layer i, d gamma_i, d beta_i."""
             mean, rstd, sc, _ = stats[i]
             coef, dg, dbt = f32(3 * 128), f32(128), f32(128)
-            _native.ganet_check(lib.ganet_mlp_bwd_stats(M, nparts, _ptr(col_part), _ptr(mean), _ptr(rstd), _ptr(sc),
+            if ctx.sync:
+                _allreduce_partials(col_part[:nparts * 256], 256)
+            _native.ganet_check(lib.ganet_mlp_bwd_stats(ctx.Mg, nparts, _ptr(col_part), _ptr(mean), _ptr(rstd), _ptr(sc),
                                                         _ptr(coef), _ptr(dg), _ptr(dbt), st))
+            if ctx.sync:
+                # d gamma / d beta come out of the GLOBAL sums, i.e. complete on every rank, while the other
+                # parameter gradients are partial sums over the rank's rows: pre-divide, the cross-rank
+                # reduction of the step (sum, or average of per-rank objectives) then restores them
+                dg, dbt = dg / parallel.world_size(), dbt / parallel.world_size()
             coefs[i], g_gamma[i], g_beta[i] = coef, dg, dbt
 
         def data_grad(gi, W, out, accumulate, src):
@@ -667,12 +682,24 @@ class _DecoderFn(torch.autograd.Function):
             grads += [g_conv_w[i], g_conv_b[i], g_gamma[i], g_beta[i]]
         for j in range(3):
             grads += [g_out_w[j], g_out_b[j]]
-        return (dx, None) + tuple(grads)
+        return (dx, None, None) + tuple(grads)
 
 
-def decoder_mlp(dec, x):
+def _allreduce_partials(col_part: torch.Tensor, width: int) -> None:
+    """Per-workgroup partial column sums [nparts, width] -> the same buffer holding the sums over ALL ranks'
+    partials in its first row and zeros elsewhere (the statistics kernels add the rows up). The local
+    reduction and the all-reduce run in float64."""
+    part = col_part.view(-1, width)
+    tot = part.double().sum(0)
+    parallel.all_reduce_sum_(tot)
+    part.zero_()
+    part[0] = tot.float()
+
+
+def decoder_mlp(dec, x, m_global=None):
     """ShapeDecoder.forward_points on the fused kernels: x [M, in_size] -> (residual [M,3],
-    scale logits [M,1], colour logits [M,3]) — the sigmoids of the two heads stay with the caller."""
+    scale logits [M,1], colour logits [M,3]) — the sigmoids of the two heads stay with the caller.
+    m_global: row count of the global batch when x holds only this rank's rows (see _DecoderFn)."""
     params = []
     for conv, bn in _decoder_bn_layers():
         c, b = getattr(dec, conv), getattr(dec, bn)
@@ -680,4 +707,4 @@ def decoder_mlp(dec, x):
     for t in _HEAD_TAGS:
         c = getattr(dec, f"conv8{t}")
         params += [c.weight, c.bias]
-    return _DecoderFn.apply(x, dec, *params)
+    return _DecoderFn.apply(x, dec, m_global, *params)

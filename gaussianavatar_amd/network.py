@@ -91,15 +91,20 @@ class ShapeDecoder(nn.Module):
         c = getattr(self, conv)
         return fused.linear(x, c.weight.squeeze(-1), c.bias)
 
-    def forward_points(self, x, raw_heads: bool = False):
+    def forward_points(self, x, raw_heads: bool = False, m_global=None):
         """x [M, in_size] -> (residual [M,3], scale [M,1], colour [M,3]); with raw_heads the scale and
-        colour heads are returned as logits (the caller applies the sigmoids, fused.decode_pack)."""
+        colour heads are returned as logits (the caller applies the sigmoids, fused.decode_pack).
+        m_global: rows of the global batch when x holds one rank's share (BatchNorm statistics are then
+        synchronised over the ranks; fused path only)."""
         act = (lambda t: t) if raw_heads else torch.sigmoid
         if fused.decoder_supported(self, x):
             # whole decoder on the fused MFMA layer kernels (activation-on-load, statistics in the
             # epilogue); the per-layer formulation below is the CPU / unsupported-shape path
-            r, s, c = fused.decoder_mlp(self, x)
+            r, s, c = fused.decoder_mlp(self, x, m_global)
             return r, act(s), act(c)
+        if m_global is not None and int(m_global) != x.shape[0]:
+            raise NotImplementedError("synchronised BatchNorm statistics need the fused decoder path "
+                                      "(HIP device, hsize 128, softplus, training mode)")
         x1 = self._layer(x, "conv1", "bn1")
         x2 = self._layer(x1, "conv2", "bn2")
         x3 = self._layer(x2, "conv3", "bn3")
@@ -249,8 +254,12 @@ class POP_no_unet(nn.Module):
             self._taps_cache = (mats, (fused.bilinear_taps(mats[0]), fused.bilinear_taps(mats[1])))
         return self._taps_cache[1]
 
-    def forward_points(self, pose_featmap, geom_featmap, uv_loc, dedup: bool = True, raw_heads: bool = False):
+    def forward_points(self, pose_featmap, geom_featmap, uv_loc, dedup: bool = True, raw_heads: bool = False,
+                       rows=None, m_global=None):
         """-> (residuals [B,HW,3], scales [B,HW,1], colours [B,HW,3]); raw_heads: scale/colour logits.
+        rows = (r0, r1): evaluate the decoder on texels r0..r1 only (outputs [b, r1-r0, .]; data-parallel
+        texel sharding, batch-invariant inputs only); m_global: decoder rows of the global batch when this
+        rank evaluates a share of them (BatchNorm statistics synchronised over ranks).
 
         If `dedup` and the inputs are batch-invariant (stage 1: pose_featmap None, geom_featmap
         and uv_loc expanded views of single maps) the net runs once and the result is expanded."""
@@ -279,7 +288,11 @@ class POP_no_unet(nn.Module):
                 # (bilinear 2x2 taps, uv columns, zero padding) — no dense GEMMs, no cat
                 taps = self._bilinear_taps(mats)
                 x = fused.upsample_cat(pix, uv_loc, taps[0], taps[1], C + 2 + pad)
-                r, s, c = self.decoder.forward_points(x, raw_heads=raw_heads)
+                if rows is not None:
+                    assert b == 1, "texel sharding applies to the batch-invariant (stage-1) decoder"
+                    x = x[rows[0]:rows[1]]
+                    HW = rows[1] - rows[0]
+                r, s, c = self.decoder.forward_points(x, raw_heads=raw_heads, m_global=m_global)
                 r, s, c = (t.reshape(b, HW, -1) for t in (r, s, c))
                 if shared:
                     r, s, c = (t.expand(B, -1, -1) for t in (r, s, c))
@@ -306,7 +319,9 @@ class POP_no_unet(nn.Module):
                 self._zero_pad = (zkey, pts.new_zeros(b, HW, pad))
             parts.append(self._zero_pad[1])
         x = torch.cat(parts, dim=2)                                           # [b, HW, C+2 (+pad)]
-        r, s, c = self.decoder.forward_points(x.reshape(b * HW, x.shape[2]), raw_heads=raw_heads)
+        if rows is not None:
+            raise NotImplementedError("texel sharding needs the fused up-sampling path (c_geom 64, separable uv grid)")
+        r, s, c = self.decoder.forward_points(x.reshape(b * HW, x.shape[2]), raw_heads=raw_heads, m_global=m_global)
         r, s, c = (t.reshape(b, HW, -1) for t in (r, s, c))
         if shared:
             r, s, c = (t.expand(B, -1, -1) for t in (r, s, c))

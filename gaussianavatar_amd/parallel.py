@@ -20,6 +20,14 @@ frame. What couples the ranks in stage 1 is only the shared decoder output, henc
 
 Losses are means over the local frames; averaging the exchanged gradients over ranks makes the
 update equal to the reference's update on the global batch (equal frames per rank).
+
+GA_DP_MODE=texels (stage 1) shards the batch-invariant decoder itself, for a FIXED global batch:
+  rank r evaluates rows [r, r+1) * S^2/R of the UV map; every BatchNorm layer's column sums are all-reduced
+  (11 small messages forward, 11 backward), so the statistics are those of the whole map; the packed
+  per-Gaussian outputs are assembled on every rank with one all-reduce (5.6 MB) and their gradients come back
+  with the one all-reduce of the frame-sharded mode; parameter gradients are partial sums over the rank's
+  rows and are SUMMED once per step (net 2 MB + geometry feature map 4 MB). The same synchronised statistics
+  serve stage 2 (decoder rows = the global batch's frames: SyncBN semantics of the single-process batch).
 """
 from __future__ import annotations
 
@@ -88,8 +96,8 @@ def exchange_output_grads(x: torch.Tensor) -> torch.Tensor:
     return _ExchangeGrad.apply(x)
 
 
-def allreduce_param_grads(params: List[torch.Tensor]) -> None:
-    """Average dense parameter gradients over ranks with one flat all-reduce."""
+def allreduce_param_grads(params: List[torch.Tensor], average: bool = True) -> None:
+    """Average (or, average=False, sum) dense parameter gradients over ranks with one flat all-reduce."""
     if world_size() == 1:
         return
     grads = [p.grad for p in params if p.grad is not None]
@@ -97,7 +105,8 @@ def allreduce_param_grads(params: List[torch.Tensor]) -> None:
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=_group)
-    flat /= dist.get_world_size(_group)
+    if average:
+        flat /= dist.get_world_size(_group)
     off = 0
     for g in grads:
         n = g.numel()
@@ -173,6 +182,94 @@ class ShardedSampler(torch.utils.data.Sampler):
         order = torch.randperm(self.n, generator=g).tolist() if self.shuffle else list(range(self.n))
         R, r = world_size(), rank()
         return iter(order[r:len(self) * R:R])
+
+
+def texel_sharding() -> bool:
+    """Stage-1 decoder sharded by UV texels over the ranks (GA_DP_MODE=texels), see the module docstring."""
+    return world_size() > 1 and os.environ.get("GA_DP_MODE", "frames") == "texels"
+
+
+def shard_range(total: int) -> tuple:
+    """Rows [r0, r1) of `total` owned by this rank (contiguous, sizes differ by at most one)."""
+    W, r = world_size(), rank()
+    return (total * r) // W, (total * (r + 1)) // W
+
+
+def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
+    if world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_group)
+    return t
+
+
+class _SumOverRanks(torch.autograd.Function):
+    """value: sum of the ranks' terms (every rank sees the global number); gradient: passes to the local
+    term only — the other ranks back-propagate their own terms."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y = x.detach().clone()
+        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=_group)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def sum_over_ranks(x: torch.Tensor) -> torch.Tensor:
+    return _SumOverRanks.apply(x) if world_size() > 1 else x
+
+
+class _ScaleGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.s = s
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.s, None
+
+
+def replicated_term(x: torch.Tensor) -> torch.Tensor:
+    """A loss term every rank computes in full (e.g. the geometry regulariser) in a mode whose parameter
+    gradients are SUMMED over ranks: the value is kept, its gradient is divided by the world size."""
+    return _ScaleGrad.apply(x, 1.0 / world_size()) if world_size() > 1 else x
+
+
+class _GatherSegments(torch.autograd.Function):
+    """Each rank owns a contiguous slice of every segment of a flat buffer (segment j of the full buffer
+    has seg[j] * n_total entries, of which this rank computed [seg[j] * n0, seg[j] * (n0 + n_local))):
+    forward assembles the full buffer on every rank (zero-fill + all-reduce), backward AVERAGES the full
+    gradient over ranks (local losses are means over local frames) and hands back this rank's slices."""
+
+    @staticmethod
+    def forward(ctx, local, n0, n_local, n_total, seg):
+        full = local.new_zeros(sum(seg) * n_total)
+        off_f, off_l = 0, 0
+        for c in seg:
+            full[off_f + c * n0: off_f + c * (n0 + n_local)] = local[off_l: off_l + c * n_local]
+            off_f += c * n_total
+            off_l += c * n_local
+        dist.all_reduce(full, op=dist.ReduceOp.SUM, group=_group)
+        ctx.dims = (n0, n_local, n_total, seg)
+        return full
+
+    @staticmethod
+    def backward(ctx, g):
+        n0, n_local, n_total, seg = ctx.dims
+        g = g.contiguous().clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=_group)
+        g /= dist.get_world_size(_group)
+        parts, off = [], 0
+        for c in seg:
+            parts.append(g[off + c * n0: off + c * (n0 + n_local)])
+            off += c * n_total
+        return torch.cat(parts), None, None, None, None
+
+
+def gather_segments(local: torch.Tensor, n0: int, n_local: int, n_total: int, seg=(3, 1, 3)) -> torch.Tensor:
+    return _GatherSegments.apply(local, n0, n_local, n_total, tuple(seg))
 
 
 def barrier() -> None:
