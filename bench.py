@@ -239,6 +239,10 @@ def main():
     ap.add_argument("--config", type=int, default=0, choices=(0, 1, 2, 3, 4, 5),
                     help="BASELINE.json configs[N-1]: 1 CPU plumbing (no HIP device needed), 2 100k@512^2, 3 headline, "
                          "4 headline with a fixed global batch of 8 frames, 5 stage 2 / SMPL-X / 300k / 1920x1080 / global batch 8")
+    ap.add_argument("--dp-mode", default="", choices=("", "frames", "texels"),
+                    help="stage-1 data parallelism (gaussianavatar_amd/parallel.py): frames = every rank evaluates the "
+                         "batch-invariant decoder (default for weak scaling); texels = the decoder is sharded by UV "
+                         "texels (default with --global-batch: fixed total work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket rasterizer kernels with HIP events in the timed region")
@@ -254,6 +258,8 @@ def main():
         args.stage, args.smpl_type, args.points, args.size, args.height = 2, "smplx", 300_000, 1920, 1080
         args.global_batch = args.global_batch or 8
 
+    if args.stage == 1 and (args.dp_mode or args.global_batch):
+        os.environ["GA_DP_MODE"] = args.dp_mode or "texels"
     from gaussianavatar_amd import parallel
     rank, world, local = parallel.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -389,7 +395,11 @@ def main():
                                + f"; synthetic {args.smpl_type.upper()}-shaped body, random-init net",
                    "gaussians": N, "image": [H, W], "uv_map": uv, "iteration": iteration, "frames_per_gpu": B,
                    "global_batch": B * world, "frames_per_s": B * world * args.steps / elapsed,
-                   "parallelism": f"frame-sharded dp{world}, one all-reduce of [N,7] output grads",
+                   "parallelism": (f"frames sharded over dp{world}; decoder sharded by UV texels (synchronised BatchNorm "
+                                   f"statistics, outputs assembled with one all-reduce, parameter gradients summed)"
+                                   if parallel.texel_sharding() else
+                                   f"frame-sharded dp{world}, one all-reduce of [N,7] output grads"
+                                   + ("" if args.stage == 1 else ", synchronised BatchNorm, parameter gradients averaged")),
                    "mean_tile_pairs_per_frame": mean_pairs, "final_loss": final_loss},
     }
     if probe:
