@@ -442,7 +442,7 @@ def main():
         if dom_family in dflops:
             # HBM bytes of one 128->128 launch of this family (PMC passes committed under profiles/)
             traffic, traffic_note = None, None
-            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
             if os.path.exists(tpath):
                 t = json.load(open(tpath)).get(dom_family)
                 if t:
@@ -479,13 +479,13 @@ def main():
         if "render_bwd" in kern:
             rb = kern["render_bwd"]
             traffic, traffic_note = None, None
-            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
             if os.path.exists(tpath) and (N, H, B) == (200_000, 1024, 2):
                 t = json.load(open(tpath)).get("render_bwd")
                 if t:
                     traffic = (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0
                     traffic_note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of this command, "
-                                    "profiles/r01_pmc_render.txt; 2*FETCH+WRITE (gfx950 wide-read correction)")
+                                    "profiles/r02_pmc_traffic.txt; 2*FETCH+WRITE (gfx950 wide-read correction)")
             out["roofline_raster_bwd"] = {
                 "kernel": "render_bwd", "bound": "hbm", "achieved": rb["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": rb["frac_of_peak"], "traffic": traffic, "traffic_note": traffic_note, "avg_us": rb["avg_us"],

@@ -29,7 +29,9 @@
 #define GSR_GRAD_STRIDE 16                   // floats per Gaussian in grad_acc: one 64-byte line per record, so a
                                              // wave's 9 atomics on a Gaussian touch exactly one line
 #define GSR_SEG_PIX 16                       // pixels of a render block (4x4) = checkpoints per segment
+#ifndef GSR_BWD_BLOCKS
 #define GSR_BWD_BLOCKS 2048                  // persistent workgroups of render_bwd (256 CUs x 8)
+#endif
 #define GSR_SEG_COUNTERS 64                  // segment slots are handed out by 64 counters on separate 256-byte
                                              // lines: 20k returning atomics on ONE address serialise at ~9-11 ns
                                              // each (measured 200 us per frame), on one LINE barely better
