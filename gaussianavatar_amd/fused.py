@@ -414,6 +414,13 @@ def _decoder_bn_layers():
 # measured on MI355X: riding the head weight gradient on head_bwd is ~3 % SLOWER per iteration than the
 # separate ganet_wgrad_act pass (head_bwd turns VALU-bound), so it stays off; GA_HEAD_RIDE=1 selects it
 _HEAD_RIDE = os.environ.get("GA_HEAD_RIDE", "0") == "1"
+# hidden 128 -> 128 layers: data gradient + weight gradient in one pass over the activations
+# (ganet_mlp_bwd_fused: 4 instead of 7 [M,128] tensors through HBM). Measured on MI355X, M = 262,144
+# (tools/microbench_bwd_fused.py): 249-259 us fused vs 237-272 us for wgrad_act + mlp_bwd_data back to back —
+# no gain, because the pair was never HBM-bound (both sit at 45-55 % of the fp32-MFMA issue rate, and one
+# wave per SIMD with 320 accumulator registers leaves nothing to hide the operand waits). Parity-tested and
+# kept as an A/B switch (GA_FUSED_BWD=1); the two separate kernels stay the default.
+_FUSED_BWD = os.environ.get("GA_FUSED_BWD", "0") == "1"
 
 
 class _RowSweep:
@@ -608,6 +615,32 @@ class _DecoderFn(torch.autograd.Function):
                 W.stride(0), _ptr(out), out.stride(0), int(accumulate), _ptr(sz), 0 if sz is None else sz.stride(0),
                 _ptr(sc), _ptr(sh), _ptr(col_part) if src is not None else None, sweep.next(), st))
 
+        fuse_ok = _FUSED_BWD and M % 32 == 0 and wg_bytes >= lib.ganet_mlp_bwd_fused_workspace()
+        n_fused = lib.ganet_mlp_bwd_fused_parts()
+        if fuse_ok and n_fused * 256 > col_part.numel():
+            col_part = torch.empty(n_fused * 256, dtype=torch.float32, device=dev)
+
+        def layer_bwd(i, src):
+            """hidden layer i (128 -> 128, input = act(bn(zs[src]))): d weight, d bias, and G of the source
+            layer written into a new tensor (with its column sums in col_part). One pass when the fused
+            kernel applies, else weight gradient + data gradient."""
+            Gs[src] = f32(M, 128)
+            if not fuse_ok:
+                dW, db = wgrad(None, i, src)
+                data_grad(i, conv_w[i], Gs[src], False, src)
+                return dW, db, n_data
+            dW, db = f32(128, 128), f32(128)
+            j = njobs[0]
+            ws = wg_ws.data_ptr() + j * wg_bytes
+            W = conv_w[i].contiguous()
+            _native.ganet_check(lib.ganet_mlp_bwd_fused(
+                M, _ptr(Gs[i]), _ptr(zs[i]), _ptr(coefs[i]), _ptr(W), _ptr(Gs[src]), _ptr(zs[src]),
+                _ptr(stats[src][2]), _ptr(stats[src][3]), _ptr(col_part), ws, wg_bytes, sweep.next(), st))
+            jobs[j].workspace, jobs[j].M, jobs[j].N, jobs[j].K = ws, M, 128, 128
+            jobs[j].dW, jobs[j].db, jobs[j].nblocks = dW.data_ptr(), db.data_ptr(), n_fused
+            njobs[0] = j + 1
+            return dW, db, n_fused
+
         Gs, coefs = [None] * nl, [None] * nl
         heads = [j for j in range(3) if d_outs[j] is not None]
         G5 = f32(M, 128) if heads else None
@@ -634,12 +667,10 @@ class _DecoderFn(torch.autograd.Function):
                                                        zs[i7].stride(0), _ptr(sc7), _ptr(sh7), _ptr(Gs[i7]),
                                                        Gs[i7].stride(0), _ptr(col_part), ws, st))
             finish(i7, n_head)
-            dW, db = wgrad(None, i7, i6)
+            dW, db, nparts = layer_bwd(i7, i6)
             g_conv_w[i7], g_conv_b[i7] = dW.unsqueeze(-1), db
-            Gs[i6] = f32(M, 128)
-            data_grad(i7, conv_w[i7], Gs[i6], False, i6)
             Gs[i7] = None
-            finish(i6, n_data)
+            finish(i6, nparts)
             dW, db = wgrad(None, i6, 4)
             g_conv_w[i6], g_conv_b[i6] = dW.unsqueeze(-1), db
             last = pos == len(heads) - 1
@@ -661,14 +692,13 @@ class _DecoderFn(torch.autograd.Function):
             Gs[3] = f32(M, 128)
             data_grad(4, w5[:, cin:], Gs[3], False, 3)
             Gs[4] = None
+            nparts = n_data
             for i in (3, 2, 1):
-                finish(i, n_data)
-                dW, db = wgrad(None, i, i - 1)
+                finish(i, nparts)
+                dW, db, nparts = layer_bwd(i, i - 1)
                 g_conv_w[i], g_conv_b[i] = dW.unsqueeze(-1), db
-                Gs[i - 1] = f32(M, 128)
-                data_grad(i, conv_w[i], Gs[i - 1], False, i - 1)
                 Gs[i] = None
-            finish(0, n_data)
+            finish(0, nparts)
             dW0, db0 = wgrad(None, 0, None, _K1_PAD)
             if need_dx:
                 data_grad(0, conv_w[0], dx, True, None)

@@ -591,3 +591,46 @@ def test_l1_ssim_pair_cache_respects_grad_mode():
     assert s.requires_grad
     s.backward()
     assert img.grad is not None and float(img.grad.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("row_order", [0, 2])
+@pytest.mark.parametrize("M", [262144, 32 * 1031, 64])
+def test_mlp_bwd_fused_matches_float64(M, row_order):
+    """ganet_mlp_bwd_fused: data gradient (-> G_src with its column sums) AND weight / bias gradient of a hidden
+    128 -> 128 layer in one pass, against float64 torch."""
+    from gaussianavatar_amd import _native, fused
+    lib = _native.ganet()
+    torch.manual_seed(M % 29)
+    dev = torch.device("cuda")
+    G = torch.randn(M, 128, device=dev)
+    z = torch.randn(M, 128, device=dev) * 2
+    coef = torch.randn(3, 128, device=dev)
+    W = torch.randn(128, 128, device=dev) * 0.1                  # [out n, in o]
+    src_z = torch.randn(M, 128, device=dev) * 2
+    sc = torch.empty(128, device=dev).uniform_(0.3, 2.0)
+    sh = torch.empty(128, device=dev).uniform_(-12, 25)
+    out = torch.full((M, 128), float("nan"), device=dev)
+    parts = lib.ganet_mlp_bwd_fused_parts()
+    part = torch.zeros(parts * 256, device=dev)
+    wsb = lib.ganet_mlp_bwd_fused_workspace()
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    _native.ganet_check(lib.ganet_mlp_bwd_fused(M, fused._ptr(G), fused._ptr(z), fused._ptr(coef), fused._ptr(W),
+                                                fused._ptr(out), fused._ptr(src_z), fused._ptr(sc), fused._ptr(sh),
+                                                fused._ptr(part), ws.data_ptr(), wsb, row_order, fused._stream(dev)))
+    dW, db = torch.empty(128, 128, device=dev), torch.empty(128, device=dev)
+    jobs = (_native.GanetWgradJob * 1)()
+    jobs[0].workspace, jobs[0].M, jobs[0].N, jobs[0].K = ws.data_ptr(), M, 128, 128
+    jobs[0].dW, jobs[0].db, jobs[0].nblocks = dW.data_ptr(), db.data_ptr(), parts
+    _native.ganet_check(lib.ganet_wgrad_reduce_batch(1, jobs, fused._stream(dev)))
+    dz = coef[0].double() * G.double() + coef[1].double() * z.double() + coef[2].double()
+    u = src_z.double() * sc.double() + sh.double()
+    ref = (dz @ W.double()) * torch.where(u > 20, torch.ones_like(u), torch.sigmoid(u))
+    assert float((out.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 2e-5
+    p = part.reshape(parts, 2, 128).double().sum(0)
+    assert float((p[0] - ref.sum(0)).abs().max()) <= 1e-4 * float(ref.abs().sum(0).max()) + 1e-3
+    r2 = (ref * src_z.double()).sum(0)
+    assert float((p[1] - r2).abs().max()) <= 1e-4 * float((ref * src_z.double()).abs().sum(0).max()) + 1e-3
+    x = torch.nn.functional.softplus(u)
+    refW = dz.t() @ x
+    assert float((dW.double() - refW).abs().max()) <= 2e-5 * float(refW.abs().max()) + 1e-4
+    assert float((db.double() - dz.sum(0)).abs().max()) <= 2e-5 * float(dz.abs().sum(0).max()) + 1e-4
