@@ -248,14 +248,16 @@ def test_wgrad_act_matches_torch(M, N, K, act, row_order):
     assert float((db.double() - rb).abs().max()) <= 2e-5 * float(rb.abs().max()) + 1e-4
 
 
-@pytest.mark.parametrize("M", [20000, 4099])
-def test_fused_decoder_equals_per_layer_formulation(M, monkeypatch):
+@pytest.mark.parametrize("M,one_pass", [(20000, False), (4099, False), (20000 // 32 * 32, True)])
+def test_fused_decoder_equals_per_layer_formulation(M, one_pass, monkeypatch):
     """The whole-decoder function on the fused layer kernels (reference widths: 66 -> 128 x 5 -> three
     heads) against the per-layer formulation (vendor GEMM + fused BN kernels) on the same device:
-    outputs, every parameter gradient, the input gradient and the BatchNorm running statistics."""
+    outputs, every parameter gradient, the input gradient and the BatchNorm running statistics.
+    one_pass: the opt-in single-pass hidden-layer backward (ganet_mlp_bwd_fused, GA_FUSED_BWD=1)."""
     import copy
     from gaussianavatar_amd import fused
     from gaussianavatar_amd.network import ShapeDecoder
+    monkeypatch.setattr(fused, "_FUSED_BWD", one_pass)
     torch.manual_seed(1)
     dec_a = ShapeDecoder(66, 128).cuda().train()
     with torch.no_grad():
@@ -286,6 +288,7 @@ def test_fused_decoder_equals_per_layer_formulation(M, monkeypatch):
     dec_a.eval(); dec_b.eval()
     with torch.no_grad():
         monkeypatch.undo()
+        monkeypatch.setattr(fused, "_FUSED_BWD", one_pass)
         assert fused.decoder_supported(dec_a, x_a.detach())
         e_a = dec_a.forward_points(x_a.detach())
         monkeypatch.setattr(fused, "decoder_supported", lambda dec, x: False)
