@@ -188,9 +188,9 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_mlp_stats_floats.argtypes = [c_int32]
         lib.ganet_mlp_fwd.restype = c_int
         lib.ganet_mlp_fwd.argtypes = [c_int64, c_int32, c_int32, c_int32, P, c_int64, P, c_int64, P, P, P, P, P,
-                                      c_int64, P, c_int32, P]
+                                      c_int64, P, P, c_int32, P]
         lib.ganet_mlp_stats.restype = c_int
-        lib.ganet_mlp_stats.argtypes = [c_int64, c_int32, P, P, P, c_float, P, P, P, P, P, P, c_float, P, P]
+        lib.ganet_mlp_stats.argtypes = [c_int64, c_int32, P, P, P, c_float, P, P, P, P, P, P, c_float, P, P, P]
         lib.ganet_wgrad_act_workspace.restype = c_size_t
         lib.ganet_wgrad_act_workspace.argtypes = [c_int64, c_int32, c_int32]
         lib.ganet_wgrad_act.restype = c_int

@@ -53,7 +53,7 @@ mlp_fwd_kernel(int64_t M, int N, const float* __restrict__ x1, int64_t ld1,
                const float* __restrict__ x2, int64_t ld2, const float* __restrict__ in_scale,
                const float* __restrict__ in_shift, const float* __restrict__ W,
                const float* __restrict__ bias, float* __restrict__ z, int64_t ldz,
-               float* __restrict__ col_part, int reverse) {
+               float* __restrict__ col_part, const float* __restrict__ stat_shift, int reverse) {
   constexpr int KB = K1B + K2B;         // k-blocks of 8
   constexpr int K = 8 * KB;
   constexpr int LDW4 = K / 4 + 1;       // row stride of W in LDS, in float4
@@ -127,6 +127,12 @@ mlp_fwd_kernel(int64_t M, int N, const float* __restrict__ x1, int64_t ld1,
   float bias_r[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) bias_r[t] = (bias && t * 32 + col < N) ? bias[t * 32 + col] : 0.f;
+  // the column statistics are accumulated about a per-column shift (the BatchNorm layer's running mean):
+  // sum (z - s), sum (z - s)^2 — E[z^2] - mean^2 from raw fp32 sums cancels catastrophically once a
+  // column's |mean| is large against its standard deviation
+  float sshift[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) sshift[t] = (stat_shift && t * 32 + col < N) ? stat_shift[t * 32 + col] : 0.f;
 
   for (int64_t slab = wave_global; slab < nslab; slab += wave_stride) {
     point_at(min(slab + wave_stride, nslab - 1), p1n, p2n);   // branch-free prefetch target
@@ -190,8 +196,9 @@ mlp_fwd_kernel(int64_t M, int N, const float* __restrict__ x1, int64_t ld1,
         for (int r = 0; r < 16; ++r) {
           const float v = acc[t][r] + bn_;
           zr[((r & 3) + 8 * (r >> 2)) * ldz + t * 32] = v;
-          csum[t] += v;
-          csq[t] = fmaf(v, v, csq[t]);
+          const float d = v - sshift[t];
+          csum[t] += d;
+          csq[t] = fmaf(d, d, csq[t]);
         }
       }
     } else {
@@ -205,8 +212,9 @@ mlp_fwd_kernel(int64_t M, int N, const float* __restrict__ x1, int64_t ld1,
           if (row < M && n < N) {
             const float v = acc[t][r] + bn_;
             z[row * ldz + n] = v;
-            csum[t] += v;
-            csq[t] = fmaf(v, v, csq[t]);
+            const float d = v - sshift[t];
+            csum[t] += d;
+            csq[t] = fmaf(d, d, csq[t]);
           }
         }
       }
@@ -242,7 +250,7 @@ mlp_stats_kernel(int nparts, int NP, int64_t M, const float* __restrict__ col_pa
                  float* __restrict__ mean_out, float* __restrict__ rstd_out,
                  float* __restrict__ scale_out, float* __restrict__ shift_out,
                  float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
-                 long long* __restrict__ num_batches_tracked) {
+                 long long* __restrict__ num_batches_tracked, const float* __restrict__ stat_shift) {
   __shared__ double s_s[256], s_q[256];
   const int n = blockIdx.x;
   double s = 0.0, q = 0.0;
@@ -257,8 +265,11 @@ mlp_stats_kernel(int nparts, int NP, int64_t M, const float* __restrict__ col_pa
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    const double mean = s_s[0] / (double)M;
-    double var = s_q[0] / (double)M - mean * mean;
+    // sums about the shift s: mean = s + S1 / M, var = S2 / M - (S1 / M)^2 (stat_shift may alias running_mean:
+    // it is read here, before the update below)
+    const double dm = s_s[0] / (double)M;
+    const double mean = (stat_shift ? (double)stat_shift[n] : 0.0) + dm;
+    double var = s_q[0] / (double)M - dm * dm;
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float sc = gamma[n] * rstd;
@@ -616,7 +627,7 @@ size_t ganet_mlp_stats_floats(int32_t N) {
 int ganet_mlp_fwd(int64_t M, int32_t N, int32_t K1, int32_t K2, const float* x1, int64_t ld1,
                   const float* x2, int64_t ld2, const float* in_scale, const float* in_shift,
                   const float* W, const float* bias, float* z, int64_t ldz, float* col_part,
-                  int32_t row_order, void* stream_) {
+                  const float* stat_shift, int32_t row_order, void* stream_) {
   const bool bad_x1 = K1 > 0 && (!x1 || (ld1 % 4) != 0 || ld1 < K1 || !aligned16(x1));
   const bool bad_x2 = K2 > 0 && (!x2 || (ld2 % 4) != 0 || ld2 < K2 || !aligned16(x2) || !in_scale ||
                                  !in_shift || !aligned16(in_scale) || !aligned16(in_shift));
@@ -642,7 +653,7 @@ int ganet_mlp_fwd(int64_t M, int32_t N, int32_t K1, int32_t K2, const float* x1,
     }                                                                                              \
     ProfScope prof_(K_MLP_FWD, stream);                                                            \
     hipLaunchKernelGGL((mlp_fwd_kernel<A, B, T>), grid, block, lds, stream, M, N, x1, ld1, x2, ld2, \
-                       in_scale, in_shift, W, bias, z, ldz, col_part, row_order == 2 ? 1 : 0);     \
+                       in_scale, in_shift, W, bias, z, ldz, col_part, stat_shift, row_order == 2 ? 1 : 0);     \
   } while (0)
   // the decoder's shapes: input layer (K1 = 72 = 66 padded), hidden layers (K2 = 128), the skip
   // layer (72 + 128) and the 3/1/3-column output heads (one 32-column tile)
@@ -661,7 +672,7 @@ int ganet_mlp_fwd(int64_t M, int32_t N, int32_t K1, int32_t K2, const float* x1,
 int ganet_mlp_stats(int64_t M, int32_t N, const float* col_part, const float* gamma,
                     const float* beta, float eps, float* mean, float* rstd, float* scale,
                     float* shift, float* running_mean, float* running_var, float momentum,
-                    int64_t* num_batches_tracked, void* stream_) {
+                    int64_t* num_batches_tracked, const float* stat_shift, void* stream_) {
   if (M <= 0 || N <= 0 || N > 128 || !col_part || !gamma || !beta || !mean || !rstd || !scale ||
       !shift || ((running_mean == nullptr) != (running_var == nullptr))) {
     set_error("ganet_mlp_stats: invalid arguments");
@@ -672,7 +683,7 @@ int ganet_mlp_stats(int64_t M, int32_t N, const float* col_part, const float* ga
   hipLaunchKernelGGL(mlp_stats_kernel, dim3(N), dim3(256), 0, static_cast<hipStream_t>(stream_),
                      FWD_BLOCKS, np, M, col_part, gamma, beta, eps, mean, rstd, scale, shift,
                      running_mean, running_var, momentum,
-                     reinterpret_cast<long long*>(num_batches_tracked));
+                     reinterpret_cast<long long*>(num_batches_tracked), stat_shift);
   return check_hip(hipGetLastError(), "mlp_stats_kernel");
 }
 

@@ -439,14 +439,14 @@ class _RowSweep:
         return 1 if self.k % 2 else 2
 
 
-def _mlp_fwd(lib, M, N, x1, x2, scale, shift, W, bias, col_part, dev, row_order=0):
+def _mlp_fwd(lib, M, N, x1, x2, scale, shift, W, bias, col_part, dev, row_order=0, stat_shift=None):
     z = torch.empty((M, N), dtype=torch.float32, device=dev)
     K1 = 0 if x1 is None else x1.shape[1]
     K2 = 0 if x2 is None else x2.shape[1]
     _native.ganet_check(lib.ganet_mlp_fwd(
         M, N, K1, K2, _ptr(x1), 0 if x1 is None else x1.stride(0), _ptr(x2), 0 if x2 is None else x2.stride(0),
-        _ptr(scale), _ptr(shift), _ptr(W), _ptr(bias), _ptr(z), z.stride(0), _ptr(col_part), row_order,
-        _stream(dev)))
+        _ptr(scale), _ptr(shift), _ptr(W), _ptr(bias), _ptr(z), z.stride(0), _ptr(col_part), _ptr(stat_shift),
+        row_order, _stream(dev)))
     return z
 
 
@@ -487,6 +487,12 @@ class _DecoderFn(torch.autograd.Function):
         zs, stats = [], []            # per BN layer: pre-activation, (mean, rstd, scale, shift)
         sweep = _RowSweep()
 
+        def stat_shift_of(i):
+            """BatchNorm statistics are accumulated about the layer's running mean (sum (z - s), sum (z - s)^2):
+            raw fp32 sums would cancel in E[z^2] - mean^2 once |mean| >> std."""
+            bn = getattr(dec, layers[i][1])
+            return bn.running_mean if (training and bn.track_running_stats) else None
+
         def bn_stats(i, z):
             bn = getattr(dec, layers[i][1])
             if training:
@@ -498,7 +504,7 @@ class _DecoderFn(torch.autograd.Function):
                     Mg, 128, _ptr(col_part), _ptr(gammas[i]), _ptr(betas[i]), float(bn.eps), _ptr(mean), _ptr(rstd),
                     _ptr(sc), _ptr(sh), _ptr(bn.running_mean if track else None),
                     _ptr(bn.running_var if track else None), float(bn.momentum),
-                    _ptr(bn.num_batches_tracked if track else None), _stream(dev)))
+                    _ptr(bn.num_batches_tracked if track else None), _ptr(stat_shift_of(i)), _stream(dev)))
             else:
                 mean = bn.running_mean
                 rstd = torch.rsqrt(bn.running_var + bn.eps)
@@ -511,7 +517,7 @@ class _DecoderFn(torch.autograd.Function):
             x2 = sc = sh = None
             if src is not None:
                 x2, (_, _, sc, sh) = zs[src], stats[src]
-            z = _mlp_fwd(lib, M, 128, x1, x2, sc, sh, W, conv_b[i], col_part, dev, sweep.next())
+            z = _mlp_fwd(lib, M, 128, x1, x2, sc, sh, W, conv_b[i], col_part, dev, sweep.next(), stat_shift_of(i))
             zs.append(z)
             stats.append(bn_stats(i, z))
 

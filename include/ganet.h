@@ -84,7 +84,9 @@ int ganet_ssim_bwd(int32_t planes, int32_t H, int32_t W, const float* img1, cons
  * connection into conv5). K1 and K2 are multiples of 8, row strides multiples of 4 floats, operands
  * 16-byte aligned; supported shapes: (K1,K2,N) = (72,0,128) (0,128,128) (72,128,128) (0,128,<=32).
  * col_part (optional, ganet_mlp_stats_floats(N) floats) receives per-workgroup partial column sums and
- * sums of squares of z; ganet_mlp_stats reduces them to mean/rstd, the folded scale/shift for the
+ * sums of squares of z - stat_shift (stat_shift [N] or NULL = 0: a per-column shift, e.g. the layer's running
+ * mean, against the cancellation of E[z^2] - mean^2; pass the same pointer to ganet_mlp_stats, it may alias
+ * running_mean); ganet_mlp_stats reduces them to mean/rstd, the folded scale/shift for the
  * NEXT layer's prologue, and updates the running statistics like F.batch_norm(training=True).
  * ganet_wgrad_act is the matching weight gradient: dW[n,k] = sum_m g[m,n] softplus(in_scale_k
  * x[m,k] + in_shift_k), db[n] = sum_m g[m,n] (N, K <= 128). */
@@ -103,11 +105,11 @@ size_t ganet_mlp_stats_floats(int32_t N);
 int ganet_mlp_fwd(int64_t M, int32_t N, int32_t K1, int32_t K2, const float* x1, int64_t ld1,
                   const float* x2, int64_t ld2, const float* in_scale, const float* in_shift,
                   const float* W, const float* bias, float* z, int64_t ldz, float* col_part,
-                  int32_t row_order, void* stream);
+                  const float* stat_shift, int32_t row_order, void* stream);
 int ganet_mlp_stats(int64_t M, int32_t N, const float* col_part, const float* gamma,
                     const float* beta, float eps, float* mean, float* rstd, float* scale,
                     float* shift, float* running_mean, float* running_var, float momentum,
-                    int64_t* num_batches_tracked, void* stream);
+                    int64_t* num_batches_tracked, const float* stat_shift, void* stream);
 size_t ganet_wgrad_act_workspace(int64_t M, int32_t N, int32_t K);
 /* gz/gcoef (both or neither): the g operand is assembled on load as gcoef[0][n] g + gcoef[1][n] gz +
  * gcoef[2][n] — the BatchNorm backward of the layer folded to per-column coefficients (see

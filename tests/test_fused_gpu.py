@@ -206,7 +206,7 @@ def test_mlp_fwd_layer_matches_torch(M, K1, K2, N, row_order):
         _native.ganet_check(lib.ganet_mlp_stats(M, N, fused._ptr(part), fused._ptr(bn.weight), fused._ptr(bn.bias),
                                                 bn.eps, fused._ptr(mean), fused._ptr(rstd), fused._ptr(s2),
                                                 fused._ptr(h2), fused._ptr(rm), fused._ptr(rv), bn.momentum,
-                                                fused._ptr(nbt), fused._stream(torch.device(dev))))
+                                                fused._ptr(nbt), None, fused._stream(torch.device(dev))))
         y_ref = bn(z)
         torch.testing.assert_close(z * s2 + h2, y_ref, rtol=1e-4, atol=1e-4)
         torch.testing.assert_close(rm, bn.running_mean, rtol=1e-5, atol=1e-6)
@@ -637,3 +637,35 @@ def test_mlp_bwd_fused_matches_float64(M, row_order):
     refW = dz.t() @ x
     assert float((dW.double() - refW).abs().max()) <= 2e-5 * float(refW.abs().max()) + 1e-4
     assert float((db.double() - dz.sum(0)).abs().max()) <= 2e-5 * float(dz.abs().sum(0).max()) + 1e-4
+
+
+def test_batchnorm_statistics_survive_a_large_mean():
+    """Advisor finding r1: E[z^2] - mean^2 from raw fp32 sums cancels once |mean| >> std. The fused layer
+    accumulates its statistics about the BatchNorm layer's running mean: with columns at mean ~1e3, std ~1
+    the folded scale/shift must still match float64 BatchNorm (and the unshifted sums must visibly not)."""
+    from gaussianavatar_amd import _native, fused
+    lib = _native.ganet()
+    dev = torch.device("cuda")
+    torch.manual_seed(5)
+    M, N = 262144, 128
+    x2 = torch.randn(M, 128, device=dev)
+    sc, sh = torch.ones(128, device=dev), torch.zeros(128, device=dev)
+    W = torch.randn(N, 128, device=dev) * 0.05
+    b = torch.full((N,), 1000.0, device=dev) + torch.randn(N, device=dev)          # |mean| ~ 1e3, std ~ 0.4
+    gamma, beta = torch.ones(N, device=dev), torch.zeros(N, device=dev)
+    z64 = torch.nn.functional.softplus(x2.double()) @ W.double().t() + b.double()
+    var64 = z64.var(0, unbiased=False)
+    errs = {}
+    for name, shift in (("shifted", z64.mean(0).float() + 0.3), ("raw", None)):      # running mean: close, not exact
+        part = torch.zeros(lib.ganet_mlp_stats_floats(N), device=dev)
+        fused._mlp_fwd(lib, M, N, None, x2, sc, sh, W, b, part, dev, 0, shift)
+        mean, rstd, s2, h2 = (torch.empty(N, device=dev) for _ in range(4))
+        _native.ganet_check(lib.ganet_mlp_stats(M, N, fused._ptr(part), fused._ptr(gamma), fused._ptr(beta), 1e-5,
+                                                fused._ptr(mean), fused._ptr(rstd), fused._ptr(s2), fused._ptr(h2),
+                                                None, None, 0.1, None, fused._ptr(shift), fused._stream(dev)))
+        var = 1.0 / rstd.double() ** 2 - 1e-5
+        errs[name] = float(((var - var64).abs() / var64).max())
+        if name == "shifted":
+            assert float((mean.double() - z64.mean(0)).abs().max()) <= 1e-3
+    assert errs["shifted"] <= 1e-3, errs
+    assert errs["raw"] > 10 * errs["shifted"], errs            # the cancellation the shift removes
