@@ -161,36 +161,53 @@ scatter_kernel(int P, int gx, int64_t max_pairs, const int4* __restrict__ rect,
 
 // ------------------------------------------------------------------ K4
 // Bitonic sort of n2 (power of two) keys held in LDS by SORT_THREADS threads.
-// Thread t owns compare-exchange pair t of a stage; the 64 threads of a wave own 64
-// consecutive pairs = one aligned block of 128 keys. Every stage with distance j <= 64 stays
-// inside such a block, so runs of those stages need no workgroup barrier (LDS operations of one
-// wave execute in order) — only the j >= 128 stages exchange data between waves.
-__device__ __forceinline__ void cmp_swap(uint64_t* s, int t, int j, int k) {
-  const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-  const int l = i | j;
-  const uint64_t a = s[i], b = s[l];
-  const bool up = (i & k) == 0;
-  if ((a > b) == up) { s[i] = b; s[l] = a; }
+// The plain network (one compare-exchange per thread and stage: two 8-byte reads + two writes) is
+// LDS-BANDWIDTH bound: a 4096-key list moves 64 KiB per stage, 78 stages = 5 MB, at 128 B/clk per CU
+// shared by the two resident workgroups = 920 cycles per stage (measured). So stages are taken three
+// at a time: a thread loads the 8 keys that three consecutive distances (j, j/2, j/4 — a closed
+// sub-network) connect, runs the 12 compare-exchanges in registers and writes the 8 keys back: one LDS
+// round trip per three stages (30 instead of 78 for 4096 keys). All 8 keys of a thread share the
+// direction bit (i & k), because k lies above every distance of its level.
+template <int S>
+__device__ __forceinline__ void bitonic_chunk(uint64_t* s, int t, int jl, int k) {
+  constexpr int NK = 1 << S;
+  const int base = ((t & ~(jl - 1)) << S) | (t & (jl - 1));      // S zero bits inserted at log2(jl)
+  const bool up = (base & k) == 0;
+  uint64_t key[NK];
+#pragma unroll
+  for (int m = 0; m < NK; ++m) key[m] = s[base + m * jl];
+#pragma unroll
+  for (int d = S - 1; d >= 0; --d)
+#pragma unroll
+    for (int m = 0; m < NK; ++m)
+      if (!(m & (1 << d))) {
+        const uint64_t a = key[m], b = key[m | (1 << d)];
+        const bool sw = (a > b) == up;
+        key[m] = sw ? b : a;
+        key[m | (1 << d)] = sw ? a : b;
+      }
+#pragma unroll
+  for (int m = 0; m < NK; ++m) s[base + m * jl] = key[m];
 }
 
 template <int SORT_THREADS>
 __device__ __forceinline__ void bitonic_sort_lds(uint64_t* s, int n2, int tid) {
-  const int half = n2 >> 1;
   for (int k = 2; k <= n2; k <<= 1) {
-    int j = k >> 1;
-    for (; j >= 2 * GSR_WAVE; j >>= 1) {          // cross-wave stages
-      for (int t = tid; t < half; t += SORT_THREADS) cmp_swap(s, t, j, k);
+    int j = k >> 1;                       // distances of this level: j, j/2, ..., 1
+    while (j >= 1) {
+      const int left = 32 - __clz(j);     // stages left in the level
+      // three stages per round trip whatever the list length (measured on the bench scene, one frame: 1 stage
+      // per trip 48.9 us, 2: 35.7, 3: 34.3, "as many as keep every thread busy": 39.6)
+      const int st = left >= 3 ? 3 : left;
+      const int jl = j >> (st - 1);       // smallest distance of the chunk
+      const int nthr = n2 >> st;
+      if (st == 3) { for (int t = tid; t < nthr; t += SORT_THREADS) bitonic_chunk<3>(s, t, jl, k); }
+      else if (st == 2) { for (int t = tid; t < nthr; t += SORT_THREADS) bitonic_chunk<2>(s, t, jl, k); }
+      else { for (int t = tid; t < nthr; t += SORT_THREADS) bitonic_chunk<1>(s, t, jl, k); }
       __syncthreads();
+      j >>= st;
     }
-    for (int t = tid; t < half; t += SORT_THREADS) {   // wave-local stages j = min(k/2,64)..1
-      for (int jj = j; jj > 0; jj >>= 1) {
-        cmp_swap(s, t, jj, k);
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-    if (k >= 2 * GSR_WAVE) __syncthreads();       // next k starts with a cross-wave stage
   }
-  __syncthreads();
 }
 
 __device__ __forceinline__ int next_pow2(int n) {
@@ -211,35 +228,17 @@ __device__ __forceinline__ int merge_split(const uint64_t* A, int na, const uint
   return lo;
 }
 
-// CAP keys fit the LDS image (one class is launched: CAP = SORT_CAP, every list length).
-template <int CAP, int SORT_THREADS>
-__global__ void __launch_bounds__(SORT_THREADS)
-tile_sort_kernel(int64_t max_pairs, const uint32_t* __restrict__ tile_order,
-                 const uint32_t* __restrict__ tile_offset,
-                 uint64_t* __restrict__ pair_key, uint64_t* __restrict__ pair_tmp,
-                 uint32_t* __restrict__ point_list, size_t ws_stride) {
-  __shared__ uint64_t s_key[CAP];
-  {
-    const size_t off = (size_t)blockIdx.y * ws_stride;
-    tile_order = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(tile_order) + off);
-    tile_offset = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(tile_offset) + off);
-    pair_key = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(pair_key) + off);
-    pair_tmp = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(pair_tmp) + off);
-    point_list = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(point_list) + off);
-  }
-  const int tile = (int)tile_order[blockIdx.x];      // largest lists first (tile_scan_kernel)
-  const int tid = threadIdx.x;
-  const int64_t cap = max_pairs;
+// One tile's list, sorted by all SORT_THREADS threads of the workgroup (s_key: SORT_CAP keys of LDS).
+template <int SORT_THREADS>
+__device__ __forceinline__ void sort_tile_whole(int tile, int64_t cap, const uint32_t* __restrict__ tile_offset,
+                                                uint64_t* __restrict__ pair_key, uint64_t* __restrict__ pair_tmp,
+                                                uint32_t* __restrict__ point_list, uint64_t* s_key, int tid) {
   const int64_t start = min((int64_t)tile_offset[tile], cap);
   const int64_t end = min((int64_t)tile_offset[tile + 1], cap);
   const int n = (int)(end - start);
   if (n <= 0) return;
   uint64_t* keys = pair_key + start;
   uint32_t* out = point_list + start;
-  if (n == 1) {
-    if (tid == 0) out[0] = (uint32_t)keys[0];
-    return;
-  }
   if (n <= SORT_CAP) {
     const int n2 = next_pow2(n);
     for (int i = tid; i < n2; i += SORT_THREADS) s_key[i] = (i < n) ? keys[i] : ~0ull;
@@ -248,7 +247,6 @@ tile_sort_kernel(int64_t max_pairs, const uint32_t* __restrict__ tile_order,
     for (int i = tid; i < n; i += SORT_THREADS) out[i] = (uint32_t)s_key[i];
     return;
   }
-  if (CAP != SORT_CAP) return;        // (only the large class meets lists beyond its LDS capacity)
   // Oversized list: sort SORT_CAP-sized runs in LDS, then merge runs through HBM.
   for (int c0 = 0; c0 < n; c0 += SORT_CAP) {
     const int m = min(SORT_CAP, n - c0);
@@ -286,6 +284,31 @@ tile_sort_kernel(int64_t max_pairs, const uint32_t* __restrict__ tile_order,
   for (int i = tid; i < n; i += SORT_THREADS) out[i] = (uint32_t)src[i];
 }
 
+// One workgroup per tile, in the size order K2 left (longest lists first). The launch is as long as its
+// longest lists: sorting only the 64 longest tiles of the bench frame takes as long as sorting all 586
+// (32.6 vs 34.3 us) — a 4096-key list is 30 dependent LDS round trips of ~1 us. Measured and rejected:
+// two short lists side by side in one workgroup (no gain), pairing ALL lists (halves the long lists' thread
+// count: 100 -> 144 us per 2 frames), two size classes in two launches (they serialise: 144 us). What would
+// shorten the chain is splitting a long list over several workgroups (partial sorts + merge path through L2).
+template <int SORT_THREADS>
+__global__ void __launch_bounds__(SORT_THREADS)
+tile_sort_kernel(int64_t max_pairs, const uint32_t* __restrict__ tile_order,
+                 const uint32_t* __restrict__ tile_offset,
+                 uint64_t* __restrict__ pair_key, uint64_t* __restrict__ pair_tmp,
+                 uint32_t* __restrict__ point_list, size_t ws_stride) {
+  __shared__ uint64_t s_key[SORT_CAP];
+  {
+    const size_t off = (size_t)blockIdx.y * ws_stride;
+    tile_order = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(tile_order) + off);
+    tile_offset = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(tile_offset) + off);
+    pair_key = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(pair_key) + off);
+    pair_tmp = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(pair_tmp) + off);
+    point_list = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(point_list) + off);
+  }
+  sort_tile_whole<SORT_THREADS>((int)tile_order[blockIdx.x], max_pairs, tile_offset, pair_key, pair_tmp, point_list,
+                                s_key, threadIdx.x);
+}
+
 }  // namespace
 
 hipError_t launch_binning(const Dims& d, const Workspace& ws, const Batch& bt, hipStream_t stream) {
@@ -306,9 +329,10 @@ hipError_t launch_binning(const Dims& d, const Workspace& ws, const Batch& bt, h
     if (e != hipSuccess) return e;
     {
       ProfScope prof_(K_SORT, stream);
-      // (two size classes — 16 KiB / 512 threads for lists <= 2048, the rest as here — were measured: the two
-      // launches serialise and the 46 long lists then run on an empty chip: 100 -> 144 us per 2 frames)
-      hipLaunchKernelGGL((tile_sort_kernel<SORT_CAP, 1024>), dim3(d.T, bt.frames), dim3(1024), 0, stream, d.max_pairs,
+      // (two size classes in two launches — 16 KiB / 512 threads for lists <= 2048, the rest with 64 KiB — were
+      // measured and rejected: the launches serialise and the 46 long lists then run on an empty chip,
+      // 100 -> 144 us per 2 frames)
+      hipLaunchKernelGGL((tile_sort_kernel<1024>), dim3(d.T, bt.frames), dim3(1024), 0, stream, d.max_pairs,
                        ws.tile_count, ws.tile_offset, ws.pair_key, ws.pair_tmp, ws.point_list, bt.ws_stride);
     }
     e = hipGetLastError();
