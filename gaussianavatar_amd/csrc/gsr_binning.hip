@@ -284,29 +284,136 @@ __device__ __forceinline__ void sort_tile_whole(int tile, int64_t cap, const uin
   for (int i = tid; i < n; i += SORT_THREADS) out[i] = (uint32_t)src[i];
 }
 
-// One workgroup per tile, in the size order K2 left (longest lists first). The launch is as long as its
-// longest lists: sorting only the 64 longest tiles of the bench frame takes as long as sorting all 586
-// (32.6 vs 34.3 us) — a 4096-key list is 30 dependent LDS round trips of ~1 us. Measured and rejected:
-// two short lists side by side in one workgroup (no gain), pairing ALL lists (halves the long lists' thread
-// count: 100 -> 144 us per 2 frames), two size classes in two launches (they serialise: 144 us). What would
-// shorten the chain is splitting a long list over several workgroups (partial sorts + merge path through L2).
-template <int SORT_THREADS>
-__global__ void __launch_bounds__(SORT_THREADS)
-tile_sort_kernel(int64_t max_pairs, const uint32_t* __restrict__ tile_order,
-                 const uint32_t* __restrict__ tile_offset,
-                 uint64_t* __restrict__ pair_key, uint64_t* __restrict__ pair_tmp,
-                 uint32_t* __restrict__ point_list, size_t ws_stride) {
-  __shared__ uint64_t s_key[SORT_CAP];
-  {
-    const size_t off = (size_t)blockIdx.y * ws_stride;
-    tile_order = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(tile_order) + off);
-    tile_offset = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(tile_offset) + off);
-    pair_key = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(pair_key) + off);
-    pair_tmp = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(pair_tmp) + off);
-    point_list = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(point_list) + off);
+// ---- K4 as launched: chunk sorts + merges.
+// One workgroup sorting a whole list makes the launch as long as its longest list: a 4096-key list is 30
+// dependent LDS round trips (~1 us each), the training scene's densest tiles (~4600 entries) pad to 8192 keys
+// — 100 us per 2 frames while the chip idles (sorting only the 64 longest tiles of a frame takes as long as
+// sorting all 586). Measured and rejected on the way: two short lists side by side in one workgroup (no gain),
+// pairing ALL lists (halves the long lists' thread count: 144 us), two size classes in two launches (144 us).
+// So a list is cut into chunks of SORT_CHUNK keys, every chunk is sorted by its own workgroup (16 KiB of LDS:
+// several per CU), and sorted runs are merged pairwise with merge path inside LDS — two passes cover 4 chunks;
+// longer lists (none in avatar scenes) take the one-workgroup path with runs merged through HBM. The order is
+// the same total order (depth bits, then Gaussian index), whatever the decomposition.
+constexpr int SORT_CHUNK = 2048;
+constexpr int SORT_MAX_CHUNKS = 4;
+
+struct TileSpan { int64_t start; int n; };
+__device__ __forceinline__ TileSpan tile_span(const uint32_t* tile_order, const uint32_t* tile_offset, int64_t cap,
+                                              int rank) {
+  const int tile = (int)tile_order[rank];                   // longest lists first (tile_scan_kernel)
+  TileSpan t;
+  t.start = min((int64_t)tile_offset[tile], cap);
+  t.n = (int)(min((int64_t)tile_offset[tile + 1], cap) - t.start);
+  return t;
+}
+
+#define GSR_FRAME_PTRS()                                                                                      \
+  {                                                                                                           \
+    const size_t off = (size_t)blockIdx.y * ws_stride;                                                        \
+    tile_order = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(tile_order) + off);          \
+    tile_offset = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(tile_offset) + off);        \
+    pair_key = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(pair_key) + off);                          \
+    pair_tmp = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(pair_tmp) + off);                          \
+    point_list = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(point_list) + off);                      \
   }
-  sort_tile_whole<SORT_THREADS>((int)tile_order[blockIdx.x], max_pairs, tile_offset, pair_key, pair_tmp, point_list,
-                                s_key, threadIdx.x);
+
+// The grids are SORT_GRID workgroups per frame (and chunk / pair index) that stride over the ranks of the size
+// order (descending size CLASS = floor(log2 n) + 1, tile_scan_kernel; `ordered` = that order exists, T <= 8192)
+// and stop at the first list whose class needs no work: ~590 of 4096 tiles are occupied, and one workgroup per tile and
+// chunk (32k mostly empty 1024-thread workgroups per frame over the four launches) cost more than the sort.
+constexpr int SORT_GRID = 768;
+constexpr int SORT_WG = 512;
+
+// chunk blockIdx.z of the tiles of rank blockIdx.x, + SORT_GRID, ...: sorted in LDS; a single-chunk list goes
+// straight to point_list, otherwise the sorted run replaces the chunk in pair_key
+__global__ void __launch_bounds__(SORT_WG)
+tile_sort_chunk_kernel(int T, int ordered, int64_t max_pairs, const uint32_t* __restrict__ tile_order,
+                       const uint32_t* __restrict__ tile_offset, uint64_t* __restrict__ pair_key,
+                       uint64_t* __restrict__ pair_tmp, uint32_t* __restrict__ point_list, size_t ws_stride) {
+  __shared__ uint64_t s_key[SORT_CHUNK];
+  GSR_FRAME_PTRS();
+  const int tid = threadIdx.x;
+  const int c0 = blockIdx.z * SORT_CHUNK;
+  for (int rank = blockIdx.x; rank < T; rank += gridDim.x) {
+    const TileSpan ts = tile_span(tile_order, tile_offset, max_pairs, rank);
+    if (ts.n <= 0) { if (ordered) break; continue; }        // every later list is empty too
+    if (c0 >= ts.n || ts.n > SORT_MAX_CHUNKS * SORT_CHUNK) continue;
+    const int m = min(SORT_CHUNK, ts.n - c0);
+    uint64_t* keys = pair_key + ts.start + c0;
+    const int m2 = next_pow2(m);
+    __syncthreads();                                        // the previous list's LDS image is dead
+    for (int i = tid; i < m2; i += SORT_WG) s_key[i] = (i < m) ? keys[i] : ~0ull;
+    __syncthreads();
+    bitonic_sort_lds<SORT_WG>(s_key, m2, tid);
+    if (ts.n <= SORT_CHUNK) {
+      for (int i = tid; i < m; i += SORT_WG) point_list[ts.start + i] = (uint32_t)s_key[i];
+    } else {
+      for (int i = tid; i < m; i += SORT_WG) keys[i] = s_key[i];
+    }
+  }
+}
+
+// merge pass PASS (runs of W = SORT_CHUNK << PASS keys): pair blockIdx.z of tile blockIdx.x. Both runs are
+// staged in LDS, every thread takes ITEMS consecutive outputs (merge path). Pass 0 reads pair_key and writes
+// pair_tmp, pass 1 the other way round; the pass that completes a list writes point_list instead.
+template <int PASS>
+__global__ void __launch_bounds__(SORT_WG)
+tile_merge_kernel(int T, int ordered, int64_t max_pairs, const uint32_t* __restrict__ tile_order,
+                  const uint32_t* __restrict__ tile_offset, uint64_t* __restrict__ pair_key,
+                  uint64_t* __restrict__ pair_tmp, uint32_t* __restrict__ point_list, size_t ws_stride) {
+  constexpr int W = SORT_CHUNK << PASS;
+  constexpr int ITEMS = 2 * W / SORT_WG;
+  __shared__ uint64_t s_run[2 * W];
+  GSR_FRAME_PTRS();
+  const int tid = threadIdx.x;
+  const int lo = blockIdx.z * 2 * W;
+  for (int rank = blockIdx.x; rank < T; rank += gridDim.x) {
+    const TileSpan ts = tile_span(tile_order, tile_offset, max_pairs, rank);
+    if (ts.n < W && ordered) break;                         // a lower size class: every later list is one run too
+    if (ts.n <= W || ts.n > SORT_MAX_CHUNKS * SORT_CHUNK || lo >= ts.n) continue;   // one run / long-list path / no such pair
+    const int mid = min(lo + W, ts.n), hi = min(lo + 2 * W, ts.n);
+    const uint64_t* src = (PASS & 1 ? pair_tmp : pair_key) + ts.start + lo;
+    uint64_t* dst = (PASS & 1 ? pair_key : pair_tmp) + ts.start + lo;
+    const int len = hi - lo, na = mid - lo, nb = hi - mid;
+    __syncthreads();
+    for (int i = tid; i < len; i += SORT_WG) s_run[i] = src[i];
+    __syncthreads();
+    const bool last = ts.n <= 2 * W;                        // this pass leaves one run = the sorted list
+    const uint64_t* A = s_run;
+    const uint64_t* B = s_run + na;
+    const int g0 = tid * ITEMS;
+    if (g0 < len) {
+      int ia = merge_split(A, na, B, nb, g0);
+      int ib = g0 - ia;
+      const int cnt = min(ITEMS, len - g0);
+#pragma unroll
+      for (int o = 0; o < ITEMS; ++o) {
+        if (o < cnt) {
+          const bool takeA = (ib >= nb) || (ia < na && A[ia] <= B[ib]);
+          const uint64_t v = takeA ? A[ia++] : B[ib++];
+          if (last) point_list[ts.start + lo + g0 + o] = (uint32_t)v;
+          else dst[g0 + o] = v;
+        }
+      }
+    }
+  }
+}
+
+// lists beyond SORT_MAX_CHUNKS chunks: one workgroup per list (64 KiB of LDS), runs merged through HBM
+__global__ void __launch_bounds__(1024)
+tile_sort_long_kernel(int T, int ordered, int64_t max_pairs, const uint32_t* __restrict__ tile_order,
+                      const uint32_t* __restrict__ tile_offset, uint64_t* __restrict__ pair_key,
+                      uint64_t* __restrict__ pair_tmp, uint32_t* __restrict__ point_list, size_t ws_stride) {
+  __shared__ uint64_t s_key[SORT_CAP];
+  GSR_FRAME_PTRS();
+  for (int rank = blockIdx.x; rank < T; rank += gridDim.x) {
+    const TileSpan ts = tile_span(tile_order, tile_offset, max_pairs, rank);
+    if (ts.n < SORT_MAX_CHUNKS * SORT_CHUNK && ordered) break;         // a lower size class: no long list follows
+    if (ts.n <= SORT_MAX_CHUNKS * SORT_CHUNK) continue;
+    __syncthreads();
+    sort_tile_whole<1024>((int)tile_order[rank], max_pairs, tile_offset, pair_key, pair_tmp, point_list, s_key,
+                          threadIdx.x);
+  }
 }
 
 }  // namespace
@@ -329,11 +436,19 @@ hipError_t launch_binning(const Dims& d, const Workspace& ws, const Batch& bt, h
     if (e != hipSuccess) return e;
     {
       ProfScope prof_(K_SORT, stream);
-      // (two size classes in two launches — 16 KiB / 512 threads for lists <= 2048, the rest with 64 KiB — were
-      // measured and rejected: the launches serialise and the 46 long lists then run on an empty chip,
-      // 100 -> 144 us per 2 frames)
-      hipLaunchKernelGGL((tile_sort_kernel<1024>), dim3(d.T, bt.frames), dim3(1024), 0, stream, d.max_pairs,
-                       ws.tile_count, ws.tile_offset, ws.pair_key, ws.pair_tmp, ws.point_list, bt.ws_stride);
+      const int gx = min(d.T, SORT_GRID);
+      const int ordered = (d.T + SCAN_THREADS - 1) / SCAN_THREADS <= 8;       // tile_scan_kernel: MAXPER
+      hipLaunchKernelGGL(tile_sort_chunk_kernel, dim3(gx, bt.frames, SORT_MAX_CHUNKS), dim3(SORT_WG), 0, stream, d.T,
+                         ordered, d.max_pairs, ws.tile_count, ws.tile_offset, ws.pair_key, ws.pair_tmp, ws.point_list,
+                         bt.ws_stride);
+      hipLaunchKernelGGL(tile_merge_kernel<0>, dim3(gx, bt.frames, SORT_MAX_CHUNKS / 2), dim3(SORT_WG), 0, stream, d.T,
+                         ordered, d.max_pairs, ws.tile_count, ws.tile_offset, ws.pair_key, ws.pair_tmp, ws.point_list,
+                         bt.ws_stride);
+      hipLaunchKernelGGL(tile_merge_kernel<1>, dim3(gx, bt.frames, SORT_MAX_CHUNKS / 4), dim3(SORT_WG), 0, stream, d.T,
+                         ordered, d.max_pairs, ws.tile_count, ws.tile_offset, ws.pair_key, ws.pair_tmp, ws.point_list,
+                         bt.ws_stride);
+      hipLaunchKernelGGL(tile_sort_long_kernel, dim3(min(d.T, 64), bt.frames), dim3(1024), 0, stream, d.T, ordered, d.max_pairs,
+                         ws.tile_count, ws.tile_offset, ws.pair_key, ws.pair_tmp, ws.point_list, bt.ws_stride);
     }
     e = hipGetLastError();
   }

@@ -349,3 +349,10 @@ def test_1080p_parity_with_partial_tile_row(raster_oracle):
     for k in ("dmeans3D", "dcolors", "dscales", "dopacity", "drots"):
         err = np.abs(grads[k] - rb[k]).max() / (np.abs(rb[k]).max() + 1e-12)
         assert err <= GRAD_REL_TOL, (k, err)
+
+
+def test_more_than_8192_tiles_unordered_tile_walk(raster_oracle):
+    """Above 8192 tiles K2 leaves the tile order unsorted: the sort / merge grids must not rely on it."""
+    sc = random_scene(2000, 2064, 2064, seed=21, kind="general", scale_med=0.004)
+    assert ((2064 + 15) // 16) ** 2 > 8192
+    assert_forward_parity(raster_oracle, sc)
