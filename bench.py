@@ -35,6 +35,8 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 EVENT_EVERY = 10          # timed steps whose dominant-family launches carry HIP events (every 20th for K >= 100)
 MFMA_F32_PEAK_TF = 157.3  # dense fp32-input MFMA peak (same guide; v_mfma_f32_32x32x2_f32)
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak (same guide; v_mfma_f32_32x32x16_bf16)
+SPLIT_PRODUCTS = 6        # bf16 MFMAs per fp32 product in the split-operand decoder kernels (csrc/ganet_split.h)
 
 
 def decoder_flops(model, frames: int = 1) -> dict:
@@ -270,7 +272,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from gaussianavatar_amd import fused, rasterizer
+    from gaussianavatar_amd import _native, fused, rasterizer
     from gaussianavatar_amd.avatar_model import AvatarModel, collate_frames, default_params
     from gaussianavatar_amd.losses import l1_loss_w, ssim, weighted_sum
 
@@ -400,7 +402,12 @@ def main():
                                    if parallel.texel_sharding() else
                                    f"frame-sharded dp{world}, one all-reduce of [N,7] output grads"
                                    + ("" if args.stage == 1 else ", synchronised BatchNorm, parameter gradients averaged")),
-                   "mean_tile_pairs_per_frame": mean_pairs, "final_loss": final_loss},
+                   "mean_tile_pairs_per_frame": mean_pairs, "final_loss": final_loss,
+                   "decoder_gemm_arithmetic": (
+                       "fp32 in / fp32 out; operands split exactly into three bf16 pieces, six bf16 MFMA products per "
+                       "fp32 product accumulated in fp32 (csrc/ganet_split.h; error vs float64 <= that of the "
+                       "v_mfma_f32_32x32x2_f32 kernels, tests/test_fused_gpu.py::test_split_mfma_is_fp32_accurate)"
+                       if _native.ganet().ganet_get_mfma_mode() == 1 else "v_mfma_f32_32x32x2_f32 (GANET_MFMA=f32)")},
     }
     if probe:
         # one launch of every rasterizer kernel processes all B frames of the rank's batch
@@ -410,6 +417,11 @@ def main():
         stage_of = {"preprocess": "preprocess", "tile_scan": "binning", "scatter": "binning", "tile_sort": "binning",
                     "render_fwd": "render_fwd", "render_bwd": "render_bwd", "preprocess_bwd": "preprocess_bwd"}
 
+        # the decoder GEMMs' matrix roof: exact fp32 on the bf16 pipe costs 6 bf16 MFMA flops per algorithmic flop
+        # (split mode, the default), so the algorithmic-flop peak is 2500 / 6 TFLOP/s; 157.3 with GANET_MFMA=f32
+        split = _native.ganet().ganet_get_mfma_mode() == 1
+        mfma_peak = MFMA_BF16_PEAK_TF / SPLIT_PRODUCTS if split else MFMA_F32_PEAK_TF
+
         def describe(name, ms, n, iters):
             """per-kernel-family record: time, and its algorithmic work priced against its roofline"""
             d = {"launches_per_iter": n / iters, "avg_us": 1e3 * ms / n, "us_per_iter": 1e3 * ms / iters}
@@ -417,7 +429,7 @@ def main():
                 # both roofs: the one that demands more time is the bound
                 tf = dflops[name] / (d["us_per_iter"] * 1e-6) / 1e12
                 gbs = dbytes[name] / (d["us_per_iter"] * 1e-6) / 1e9
-                mf, hf = tf / MFMA_F32_PEAK_TF, gbs / HBM_PEAK_GBS
+                mf, hf = tf / mfma_peak, gbs / HBM_PEAK_GBS
                 d.update({"bound": "mfma" if mf >= hf else "hbm", "flops_per_iter": dflops[name], "TFLOPs": tf,
                           "frac_of_mfma_peak": mf, "bytes_per_iter": dbytes[name], "GBps": gbs,
                           "frac_of_hbm_peak": hf, "frac_of_peak": max(mf, hf)})
@@ -450,7 +462,7 @@ def main():
                     traffic_note = ("HBM bytes of one 128->128 launch (M = 262,144) of this family: rocprofv3 --pmc "
                                     "FETCH_SIZE / WRITE_SIZE, separate passes, profiles/r01_pmc_decoder_traffic.txt; "
                                     "2*FETCH+WRITE (gfx950 wide-read correction); equals the algorithmic traffic")
-            mfma = {"bound": "mfma", "achieved": d["TFLOPs"], "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+            mfma = {"bound": "mfma", "achieved": d["TFLOPs"], "peak": mfma_peak, "unit": "TFLOP/s",
                     "frac": d["frac_of_mfma_peak"], "algorithmic_flops_per_iter": d["flops_per_iter"]}
             hbm = {"bound": "hbm", "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": d["frac_of_hbm_peak"], "algorithmic_bytes_per_iter": d["bytes_per_iter"]}
@@ -459,10 +471,13 @@ def main():
                     "avg_us": d["avg_us"], "launches_per_iter": d["launches_per_iter"], "us_per_iter": d["us_per_iter"],
                     "other_roof": second,
                     "note": "a tall-skinny fp32 GEMM family (activations 134 MB per operand, 8.6 GFLOP per 128x128 "
-                            "layer): its arithmetic intensity sits at the ridge of fp32-input MFMA (157.3 TFLOP/s "
-                            "dense, v_mfma_f32_32x32x2_f32, exact fp32) vs HBM (8 TB/s), so both roofs are priced and "
-                            "the one that demands more time is reported as the bound; the family's launches differ "
-                            "in shape, so flops, bytes and time are summed over one iteration"}
+                            "layer). Both roofs are priced and the one that demands more time is reported as the bound: "
+                            "HBM (8 TB/s, algorithmic bytes) and the matrix pipe — "
+                            + ("fp32 operands split exactly into three bf16 pieces, 6 v_mfma_f32_32x32x16_bf16 products "
+                               "per fp32 product accumulated in fp32: algorithmic-flop peak 2500 / 6 = 416.7 TFLOP/s"
+                               if split else "v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s dense")
+                            + "; the family's launches differ in shape, so flops, bytes and time are summed over one "
+                              "iteration"}
         else:
             st = stage_of.get(dom_family, dom_family)
             gbs = alg[st] / (d["us_per_iter"] * 1e-6) / 1e9

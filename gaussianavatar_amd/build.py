@@ -42,6 +42,8 @@ LIBS = {
         ("ganet_ssim.hip", []),
         ("ganet_mlp.hip", []),
         ("ganet_mlp_bwd.hip", []),
+        ("ganet_mlp_split.hip", []),
+        ("ganet_wgrad_split.hip", []),
         ("ganet_mlp_bwd_fused.hip", []),
         ("ganet_pack.hip", []),
         ("ganet_upsample.hip", []),

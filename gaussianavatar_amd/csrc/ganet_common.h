@@ -1,5 +1,7 @@
 // ganet_common.h — shared helpers of the ganet_* translation units (internal).
 #pragma once
+#include <cstdint>
+
 #include <hip/hip_runtime.h>
 
 namespace ganet {
@@ -16,4 +18,19 @@ struct ProfScope {
   int slot;
   hipStream_t stream;
 };
+
+// 0 = exact fp32-MFMA decoder kernels, 1 = split-bf16 kernels (ganet_split.h) wherever a shape has one.
+// Default 1; the environment variable GANET_MFMA=f32 or ganet_set_mfma_mode(0) selects the fp32 kernels.
+int mfma_mode();
+// ganet_mlp_split.hip / ganet_wgrad_split.hip: return -1 when the shape has no split kernel
+int mlp_fwd_split(int64_t M, int N, int K1, int K2, const float* x1, int64_t ld1, const float* x2, int64_t ld2,
+                  const float* in_scale, const float* in_shift, const float* W, const float* bias, float* z,
+                  int64_t ldz, float* col_part, const float* stat_shift, int reverse, hipStream_t stream);
+int mlp_bwd_split(int64_t M, int O, const float* g, int64_t ldg, const float* gz, int64_t ldgz,
+                  const float* gcoef, const float* W, int64_t ldw, float* out, int64_t ldo, bool accumulate,
+                  const float* src_z, int64_t ld_src, const float* src_scale, const float* src_shift,
+                  float* col_part, int reverse, hipStream_t stream);
+int wgrad_split(int64_t M, int N, int K, const float* g, int64_t ldg, const float* gz, int64_t ldgz,
+                const float* gcoef, const float* x, int64_t ldx, const float* in_scale, const float* in_shift,
+                float* partial, int blocks, int order, hipStream_t stream);
 }  // namespace ganet

@@ -638,6 +638,11 @@ int ganet_mlp_fwd(int64_t M, int32_t N, int32_t K1, int32_t K2, const float* x1,
     return 1;
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (mfma_mode() == 1) {
+    const int rc = mlp_fwd_split(M, N, K1, K2, x1, ld1, x2, ld2, in_scale, in_shift, W, bias, z, ldz, col_part,
+                                 stat_shift, row_order == 2 ? 1 : 0, stream);
+    if (rc >= 0) return rc;
+  }
   const int nt = (N + 31) / 32;
   const dim3 grid(FWD_BLOCKS), block(WG);
 #define LAUNCH(A, B, T)                                                                            \
@@ -719,6 +724,11 @@ int ganet_wgrad_act(int64_t M, int32_t N, int32_t K, const float* g, int64_t ldg
   const dim3 grid(nb), block(WG_W);
   const int nt = N > 32 ? 4 : 1, kt = K > 96 ? 4 : 3;
   const bool act = in_scale != nullptr, gpro = gz != nullptr;
+  int rc = -1;
+  if (mfma_mode() == 1)
+    rc = wgrad_split(M, N, K, g, ldg, gz, ldgz, gcoef, x, ldx, in_scale, in_shift, partial, nb, row_order, stream);
+  if (rc > 0) return rc;
+  if (rc < 0) {
 #define LAUNCH(T, KT_, A, G)                                                                       \
   do {                                                                                             \
     const size_t lds = 2 * ((size_t)(T) * 32 * (KT_) * 32 + (T) * 32) * sizeof(float);             \
@@ -747,7 +757,8 @@ int ganet_wgrad_act(int64_t M, int32_t N, int32_t K, const float* g, int64_t ldg
     return 4;
   }
 #undef LAUNCH
-  int rc = check_hip(hipGetLastError(), "wgrad_act_kernel");
+  rc = check_hip(hipGetLastError(), "wgrad_act_kernel");
+  }
   if (rc || !dW) return rc;           // dW NULL: partials only, ganet_wgrad_reduce_batch finishes
   const int total = N * K + N;
   {

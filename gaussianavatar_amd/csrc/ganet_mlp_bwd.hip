@@ -396,6 +396,11 @@ int ganet_mlp_bwd_data(int64_t M, int32_t O, const float* g, int64_t ldg, const 
     return 1;
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (mfma_mode() == 1) {
+    const int rc = mlp_bwd_split(M, O, g, ldg, gz, ldgz, gcoef, W, ldw, out, ldo, accumulate != 0, src_z, ld_src,
+                                 src_scale, src_shift, col_part, g_reverse_bwd, stream);
+    if (rc >= 0) return rc;
+  }
   const dim3 grid(BWD_BLOCKS), block(WG);
   const int nt = O > 96 ? 4 : 3;
 #define LAUNCH(T, AC, SG)                                                                          \
