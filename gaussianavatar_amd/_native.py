@@ -148,7 +148,8 @@ GANET_SYMBOLS = ["ganet_linear_wgrad_workspace", "ganet_linear_wgrad", "ganet_bn
                  "ganet_mlp_head_bwd_parts", "ganet_mlp_bwd_data", "ganet_mlp_head_bwd", "ganet_mlp_bwd_stats",
                  "ganet_mlp_bwd_fused_parts", "ganet_mlp_bwd_fused_workspace", "ganet_mlp_bwd_fused",
                  "ganet_decode_pack_fwd", "ganet_decode_pack_bwd", "ganet_mean_sq_fwd", "ganet_mean_sq_bwd", "ganet_weighted_sum_fwd", "ganet_weighted_sum_bwd", "ganet_upsample_cat_fwd", "ganet_upsample_cat_bwd", "ganet_profile_enable", "ganet_profile_count", "ganet_profile_read", "ganet_profile_kernel_name",
-                 "ganet_get_mfma_mode", "ganet_set_mfma_mode", "ganet_last_error", "ganet_abi_version"]
+                 "ganet_conv5_packed_bytes", "ganet_conv5_pack", "ganet_conv5_apply",
+                 "ganet_conv5_wgrad_workspace", "ganet_conv5_wgrad", "ganet_get_mfma_mode", "ganet_set_mfma_mode", "ganet_last_error", "ganet_abi_version"]
 
 
 class GanetWgradJob(ctypes.Structure):
@@ -234,6 +235,16 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_profile_read.argtypes = [P, P, c_int]
         lib.ganet_profile_kernel_name.restype = c_char_p
         lib.ganet_profile_kernel_name.argtypes = [c_int]
+        lib.ganet_conv5_packed_bytes.restype = c_size_t
+        lib.ganet_conv5_packed_bytes.argtypes = [c_int32]
+        lib.ganet_conv5_pack.restype = c_int
+        lib.ganet_conv5_pack.argtypes = [c_int32, P, P, P]
+        lib.ganet_conv5_apply.restype = c_int
+        lib.ganet_conv5_apply.argtypes = [c_int32, c_int32, c_int32, P, P, c_int32, c_int32, P, P]
+        lib.ganet_conv5_wgrad_workspace.restype = c_size_t
+        lib.ganet_conv5_wgrad_workspace.argtypes = [c_int32, c_int32, c_int32]
+        lib.ganet_conv5_wgrad.restype = c_int
+        lib.ganet_conv5_wgrad.argtypes = [c_int32, c_int32, c_int32, P, P, P, P, c_size_t, P]
         lib.ganet_get_mfma_mode.restype = c_int
         lib.ganet_set_mfma_mode.argtypes = [c_int]
         lib.ganet_set_mfma_mode.restype = None

@@ -47,6 +47,7 @@ LIBS = {
         ("ganet_mlp_bwd_fused.hip", []),
         ("ganet_pack.hip", []),
         ("ganet_upsample.hip", []),
+        ("ganet_conv.hip", []),
         ("ganet_optim.hip", []),
     ],
 }

@@ -316,6 +316,65 @@ def upsample_cat(pix, uv, rows, cols, ldx):
     return _UpsampleCatFn.apply(pix, uv, rows, cols, ldx)
 
 
+def geom_convs_supported(x, weights) -> bool:
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 64 and x.shape[3] % 64 == 0
+            and x.shape[0] * x.shape[2] * x.shape[3] < (1 << 24) and 0 < len(weights) <= 4
+            and all(tuple(w.shape) == (64, 64, 5, 5) and w.dtype == torch.float32 for w in weights))
+
+
+class _GeomConvFn(torch.autograd.Function):
+    """A chain of 5x5 / pad 2 / bias-free 64 -> 64 convolutions (GeomConvLayers) on the hand-written kernels of
+    csrc/ganet_conv.hip. Input: logical NCHW; the result is a logical-NCHW VIEW of a channels-last buffer — what
+    the up-sampling kernel reads — so no layout copy follows."""
+
+    @staticmethod
+    def forward(ctx, x, *weights):
+        lib = _native.ganet()
+        b, _, H, W = x.shape
+        n = len(weights)
+        st = _stream(x.device)
+        xh = x.permute(0, 2, 3, 1).contiguous()
+        ws = [w.contiguous() for w in weights]
+        packed = torch.empty(lib.ganet_conv5_packed_bytes(n), dtype=torch.uint8, device=x.device)
+        ptrs = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws])
+        _native.ganet_check(lib.ganet_conv5_pack(n, ptrs, _ptr(packed), st))
+        maps = [xh]
+        for i in range(n):
+            y = torch.empty_like(xh)
+            _native.ganet_check(lib.ganet_conv5_apply(b, H, W, _ptr(maps[-1]), _ptr(packed), i, 0, _ptr(y), st))
+            maps.append(y)
+        ctx.save_for_backward(packed, *maps[:-1])
+        ctx.dims = (b, H, W, n)
+        return maps[-1].permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _native.ganet()
+        packed, *maps = ctx.saved_tensors
+        b, H, W, n = ctx.dims
+        st = _stream(g.device)
+        gh = g.permute(0, 2, 3, 1).contiguous()
+        nbytes = lib.ganet_conv5_wgrad_workspace(b, H, W)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
+        dws = [None] * n
+        for i in reversed(range(n)):
+            if ctx.needs_input_grad[1 + i]:
+                dws[i] = torch.empty((64, 64, 5, 5), dtype=torch.float32, device=g.device)
+                _native.ganet_check(lib.ganet_conv5_wgrad(b, H, W, _ptr(maps[i]), _ptr(gh), _ptr(dws[i]), _ptr(ws),
+                                                          nbytes, st))
+            if i > 0 or ctx.needs_input_grad[0]:
+                gx = torch.empty_like(gh)
+                _native.ganet_check(lib.ganet_conv5_apply(b, H, W, _ptr(gh), _ptr(packed), i, 1, _ptr(gx), st))
+                gh = gx
+        dx = gh.permute(0, 3, 1, 2) if ctx.needs_input_grad[0] else None
+        return (dx,) + tuple(dws)
+
+
+def geom_convs(x, weights):
+    """conv5x5(... conv5x5(x, weights[0]) ..., weights[-1]) (padding 2, no bias) for x [b,64,H,W]."""
+    return _GeomConvFn.apply(x, *weights)
+
+
 class _DecodePackFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, res, s_logit, c_logit, valid_index, inv_index, res_scale, scale_mult):

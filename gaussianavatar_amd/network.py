@@ -45,6 +45,11 @@ class GeomConvLayers(nn.Module):
             setattr(self, f"conv{i}", nn.Conv2d(ci, co, kernel_size=5, stride=1, padding=2, bias=False))
 
     def forward(self, x):
+        weights = [getattr(self, f"conv{i}").weight for i in (1, 2, 3)]
+        if not self.use_relu and fused.geom_convs_supported(x, weights):
+            # hand-written channels-last kernels (csrc/ganet_conv.hip); the result is a logical-NCHW view of the
+            # channels-last map the up-sampling kernel reads
+            return fused.geom_convs(x, weights)
         for i in (1, 2, 3):
             x = getattr(self, f"conv{i}")(x)
             if self.use_relu and i < 3:

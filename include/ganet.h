@@ -230,6 +230,23 @@ int ganet_weighted_sum_fwd(int32_t n, const float* const* terms, const float* we
 int ganet_weighted_sum_bwd(int32_t n, const float* weights, const float* d_out, float* d_terms,
                            void* stream);
 
+/* ---- geometry-feature convolutions (ganet_conv.hip): 5x5, stride 1, zero padding 2, no bias, 64 -> 64 channels
+ * (/root/reference/model/modules.py:114-137, GeomConvLayers; replaces the three nn.Conv2d calls and their autograd
+ * backward). Maps are channels-last fp32 [b][H][W][64] (W a multiple of 64); weights are nn.Conv2d's
+ * [64][64][5][5]. ganet_conv5_pack splits the weights of up to GANET_CONV5_MAX convolutions into the bf16 planes
+ * both passes read (forward and transposed / tap-flipped for the input gradient; ganet_conv5_packed_bytes bytes);
+ * ganet_conv5_apply(..., conv, input_gradient, ...) is y = conv(x, w[conv]) or dL/dx = conv^T(dL/dy, w[conv]);
+ * ganet_conv5_wgrad writes dL/dw [64][64][5][5] (workspace: ganet_conv5_wgrad_workspace bytes). Arithmetic as the
+ * decoder GEMMs: exactly split fp32 operands on the bf16 matrix pipe, fp32 accumulation. */
+#define GANET_CONV5_MAX 4
+size_t ganet_conv5_packed_bytes(int32_t n_convs);
+int ganet_conv5_pack(int32_t n_convs, const float* const* w, void* packed, void* stream);
+int ganet_conv5_apply(int32_t b, int32_t H, int32_t W, const float* x, const void* packed, int32_t conv,
+                      int32_t input_gradient, float* y, void* stream);
+size_t ganet_conv5_wgrad_workspace(int32_t b, int32_t H, int32_t W);
+int ganet_conv5_wgrad(int32_t b, int32_t H, int32_t W, const float* x, const float* dy, float* dw, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
 /* ---- bilinear up-sampling at the separable UV texel grid + decoder-input assembly (ganet_upsample.hip)
  * x[(i,j), 0:C] = sum_{a,b<2} row_w[i,a] col_w[j,b] feat[row_idx[i,a], col_idx[j,b], :], followed by the two
  * uv columns and zeros up to ldx — F.grid_sample(bilinear, align_corners=False, zero padding) at the

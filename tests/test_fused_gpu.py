@@ -669,3 +669,88 @@ def test_batchnorm_statistics_survive_a_large_mean():
             assert float((mean.double() - z64.mean(0)).abs().max()) <= 1e-3
     assert errs["shifted"] <= 1e-3, errs
     assert errs["raw"] > 10 * errs["shifted"], errs            # the cancellation the shift removes
+
+
+def test_split_mfma_is_fp32_accurate():
+    """The decoder GEMMs feed the bf16 matrix pipe with an exact three-way split of their fp32 operands
+    (csrc/ganet_split.h: six bf16 products per fp32 product, fp32 accumulation). That is an fp32 GEMM, not a
+    bf16 one: against float64 its error must not exceed that of the v_mfma_f32_32x32x2_f32 kernels it replaces
+    (measured: equal or smaller, because an MFMA step adds 16 exact products before it rounds), while a plain
+    bf16 GEMM of the same operands is three orders of magnitude away."""
+    from gaussianavatar_amd import _native, fused
+    lib = _native.ganet()
+    dev = torch.device("cuda")
+    torch.manual_seed(5)
+    M = 262144
+    P, st = fused._ptr, fused._stream(dev)
+    z = torch.randn(M, 128, device=dev) * 1.5 + 0.3
+    sc, sh = torch.rand(128, device=dev) + 0.5, torch.randn(128, device=dev)
+    W = torch.randn(128, 128, device=dev) * 0.1
+    b = torch.randn(128, device=dev)
+    g, gz = torch.randn(M, 128, device=dev), torch.randn(M, 128, device=dev)
+    coef = torch.randn(3, 128, device=dev)
+    act64 = F.softplus(z.double() * sc.double() + sh.double())
+    dz64 = g.double() * coef[0].double() + gz.double() * coef[1].double() + coef[2].double()
+    part = torch.zeros(lib.ganet_mlp_stats_floats(128), device=dev)
+    bpart = torch.zeros(lib.ganet_mlp_bwd_data_parts() * 256, device=dev)
+    nb = lib.ganet_wgrad_act_workspace(M, 128, 128)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    dW, db = torch.empty(128, 128, device=dev), torch.empty(128, device=dev)
+    out = torch.empty(M, 128, device=dev)
+
+    def fwd():
+        return fused._mlp_fwd(lib, M, 128, None, z, sc, sh, W, b, part, dev)
+
+    def bwd():
+        _native.ganet_check(lib.ganet_mlp_bwd_data(M, 128, P(g), 128, P(gz), 128, P(coef), P(W), 128, P(out), 128, 0,
+                                                   P(z), 128, P(sc), P(sh), P(bpart), 0, st))
+        return out.clone()
+
+    def wgrad():
+        _native.ganet_check(lib.ganet_wgrad_act(M, 128, 128, P(g), 128, P(gz), 128, P(coef), P(z), 128, P(sc), P(sh),
+                                                P(dW), P(db), P(ws), nb, 0, st))
+        return dW.clone()
+
+    refs = {"fwd": act64 @ W.double().t() + b.double(),
+            "bwd": (dz64 @ W.double()) * torch.sigmoid(z.double() * sc.double() + sh.double()),
+            "wgrad": dz64.t() @ act64}
+    err = {}
+    try:
+        for mode in (0, 1):
+            lib.ganet_set_mfma_mode(mode)
+            for name, fn in (("fwd", fwd), ("bwd", bwd), ("wgrad", wgrad)):
+                err[name, mode] = float((fn().double() - refs[name]).abs().max() / refs[name].abs().max())
+    finally:
+        lib.ganet_set_mfma_mode(1)
+    bf16 = (act64.float().bfloat16() @ W.bfloat16().t()).double() + b.double()
+    err_bf16 = float((bf16 - refs["fwd"]).abs().max() / refs["fwd"].abs().max())
+    for name in ("fwd", "bwd", "wgrad"):
+        assert err[name, 1] <= 1.25 * err[name, 0] + 1e-7, (name, err)
+        assert err[name, 1] < 2e-6, (name, err)
+    assert err_bf16 > 100 * err["fwd", 1], (err_bf16, err)
+
+
+@pytest.mark.parametrize("b,H,W", [(1, 128, 128), (2, 64, 128), (1, 8, 64)])
+def test_geom_convs_match_torch_float64(b, H, W):
+    """csrc/ganet_conv.hip (forward, input gradient, weight gradient of the three 5x5 convolutions of
+    GeomConvLayers) against F.conv2d and its autograd in float64."""
+    from gaussianavatar_amd import fused
+    torch.manual_seed(H + W)
+    x = torch.randn(b, 64, H, W, device="cuda", requires_grad=True)
+    ws = [(torch.randn(64, 64, 5, 5, device="cuda") * 0.03).requires_grad_(True) for _ in range(3)]
+    assert fused.geom_convs_supported(x, ws)
+    y = fused.geom_convs(x, ws)
+    g = torch.randn(b, 64, H, W, device="cuda")
+    y.backward(g)
+    xr = x.detach().double().requires_grad_(True)
+    wr = [w.detach().double().requires_grad_(True) for w in ws]
+    yr = xr
+    for w in wr:
+        yr = F.conv2d(yr, w, padding=2)
+    yr.backward(g.double())
+    rel = lambda a, r: float((a.double() - r).abs().max() / r.abs().max())
+    assert tuple(y.shape) == (b, 64, H, W)
+    assert rel(y, yr) < 2e-6, rel(y, yr)
+    assert rel(x.grad, xr.grad) < 2e-6, rel(x.grad, xr.grad)
+    for w, r in zip(ws, wr):
+        assert rel(w.grad, r.grad) < 2e-6, rel(w.grad, r.grad)
