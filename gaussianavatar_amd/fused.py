@@ -482,6 +482,22 @@ _HEAD_RIDE = os.environ.get("GA_HEAD_RIDE", "0") == "1"
 _FUSED_BWD = os.environ.get("GA_FUSED_BWD", "0") == "1"
 
 
+# The weight-gradient launches of the decoder backward are off its dependency chain (nothing reads dW before the
+# batched reduction at the end): they are issued on a side stream (GA_WGRAD_STREAM=0: on the main one), ordered by
+# events behind the statistics they need, so that their heads (weight staging, launch latency) fill the tails of the
+# data-gradient kernels. LDS keeps the two kernel families from sharing a CU, so they do not slow each other's main
+# loops. Measured: +1.3 % iterations/s.
+_WGRAD_STREAM = os.environ.get("GA_WGRAD_STREAM", "1") != "0"
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
 class _RowSweep:
     """Alternates GANET_ROWS_UP / GANET_ROWS_DOWN between consecutive big launches of a pass (include/ganet.h:
     each kernel starts on the rows its predecessor touched last, which are still in the Infinity Cache).
@@ -634,6 +650,12 @@ class _DecoderFn(torch.autograd.Function):
         col_part = torch.empty(max(n_data, n_head) * 256, dtype=torch.float32, device=dev)
         f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
 
+        main_stream = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if _WGRAD_STREAM else None
+        wst = st if side is None else ctypes.c_void_p(side.cuda_stream)
+        if side is not None:
+            wg_ws.record_stream(side)
+
         def wgrad(g, gi, src, K=128):
             """dW [N,K], db [N]. g operand: raw tensor (gi None) or layer gi's (G, z, coef) triple;
             x operand: act(bn(zs[src])), or the padded decoder input when src is None."""
@@ -646,9 +668,15 @@ class _DecoderFn(torch.autograd.Function):
             dW, db = f32(N, K), f32(N)
             j = njobs[0]
             ws = wg_ws.data_ptr() + j * wg_bytes
+            if side is not None:
+                # everything this launch reads has been enqueued on the main stream by now
+                side.wait_stream(main_stream)
+                for t in (gt, gz, coef, x, sc, sh, dW, db):
+                    if t is not None:
+                        t.record_stream(side)
             _native.ganet_check(lib.ganet_wgrad_act(
                 M, N, K, _ptr(gt), gt.stride(0), _ptr(gz), 0 if gz is None else gz.stride(0), _ptr(coef),
-                _ptr(x), x.stride(0), _ptr(sc), _ptr(sh), None, None, ws, wg_bytes, sweep.next(), st))
+                _ptr(x), x.stride(0), _ptr(sc), _ptr(sh), None, None, ws, wg_bytes, sweep.next(), wst))
             jobs[j].workspace, jobs[j].M, jobs[j].N, jobs[j].K = ws, M, N, K
             jobs[j].dW, jobs[j].db, jobs[j].nblocks = dW.data_ptr(), db.data_ptr(), 0
             njobs[0] = j + 1
@@ -768,6 +796,8 @@ class _DecoderFn(torch.autograd.Function):
             if need_dx:
                 data_grad(0, conv_w[0], dx, True, None)
         if njobs[0]:
+            if side is not None:
+                main_stream.wait_stream(side)
             _native.ganet_check(lib.ganet_wgrad_reduce_batch(njobs[0], jobs, st))
         if heads:
             g_conv_w[4], g_conv_b[4] = torch.cat([dWx[:, :cin], dWy], 1).unsqueeze(-1), db5
