@@ -24,6 +24,9 @@ def _stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+_profiling = False        # per-kernel HIP events on: launches stay on ONE stream, so that a kernel's events time that kernel
+
+
 def profile_kernels() -> tuple:
     lib = _native.ganet()
     return tuple(lib.ganet_profile_kernel_name(i).decode() for i in range(lib.ganet_profile_count()))
@@ -40,6 +43,8 @@ def profile_enable(on=True) -> None:
     else:
         mask = sum(1 << names.index(k) for k in on)
     _native.ganet_check(_native.ganet().ganet_profile_enable(mask))
+    global _profiling
+    _profiling = bool(mask)
 
 
 def profile_read(reset: bool = True) -> dict:
@@ -651,7 +656,7 @@ class _DecoderFn(torch.autograd.Function):
         f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
 
         main_stream = torch.cuda.current_stream(dev)
-        side = _side_stream(dev) if _WGRAD_STREAM else None
+        side = _side_stream(dev) if (_WGRAD_STREAM and not _profiling) else None
         wst = st if side is None else ctypes.c_void_p(side.cuda_stream)
         if side is not None:
             wg_ws.record_stream(side)
