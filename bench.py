@@ -460,7 +460,7 @@ def main():
                 if t:
                     traffic = (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0
                     traffic_note = ("HBM bytes of one 128->128 launch (M = 262,144) of this family: rocprofv3 --pmc "
-                                    "FETCH_SIZE / WRITE_SIZE, separate passes, profiles/r01_pmc_decoder_traffic.txt; "
+                                    "FETCH_SIZE / WRITE_SIZE, separate passes of this command, profiles/r02_final_pmc_traffic.txt; "
                                     "2*FETCH+WRITE (gfx950 wide-read correction); equals the algorithmic traffic")
             mfma = {"bound": "mfma", "achieved": d["TFLOPs"], "peak": mfma_peak, "unit": "TFLOP/s",
                     "frac": d["frac_of_mfma_peak"], "algorithmic_flops_per_iter": d["flops_per_iter"]}
@@ -500,7 +500,7 @@ def main():
                 if t:
                     traffic = (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0
                     traffic_note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of this command, "
-                                    "profiles/r02_pmc_traffic.txt; 2*FETCH+WRITE (gfx950 wide-read correction)")
+                                    "profiles/r02_final_pmc_traffic.txt; 2*FETCH+WRITE (gfx950 wide-read correction)")
             out["roofline_raster_bwd"] = {
                 "kernel": "render_bwd", "bound": "hbm", "achieved": rb["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": rb["frac_of_peak"], "traffic": traffic, "traffic_note": traffic_note, "avg_us": rb["avg_us"],

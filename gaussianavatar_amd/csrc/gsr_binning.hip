@@ -135,12 +135,14 @@ scatter_kernel(int P, int gx, int64_t max_pairs, const int4* __restrict__ rect,
   agg_clear(s_agg);
   const int4 rc = i < P ? rect[i] : make_int4(0, 0, 0, 0);
   const uint64_t key = i < P ? (((uint64_t)__float_as_uint(depth[i]) << 32) | (uint32_t)i) : 0ull;
+  const bool big = rect_is_big(rc);                     // walked by the whole wave below (gsr_common.h)
   __syncthreads();
-  for (int cy = rc.y; cy < rc.w; ++cy)
-    for (int cx = rc.x; cx < rc.z; ++cx) {
-      const int slot = agg_claim(s_agg, cy * gx + cx);
-      if (slot >= 0) atomicAdd(&s_agg.cnt[slot], 1u);
-    }
+  if (!big)
+    for (int cy = rc.y; cy < rc.w; ++cy)
+      for (int cx = rc.x; cx < rc.z; ++cx) {
+        const int slot = agg_claim(s_agg, cy * gx + cx);
+        if (slot >= 0) atomicAdd(&s_agg.cnt[slot], 1u);
+      }
   __syncthreads();
   for (int sl = threadIdx.x; sl < GSR_AGG_SLOTS; sl += blockDim.x)
     if (s_agg.key[sl] >= 0) {
@@ -148,15 +150,22 @@ scatter_kernel(int P, int gx, int64_t max_pairs, const int4* __restrict__ rect,
       s_agg.cnt[sl] = 0u;
     }
   __syncthreads();
-  for (int cy = rc.y; cy < rc.w; ++cy)
-    for (int cx = rc.x; cx < rc.z; ++cx) {
-      const int tile = cy * gx + cx;
-      const int slot = agg_find(s_agg, tile);
-      // (a tile that found no room in the table — huge Gaussians — takes its slot directly)
-      const uint32_t pos = slot >= 0 ? s_agg.base[slot] + atomicAdd(&s_agg.cnt[slot], 1u)
-                                     : atomicAdd(&tile_cursor[tile], 1u);
-      if ((int64_t)pos < max_pairs) pair_key[pos] = key;
-    }
+  if (!big)
+    for (int cy = rc.y; cy < rc.w; ++cy)
+      for (int cx = rc.x; cx < rc.z; ++cx) {
+        const int tile = cy * gx + cx;
+        const int slot = agg_find(s_agg, tile);
+        // (a tile that found no room in the table takes its slot directly)
+        const uint32_t pos = slot >= 0 ? s_agg.base[slot] + atomicAdd(&s_agg.cnt[slot], 1u)
+                                       : atomicAdd(&tile_cursor[tile], 1u);
+        if ((int64_t)pos < max_pairs) pair_key[pos] = key;
+      }
+  for_big_rects(rc, gx,
+                [&](int src) { return ((uint64_t)__shfl((uint32_t)(key >> 32), src) << 32) | __shfl((uint32_t)key, src); },
+                [&](int tile, uint64_t k) {
+                  const uint32_t pos = atomicAdd(&tile_cursor[tile], 1u);
+                  if ((int64_t)pos < max_pairs) pair_key[pos] = k;
+                });
 }
 
 // ------------------------------------------------------------------ K4

@@ -164,6 +164,30 @@ __device__ __forceinline__ int agg_find(const TileAgg& t, int tile) {
   return -1;
 }
 
+// A Gaussian whose tile rectangle holds more than GSR_BIG_RECT tiles (a handful per frame at most, but thousands of
+// tiles each: a stage-2 scene had a few that covered the screen) is not walked by its own lane through the LDS table
+// — it would fill the table and turn every later claim of the workgroup into a full probe sequence (measured: 3.6 ms
+// instead of 50 us for K3) — but by its whole wave, one tile per lane and step, with direct global atomics.
+#define GSR_BIG_RECT 64
+__device__ __forceinline__ bool rect_is_big(const int4& rc) {
+  return (rc.z - rc.x) * (rc.w - rc.y) > GSR_BIG_RECT;
+}
+// calls f(tile, payload) for every tile of every big rectangle held by a lane of this wave (all lanes must call);
+// payload = bcast(src lane), evaluated by ALL lanes before the tiles are dealt out (wave shuffles belong there)
+template <typename G, typename F>
+__device__ __forceinline__ void for_big_rects(const int4& rc, int gx, G bcast, F f) {
+  uint64_t pending = __ballot(rect_is_big(rc));
+  const int lane = threadIdx.x & 63;
+  while (pending) {
+    const int src = __ffsll((unsigned long long)pending) - 1;
+    pending &= pending - 1;
+    const int x0 = __shfl(rc.x, src), y0 = __shfl(rc.y, src), x1 = __shfl(rc.z, src), y1 = __shfl(rc.w, src);
+    const int w = x1 - x0, n = w * (y1 - y0);
+    const auto payload = bcast(src);
+    for (int t = lane; t < n; t += 64) f((y0 + t / w) * gx + x0 + t % w, payload);
+  }
+}
+
 int compute_layout(int P, int W, int H, int64_t max_pairs, GsrLayout* out);
 Workspace resolve(void* base, const GsrLayout& L);
 void set_error(const char* fmt, ...);

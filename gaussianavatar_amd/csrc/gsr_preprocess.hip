@@ -184,13 +184,15 @@ preprocess_kernel(int P, int W, int H, int gx, int gy, float tanfovx, float tanf
   // per-tile histogram of pairs (consumed by K2/K3): counted in the workgroup's LDS table first
   // (gsr_common.h: TileAgg), then one global atomic per (workgroup, tile)
   __syncthreads();
-  for (int cy = rc.y; cy < rc.w; ++cy)
-    for (int cx = rc.x; cx < rc.z; ++cx) {
-      const int tile = cy * gx + cx;
-      const int slot = agg_claim(s_agg, tile);
-      if (slot >= 0) atomicAdd(&s_agg.cnt[slot], 1u);
-      else atomicAdd(&ws.tile_count[tile], 1u);          // table full (huge Gaussians): direct
-    }
+  if (!rect_is_big(rc))
+    for (int cy = rc.y; cy < rc.w; ++cy)
+      for (int cx = rc.x; cx < rc.z; ++cx) {
+        const int tile = cy * gx + cx;
+        const int slot = agg_claim(s_agg, tile);
+        if (slot >= 0) atomicAdd(&s_agg.cnt[slot], 1u);
+        else atomicAdd(&ws.tile_count[tile], 1u);        // table full along the probe sequence: direct
+      }
+  for_big_rects(rc, gx, [](int) { return 0; }, [&](int tile, int) { atomicAdd(&ws.tile_count[tile], 1u); });
   __syncthreads();
   for (int sl = threadIdx.x; sl < GSR_AGG_SLOTS; sl += blockDim.x)
     if (s_agg.key[sl] >= 0) atomicAdd(&ws.tile_count[s_agg.key[sl]], s_agg.cnt[sl]);

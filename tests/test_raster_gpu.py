@@ -102,6 +102,16 @@ def test_large_gaussians_cover_all_tiles(raster_oracle):
     assert_forward_parity(raster_oracle, sc)
 
 
+def test_a_few_screen_filling_gaussians_among_many_small_ones(raster_oracle):
+    """Rectangles above GSR_BIG_RECT tiles are binned by their whole wave with direct atomics, the rest through the
+    workgroup's LDS table — both in the same workgroups here; the per-tile lists must come out identical."""
+    sc = random_scene(30000, 512, 512, seed=21, kind="avatar", scale_med=0.004)
+    sc["scales"][::3000] = 0.8          # ten Gaussians that cover the whole image (1024 tiles each)
+    sc["scales"][1500::3000] = 0.05     # and ten of ~100 tiles
+    ref, got = assert_forward_parity(raster_oracle, sc)
+    assert got["status"][0] > 10 * 1024
+
+
 def test_overflow_is_flagged_and_recovered(raster_oracle):
     import torch
     from gaussianavatar_amd import rasterizer as R
