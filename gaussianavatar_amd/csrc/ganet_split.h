@@ -6,7 +6,8 @@
 //
 //     a = a1 + a2 + a3,   a1 = trunc_bf16(a),  a2 = trunc_bf16(a - a1),  a3 = a - a1 - a2
 //
-// (8 + 8 + 8 significand bits: the subtractions are exact and a3 needs no rounding), and accumulate in fp32
+// (8 + 8 + 8 significand bits: the subtractions are exact and a3 needs no rounding — for normal fp32 values; of a
+// subnormal only its upper 7 mantissa bits survive, an error below 2^-132), and accumulate in fp32
 // the six products whose weight is above 2^-24 of |a b|:
 //
 //     a b ~= a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1)        dropped: a2 b3 + a3 b2 + a3 b3 <= 2^-23 |a b|
