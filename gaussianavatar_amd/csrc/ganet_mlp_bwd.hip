@@ -375,7 +375,7 @@ bwd_stats_kernel(int nparts, int64_t M, const float* __restrict__ col_part,
 
 using namespace ganet;
 
-int g_reverse_bwd = 0;      // EXPERIMENT
+int g_reverse_bwd = 0;      // row sweep of the data-gradient kernels (dev switch, ganet_dev_set_reverse_bwd): 0 = first row up
 extern "C" void ganet_dev_set_reverse_bwd(int r) { g_reverse_bwd = r; }
 
 extern "C" {

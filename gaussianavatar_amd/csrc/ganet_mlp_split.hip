@@ -9,9 +9,10 @@
 // k of its row per k-step of 16 (two 16-byte loads), applies the prologue in fp32, splits the 8 values into three
 // bf16x8 fragments (44 VALU instructions) and issues 6 MFMAs per 32-column tile against the weight's three bf16
 // planes, resident in LDS for the whole kernel (split once per workgroup while staging). A 128 x 128 layer needs
-// 8 x 4 x 6 = 192 MFMAs of 32 cycles per slab (6.1 k cycles) where the fp32 form needs 256 of 64 (16.4 k), and
-// the VALU work of a wave (prologue + split, ~100 instructions per k-step) fits in the issue slots the other
-// wave's MFMAs leave free, so these kernels are bound by their HBM streams.
+// 8 x 4 x 6 = 192 MFMAs per slab where the fp32 form needs 256 of twice the issue time; measured:
+// the bf16 MFMA sustains ~44 cycles per instruction chip-wide, the VALU work (prologue + split, ~100 instructions
+// per k-step) hides under it, a slab costs ~9 k cycles of k-loop + 2.5 k of epilogue, and the kernels run at
+// 4.2-4.9 TB/s of algorithmic HBM traffic (forward 61 us, data gradient 103 us; fp32 form: 99 / 150 us).
 #include <cstdint>
 
 #include "ganet.h"
