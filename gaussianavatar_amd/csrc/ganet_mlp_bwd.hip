@@ -19,6 +19,8 @@
 // This replaces, per layer, a vendor GEMM + two BatchNorm-backward passes + the softplus backward
 // of /root/reference/model/modules.py:554-582's autograd graph.
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 
 #include "ganet.h"
 #include "ganet_common.h"
@@ -375,8 +377,17 @@ bwd_stats_kernel(int nparts, int64_t M, const float* __restrict__ col_part,
 
 using namespace ganet;
 
-int g_reverse_bwd = 0;      // row sweep of the data-gradient kernels (dev switch, ganet_dev_set_reverse_bwd): 0 = first row up
+// Row sweep of the data-gradient kernels: -1 (default) = follow the call's row_order (GANET_ROWS_DOWN -> last row
+// first), 0 / 1 = force up / down (dev switch: ganet_dev_set_reverse_bwd, or GANET_BWD_SWEEP=up|down in the environment)
+int g_reverse_bwd = -2;
 extern "C" void ganet_dev_set_reverse_bwd(int r) { g_reverse_bwd = r; }
+static int bwd_reverse(int row_order) {
+  if (g_reverse_bwd == -2) {
+    const char* e = getenv("GANET_BWD_SWEEP");
+    g_reverse_bwd = !e ? -1 : (!strcmp(e, "up") ? 0 : (!strcmp(e, "down") ? 1 : -1));
+  }
+  return g_reverse_bwd >= 0 ? g_reverse_bwd : (row_order == 2 ? 1 : 0);
+}
 
 extern "C" {
 
@@ -398,7 +409,7 @@ int ganet_mlp_bwd_data(int64_t M, int32_t O, const float* g, int64_t ldg, const 
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (mfma_mode() == 1) {
     const int rc = mlp_bwd_split(M, O, g, ldg, gz, ldgz, gcoef, W, ldw, out, ldo, accumulate != 0, src_z, ld_src,
-                                 src_scale, src_shift, col_part, g_reverse_bwd, stream);
+                                 src_scale, src_shift, col_part, bwd_reverse(row_order), stream);
     if (rc >= 0) return rc;
   }
   const dim3 grid(BWD_BLOCKS), block(WG);
@@ -416,7 +427,7 @@ int ganet_mlp_bwd_data(int64_t M, int32_t O, const float* g, int64_t ldg, const 
     ProfScope prof_(K_BWD_DATA, stream);                                                           \
     hipLaunchKernelGGL((mlp_bwd_kernel<T, AC, SG>), grid, block, lds, stream, M, O, g, ldg, gz, ldgz, \
                        gcoef, W, ldw, out, ldo, src_z, ld_src, src_scale, src_shift, col_part,     \
-                       g_reverse_bwd);                                                             \
+                       bwd_reverse(row_order));                                                    \
   } while (0)
   const bool acc = accumulate != 0;
   if (nt == 4 && !acc && sig) LAUNCH(4, false, true);
