@@ -81,3 +81,30 @@ def test_ops_fail_loudly_without_a_device():
         GaussianRasterizer(rs)(means3D=torch.zeros(4, 3), means2D=None, opacities=torch.ones(4, 1),
                                colors_precomp=torch.zeros(4, 3), scales=torch.ones(4, 3),
                                rotations=torch.zeros(4, 4))
+
+
+def test_net_kernels_reject_bad_arguments_before_touching_the_device():
+    """The decoder / convolution entry points validate their arguments on the host first: error code + text,
+    nothing launched (works without a GPU)."""
+    from gaussianavatar_amd import _native
+    lib = _native.ganet()
+    # convolutions: workspace / packed-weight queries and argument checks
+    assert lib.ganet_conv5_packed_bytes(3) == 3 * 2 * 25 * (3 * 4 * 2 * 64) * 16
+    assert lib.ganet_conv5_packed_bytes(0) == 0
+    assert lib.ganet_conv5_wgrad_workspace(1, 128, 128) > 0
+    assert lib.ganet_conv5_wgrad_workspace(1, 128, 100) == 0              # W must be a multiple of 64
+    assert lib.ganet_conv5_pack(0, None, None, None) == 1 and b"ganet_conv5_pack" in lib.ganet_last_error()
+    assert lib.ganet_conv5_apply(1, 128, 100, None, None, 0, 0, None, None) == 1
+    assert b"W % 64" in lib.ganet_last_error()
+    assert lib.ganet_conv5_wgrad(1, 128, 128, None, None, None, None, 0, None) == 1
+    # decoder layers: shape checks
+    assert lib.ganet_mlp_fwd(0, 128, 0, 128, None, 0, None, 0, None, None, None, None, None, 0, None, None, 0, None) == 1
+    assert b"ganet_mlp_fwd" in lib.ganet_last_error()
+    assert lib.ganet_wgrad_act_workspace(262144, 128, 128) == 256 * (128 * 128 + 128) * 4
+    # the arithmetic switch (no device needed): default = split operands on the bf16 pipe
+    mode = lib.ganet_get_mfma_mode()
+    assert mode in (0, 1)
+    lib.ganet_set_mfma_mode(0)
+    assert lib.ganet_get_mfma_mode() == 0
+    lib.ganet_set_mfma_mode(mode)
+    assert lib.ganet_get_mfma_mode() == mode
