@@ -14,10 +14,11 @@
 //     [plane][mg][column]: every element of the step is loaded, activated and split exactly ONCE per CU;
 //   * consume: wave w accumulates the 64 x 64 quadrant (w >> 1, w & 1) of the dW tile: 12 conflict-free
 //     ds_read_b128 and 24 MFMAs per step, 64 accumulator registers.
-// The two groups of a workgroup reduce different row blocks and run in opposite phases (one produces — VALU —
-// while the other consumes — matrix pipe — with a workgroup barrier between the phases), so each SIMD always has
-// one wave of either kind; loads are issued two steps ahead. The groups' tiles are added through LDS at the end:
-// 256 partial tiles per launch, summed by the deterministic reduction kernel of ganet_mlp.hip.
+// The two groups of four waves of a workgroup reduce different row blocks (two waves per SIMD). K = 128: while a
+// group multiplies step t out of one LDS buffer it converts step t + 1 into the other, one workgroup barrier per
+// step; K = 72: the groups alternate produce-only and consume-only phases in opposition (see the main loop). Loads
+// are issued two steps ahead. The groups' tiles are added through LDS at the end: 256 partial tiles per launch,
+// summed by the deterministic reduction kernel of ganet_mlp.hip.
 #include <cstdint>
 
 #include "ganet.h"
@@ -47,13 +48,15 @@ wgrad_split_kernel(int64_t M, int K, const float* __restrict__ g, const float* _
   constexpr int KP = 32 * KT;
   constexpr int A_UNITS = 3 * 2 * N, B_UNITS = 3 * 2 * KP;      // per group: [plane][mg][column]
   constexpr int KTW = (KT + 1) / 2;                              // k-tiles of a consumer wave
-  extern __shared__ u32x4 s_mem[];   // 2 x (A_UNITS + B_UNITS) step buffers; reused for the final [N][KP] tile + bias
+  extern __shared__ u32x4 s_mem[];   // 2 groups x 2 step buffers (A_UNITS + B_UNITS); reused for the final tile + bias
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int grp = wave >> 2, w = wave & 3;
   const int lane = threadIdx.x & 63;
   const int mg = lane >> 5, c = lane & 31;
-  u32x4* s_a = s_mem + grp * (A_UNITS + B_UNITS);
-  u32x4* s_b = s_a + A_UNITS;
+  // two step buffers per group: [grp][buf] (A_UNITS + B_UNITS); produce writes (pa, pb), consume reads (ca, cb)
+  u32x4* const s_grp = s_mem + grp * 2 * (A_UNITS + B_UNITS);
+  u32x4 *pa = s_grp, *pb = s_grp + A_UNITS;
+  const u32x4 *ca = s_grp, *cb = s_grp + A_UNITS;
 
   // producer columns and their prologue coefficients
   const int ncol = 32 * w + c;
@@ -97,20 +100,20 @@ wgrad_split_kernel(int64_t M, int K, const float* __restrict__ g, const float* _
   };
 
   float bias = 0.f;
-  auto produce = [&](const Raw& r, int64_t m0) {
+  auto produce = [&](const Raw& r, int64_t m0, bool live) {      // live = false: a step nobody consumes (no bias)
     float v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       float d = GPRO ? fmaf(cA, r.g[i], fmaf(cq, r.z[i], cp)) : r.g[i];
       if (!EXACT) d = (m0 + 8 * mg + i < M) ? d : 0.f;           // rows beyond M contribute nothing
       v[i] = d;
-      bias += d;
+      bias += live ? d : 0.f;
     }
     u32x4 p1, p2, p3;
     split8(v, p1, p2, p3);
-    s_a[(0 * 2 + mg) * N + ncol] = p1;
-    s_a[(1 * 2 + mg) * N + ncol] = p2;
-    s_a[(2 * 2 + mg) * N + ncol] = p3;
+    pa[(0 * 2 + mg) * N + ncol] = p1;
+    pa[(1 * 2 + mg) * N + ncol] = p2;
+    pa[(2 * 2 + mg) * N + ncol] = p3;
     if (bprod) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -118,9 +121,9 @@ wgrad_split_kernel(int64_t M, int K, const float* __restrict__ g, const float* _
         v[i] = kok ? a : 0.f;
       }
       split8(v, p1, p2, p3);
-      s_b[(0 * 2 + mg) * KP + 32 * w + c] = p1;
-      s_b[(1 * 2 + mg) * KP + 32 * w + c] = p2;
-      s_b[(2 * 2 + mg) * KP + 32 * w + c] = p3;
+      pb[(0 * 2 + mg) * KP + 32 * w + c] = p1;
+      pb[(1 * 2 + mg) * KP + 32 * w + c] = p2;
+      pb[(2 * 2 + mg) * KP + 32 * w + c] = p3;
     }
   };
 
@@ -138,11 +141,11 @@ wgrad_split_kernel(int64_t M, int K, const float* __restrict__ g, const float* _
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) fa[a][p] = s_a[(p * 2 + mg) * N + (2 * jn + a) * 32 + c];
+      for (int p = 0; p < 3; ++p) fa[a][p] = ca[(p * 2 + mg) * N + (2 * jn + a) * 32 + c];
 #pragma unroll
     for (int b = 0; b < KTW; ++b)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) fb[b][p] = s_b[(p * 2 + mg) * KP + min(KTW * ik + b, KT - 1) * 32 + c];
+      for (int p = 0; p < 3; ++p) fb[b][p] = cb[(p * 2 + mg) * KP + min(KTW * ik + b, KT - 1) * 32 + c];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -150,26 +153,59 @@ wgrad_split_kernel(int64_t M, int K, const float* __restrict__ g, const float* _
         if (KTW * ik + b < KT) GANET_SPLIT_PRODUCTS(acc[a][b], fa[a][0], fa[a][1], fa[a][2], fb[b][0], fb[b][1], fb[b][2]);
   };
 
-  // group 0: produce | consume | produce | ...      group 1: (wait) | produce | consume | ...
   Raw ring[PF];
 #pragma unroll
   for (int u = 0; u < PF; ++u) load(ring[u], row_of(u));
-  if (grp == 1) __syncthreads();
-  for (int64_t t = 0; t < steps; t += PF) {
+  static_assert(PF == 2, "the ring indexing below is written for two register sets");
+  if constexpr (KT == 4) {
+    // One barrier per step: while the workgroup multiplies step t out of one buffer (consume: LDS reads + MFMAs) it
+    // converts step t + 1 into the other (produce: VALU + LDS writes) — the two halves of a wave's instruction
+    // stream are independent, so the compiler and the SIMD's two waves interleave them (128 x 128: 95 -> 90 us
+    // against the two-phase schedule below).
+    auto point = [&](int buf, bool producer) {
+      u32x4* base = s_grp + buf * (A_UNITS + B_UNITS);
+      if (producer) { pa = base; pb = base + A_UNITS; } else { ca = base; cb = base + A_UNITS; }
+    };
+    point(0, true);
+    produce(ring[0], row_of(0), true);
+    __builtin_amdgcn_sched_barrier(0);
+    load(ring[0], row_of(PF));
+    __syncthreads();
+    for (int64_t t = 0; t < steps; t += PF) {
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      // (no control flow in here — `steps` is a multiple of PF: with branches around the loads the compiler's
-      // s_waitcnt bookkeeping falls back to vmcnt(0) and the prefetch is lost)
-      produce(ring[u], row_of(t + u));
-      __builtin_amdgcn_sched_barrier(0);
-      load(ring[u], row_of(t + u + PF));
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();
-      consume();
-      __syncthreads();
+      for (int u = 0; u < PF; ++u) {
+        // (no control flow around the loads — `steps` is a multiple of PF: with branches the compiler's s_waitcnt
+        // bookkeeping falls back to vmcnt(0) and the prefetch is lost; the step after the last one is produced
+        // from re-read rows and never consumed)
+        point((u + 1) & 1, true);
+        produce(ring[(u + 1) % PF], row_of(t + u + 1), t + u + 1 < steps);
+        __builtin_amdgcn_sched_barrier(0);
+        load(ring[(u + 1) % PF], row_of(t + u + 1 + PF));
+        __builtin_amdgcn_sched_barrier(0);
+        point(u & 1, false);
+        consume();
+        __syncthreads();
+      }
     }
+  } else {
+    // K = 72 (three k-tiles: uneven producer / consumer work) is faster on the two-phase schedule (78 vs 94 us):
+    // group 0: produce | consume | produce | ...      group 1: (wait) | produce | consume | ...   one buffer per
+    // group, a barrier after every phase, so that each SIMD always holds one producing and one consuming wave
+    if (grp == 1) __syncthreads();
+    for (int64_t t = 0; t < steps; t += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        produce(ring[u], row_of(t + u), true);
+        __builtin_amdgcn_sched_barrier(0);
+        load(ring[u], row_of(t + u + PF));
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        consume();
+        __syncthreads();
+      }
+    }
+    if (grp == 0) __syncthreads();
   }
-  if (grp == 0) __syncthreads();
 
   // combine the two groups' tiles through LDS (all step buffers are dead), write the partial tile
   float* tile = reinterpret_cast<float*>(s_mem);             // [N][KP] + [N] bias
@@ -229,7 +265,7 @@ int wgrad_split(int64_t M, int N, int K, const float* g, int64_t ldg, const floa
   const bool exact = (M % STEP) == 0 && steps * 2 * blocks == nsteps;
 #define LAUNCH(KT_, LDX_, A, G, E)                                                                             \
   do {                                                                                                         \
-    constexpr size_t step_bytes = (size_t)2 * (3 * 2 * 128 + 3 * 2 * 32 * (KT_)) * 16;                         \
+    constexpr size_t step_bytes = (size_t)4 * (3 * 2 * 128 + 3 * 2 * 32 * (KT_)) * 16;                         \
     constexpr size_t tile_bytes = ((size_t)128 * 32 * (KT_) + 128) * 4;                                        \
     const size_t lds = step_bytes > tile_bytes ? step_bytes : tile_bytes;                                      \
     static bool attr_set = false;                                                                              \
