@@ -31,6 +31,11 @@ constexpr int BLOCKS = 256;
 #ifndef GANET_SPLIT_RING
 #define GANET_SPLIT_RING 4
 #endif
+// scheduling barriers that pin the ring refills: classes that may cross (ganet_mlp_common.h: kSchedMask = VALU, SALU,
+// LDS, transcendental; | 0x8 lets MFMAs cross as well)
+#ifndef GANET_SPLIT_MASK
+#define GANET_SPLIT_MASK kSchedMask
+#endif
 #ifndef GANET_SPLIT_RING_BWD
 #define GANET_SPLIT_RING_BWD 2
 #endif
@@ -176,9 +181,9 @@ mlp_fwd_split_kernel(int64_t M, int N, const float* __restrict__ x1, int64_t ld1
     for (int s = 0; s < KS; ++s) {
       // the slot of step s is free (its fragments are `cur`): refill it first, so that the load has D2 - 1
       // steps to land
-      __builtin_amdgcn_sched_barrier(kSchedMask);
+      __builtin_amdgcn_sched_barrier(GANET_SPLIT_MASK);
       refill(s);
-      __builtin_amdgcn_sched_barrier(kSchedMask);
+      __builtin_amdgcn_sched_barrier(GANET_SPLIT_MASK);
       const Pieces nxt = make_pieces((s + 1) % KS, soff);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -333,9 +338,9 @@ mlp_bwd_split_kernel(int64_t M, int O, const float* __restrict__ g, int64_t ldg,
       v[6] = fmaf(a1c.z, q.ghi.z, fmaf(q1.z, q.zhi.z, c1.z)); v[7] = fmaf(a1c.w, q.ghi.w, fmaf(q1.w, q.zhi.w, c1.w));
       u32x4 a1, a2, a3;
       split8(v, a1, a2, a3);
-      __builtin_amdgcn_sched_barrier(kSchedMask);
+      __builtin_amdgcn_sched_barrier(GANET_SPLIT_MASK);
       ring[s % D] = (s + D < KS) ? load(pgc, pzc, s + D) : load(pgn, pzn, s + D - KS);
-      __builtin_amdgcn_sched_barrier(kSchedMask);
+      __builtin_amdgcn_sched_barrier(GANET_SPLIT_MASK);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int at = split_unit<RU>(wrow + t * 32, 2 * s + ukg);
