@@ -1,4 +1,6 @@
-"""Feature networks of the hot path on PyTorch-ROCm (rocBLAS/MIOpen do the GEMMs/convs).
+"""Feature networks of the hot path: state-dict compatible torch modules whose HIP-device forward/backward run on
+the hand-written kernels of csrc/ganet_*.hip (decoder MLP, 5x5 convolutions, up-sampling; gaussianavatar_amd/fused.py);
+on the CPU — and for shapes the kernels do not cover, e.g. the stage-2 UNet — the plain torch formulation runs.
 
 State-dict compatible re-implementation of the modules the reference instantiates for its
 default flags (`geom_layer_type='conv'`, /root/reference/arguments/__init__.py:111):
