@@ -39,6 +39,13 @@ MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak (same guide; v_mfma_f32_32x32
 SPLIT_PRODUCTS = 6        # bf16 MFMAs per fp32 product in the split-operand decoder kernels (csrc/ganet_split.h)
 
 
+def _one_pass_backward(model, frames: int) -> bool:
+    """Do the hidden 128 -> 128 layers take the one-pass backward (ganet_mlp_bwd_fused)? Mirrors fused.py."""
+    from gaussianavatar_amd import fused
+    M = int(model.uv_coord_map.shape[0]) * frames
+    return bool(fused._FUSED_BWD) and M % 32 == 0
+
+
 def decoder_flops(model, frames: int = 1) -> dict:
     """Algorithmic flops (2 M N K per GEMM) of one iteration's decoder launches, by kernel family.
     Stage 1 evaluates the batch-invariant decoder once (frames=1): M = UV texels (S^2); stage 2
@@ -48,6 +55,18 @@ def decoder_flops(model, frames: int = 1) -> dict:
     h, cin = dec.hsize, dec.in_size
     hidden = cin * h + 3 * h * h + (h + cin) * h + 6 * h * h      # conv1, conv2-4, conv5, conv6/7 x 3 heads
     outs = h * (3 + 1 + 3)                                        # conv8 x 3 heads
+    if _one_pass_backward(model, frames):
+        # ten hidden layers with a 128-column activated input (conv2-4, conv5's activated half, conv6/7 x 3): data
+        # gradient + weight gradient in one launch; the separate families keep conv1 / conv5's 66-column input operand
+        # (weight gradient, input gradient) and the heads' weight gradient
+        fused_layers = 10 * h * h
+        return {
+            "mlp_fwd": 2.0 * M * (hidden + outs),
+            "layer_bwd": 4.0 * M * fused_layers,
+            "wgrad_act": 2.0 * M * (2 * cin * h + outs),
+            "mlp_bwd_data": 2.0 * M * (2 * cin * h),
+            "head_bwd": 2.0 * M * outs,
+        }
     return {
         "mlp_fwd": 2.0 * M * (hidden + outs),
         "wgrad_act": 2.0 * M * (hidden + outs),
@@ -60,12 +79,28 @@ def decoder_flops(model, frames: int = 1) -> dict:
 def decoder_bytes(model, frames: int = 1) -> dict:
     """Algorithmic HBM bytes (fp32, every operand of every launch moved once: activations are 134 MB at
     M = 262,144 and do not survive between launches) of one iteration's decoder launches, by kernel
-    family — the operand lists of gaussianavatar_amd/fused.py::_DecoderFn. Columns per row of M:"""
+    family — the operand lists of gaussianavatar_amd/fused.py::_DecoderFn. Columns per row of M.
+    "backward_minimum": the bytes the backward pass would move if every layer touched each of its tensors once
+    (G, z, z_src in, G_src out per hidden layer; the three conv6 branches adding into conv5's gradient without
+    re-reading it) — the figure the per-launch sums of the backward families are to be compared with."""
     dec = model.net.decoder
     M = float(model.uv_coord_map.shape[0]) * frames
     h, cin, xp = dec.hsize, dec.in_size, 72          # xp: decoder input padded to 8-float blocks
     outs = (3, 1, 3)
     fwd = (xp + h) + 3 * (2 * h) + (xp + 2 * h) + 6 * (2 * h) + sum(h + o for o in outs)
+    head = sum(o + 2 * h for o in outs)
+    # minimum: conv8 wgrad rides on head_bwd's operands (g, z7: counted in `head`); per head conv7 (G7, z7, z6 -> G6)
+    # and conv6 (G6, z6 [z5 shared] ...); conv5 (G5, z5, z4, x -> G4, dx); conv4..2; conv1 (G1, z1, x -> dx)
+    minimum = (head + 3 * 4 * h + (3 * 2 * h + 2 * h) + (3 * h + xp + h + cin) + 3 * 4 * h + (2 * h + xp + cin))
+    if _one_pass_backward(model, frames):
+        layer = (3 * 4 * h                       # conv7 -> G6: G, z, src z in, out
+                 + (4 * h) + (5 * h) + (5 * h)   # conv6 -> G5: first writes, then accumulates (out read + written)
+                 + 4 * h                         # conv5's activated half -> G4
+                 + 3 * 4 * h)                    # conv4..2
+        wgrad = sum(o + h for o in outs) + 2 * (2 * h + xp)       # conv8 x 3; conv5 / conv1 input operand
+        bwd = (2 * h + cin) + (2 * h + 2 * cin)                   # conv5 -> d(input); conv1 -> d(input), accumulated
+        return {"mlp_fwd": 4.0 * M * fwd, "layer_bwd": 4.0 * M * layer, "wgrad_act": 4.0 * M * wgrad,
+                "mlp_bwd_data": 4.0 * M * bwd, "head_bwd": 4.0 * M * head, "backward_minimum": 4.0 * M * minimum}
     wgrad = (sum(o + h for o in outs)            # conv8: raw g + x
              + 6 * 3 * h                         # conv7, conv6 per head: G, z, x
              + 3 * h + (2 * h + xp)              # conv5: activated operand / input operand
@@ -75,9 +110,8 @@ def decoder_bytes(model, frames: int = 1) -> dict:
            + (2 * h + cin) + 4 * h               # conv5 -> d(input), G4
            + 3 * 4 * h                           # conv4..2
            + (2 * h + 2 * cin))                  # conv1 -> d(input), accumulated
-    head = sum(o + 2 * h for o in outs)
     return {"mlp_fwd": 4.0 * M * fwd, "wgrad_act": 4.0 * M * wgrad, "mlp_bwd_data": 4.0 * M * bwd,
-            "head_bwd": 4.0 * M * head}
+            "head_bwd": 4.0 * M * head, "backward_minimum": 4.0 * M * minimum}
 
 
 def algorithmic_bytes(P: int, D: float, npix: int) -> dict:

@@ -205,7 +205,8 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_mlp_bwd_fused_parts.restype = c_int32
         lib.ganet_mlp_bwd_fused_workspace.restype = c_size_t
         lib.ganet_mlp_bwd_fused.restype = c_int
-        lib.ganet_mlp_bwd_fused.argtypes = [c_int64, P, P, P, P, P, P, P, P, P, P, c_size_t, c_int32, P]
+        lib.ganet_mlp_bwd_fused.argtypes = [c_int64, P, P, P, P, c_int64, P, c_int32, P, P, P, c_int32, P, P, c_size_t,
+                                            c_int32, P]
         lib.ganet_mlp_head_bwd.restype = c_int
         lib.ganet_mlp_head_bwd.argtypes = [c_int64, c_int32, P, P, P, c_int64, P, P, P, c_int64, P, P, P]
         lib.ganet_mlp_bwd_stats.restype = c_int
@@ -250,7 +251,7 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_set_mfma_mode.restype = None
         lib.ganet_last_error.restype = c_char_p
         lib.ganet_abi_version.restype = c_int
-        if lib.ganet_abi_version() != 3:
+        if lib.ganet_abi_version() != 4:
             raise RuntimeError("libganet_hip.so ABI version mismatch; rebuild")
         _ganet = lib
     return _ganet

@@ -44,7 +44,7 @@ LIBS = {
         ("ganet_mlp_bwd.hip", []),
         ("ganet_mlp_split.hip", []),
         ("ganet_wgrad_split.hip", []),
-        ("ganet_mlp_bwd_fused.hip", []),
+        ("ganet_layer_bwd.hip", []),
         ("ganet_pack.hip", []),
         ("ganet_upsample.hip", []),
         ("ganet_conv.hip", []),

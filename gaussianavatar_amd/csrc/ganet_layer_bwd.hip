@@ -1,0 +1,389 @@
+// ganet_layer_bwd.hip — one-pass backward of a hidden decoder layer on the bf16 matrix pipe with exactly split
+// fp32 operands (ganet_split.h): the data gradient AND the weight gradient from ONE sweep over the activations.
+//
+//   dz     = A G + q Z + p                                  [M,128]  (BatchNorm backward folded, ganet_mlp_bwd.hip)
+//   a      = softplus(scale_src Z_src + shift_src)          [M,128]  (the layer's input activation, never stored)
+//   out    (+)= dz . W[128, 0:128]   (x softplus'(u_src) -> G_src, with column sums of G_src and G_src z_src)
+//   dW[n,k] = sum_m dz[m,n] a[m,k],   db[n] = sum_m dz[m,n]
+//
+// The separate kernels (mlp_bwd_split + wgrad_split) each stream G, Z and Z_src: 7 [M,128] tensors per layer
+// through HBM where 4 suffice (G, Z, Z_src in, G_src out). They are HBM-bound (0.60-0.64 of 8 TB/s) with the
+// matrix pipe at 0.19, so the bytes are what is left to remove.
+//
+// Why this needs a transposition, and where it comes from. The data gradient multiplies dz from the left: its MFMA
+// A fragment is "row m, 8 consecutive n". The weight gradient reduces over m: its fragments (of dz AND of a) are
+// "column n, 8 consecutive m". Both are the same elements, split once (the three bf16 pieces are element-wise), but
+// packed along different axes. gfx950's LDS has the transposing read for exactly this: ds_read_b64_tr_b16 hands a
+// lane four 16-bit elements of one COLUMN of a row-major image. So a workgroup keeps, per 32-row slab, the three
+// bf16 planes of dz and of a ROW-major in LDS (ds_write_b128 by the lanes that computed them); the data-gradient
+// waves read rows (ds_read_b128), the weight-gradient waves read columns (ds_read_b64_tr_b16), nobody converts twice.
+//
+// Workgroup = 8 waves on one CU, one 32-row slab per round, LDS double-buffered, ONE barrier per round:
+//   * produce (all 8 waves, slab r + 1): wave w takes rows 4 w .. 4 w + 3: per lane 8 consecutive columns of G, Z,
+//     Z_src (six 16-byte loads, issued a round ahead), dz and a in fp32, exact three-way split, three ds_write_b128
+//     per operand; Z_src itself goes to LDS as fp32 for the epilogue;
+//   * consume (slab r): waves 0-3 = data gradient of output columns 32 w .. 32 w + 31 (48 MFMAs; the W fragments
+//     of that column tile — 8 k-steps x 3 planes — live in 96 registers for the whole kernel, so W needs no LDS);
+//     waves 4-7 = weight-gradient quadrant (64 x 64 of dW, 64 accumulator registers, 48 MFMAs, 48 transposing
+//     reads). Waves w and w + 4 share a SIMD: one data-gradient and one weight-gradient wave each; they run their
+//     round in opposite order (produce -> consume vs consume -> produce), so that one wave's VALU phase lies beside
+//     the other's MFMA phase.
+// LDS image of a plane: [32 rows][256 B], 16-byte chunk q of row m stored at chunk q ^ swz(m), swz(m) =
+// ((m & 3) << 2) | ((m >> 2) & 3): 16 rows of one chunk column cover the 16 chunk slots (ds_read_b128 of the data
+// gradient: conflict-free), and the 4 rows x 4 chunks of a transposing half-wave read do too.
+#include <cstdint>
+
+#include "ganet.h"
+#include "ganet_common.h"
+#include "ganet_mlp_common.h"
+#include "ganet_split.h"
+
+namespace ganet {
+
+namespace {
+
+constexpr int LWG = 512;
+constexpr int LBLOCKS = 256;
+constexpr int LSLAB = 32;
+constexpr int PLANE = LSLAB * 256;          // bytes of one bf16 plane of a slab
+constexpr int IMG = 3 * PLANE;              // dz or a: 24 KB
+constexpr int ZSRC = LSLAB * 128 * 4;       // fp32 Z_src of the slab: 16 KB
+constexpr int BUF = 2 * IMG + ZSRC;         // 64 KB
+constexpr int COEF_OFF = 2 * BUF;           // A | q | p | scale log2e | shift log2e   (5 x 128 floats)
+constexpr int LDS_BYTES = COEF_OFF + 5 * 128 * 4;
+constexpr int LTILE = 128 * 128 + 128;      // partial tile + bias, as wgrad_split writes it
+
+#ifndef GANET_LBWD_ORDER
+#define GANET_LBWD_ORDER 1                  // 1: data-gradient waves produce first, weight-gradient waves consume first
+#endif
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+__device__ __forceinline__ uint2 read_tr(const char* p) {
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
+  return __builtin_bit_cast(uint2, v);
+}
+
+template <bool ACCUM, bool SIG>
+__global__ void __attribute__((amdgpu_flat_work_group_size(LWG, LWG), amdgpu_waves_per_eu(2, 2)))
+layer_bwd_kernel(int64_t M, const float* __restrict__ g, const float* __restrict__ gz,
+                 const float* __restrict__ gcoef, const float* __restrict__ W, int64_t ldw,
+                 float* __restrict__ out, const float* __restrict__ src_z, const float* __restrict__ src_scale,
+                 const float* __restrict__ src_shift, float* __restrict__ col_part, float* __restrict__ wpartial,
+                 int reverse) {
+  extern __shared__ u32x4 s_mem[];
+  char* const lds = reinterpret_cast<char*>(s_mem);
+  float* const s_coef = reinterpret_cast<float*>(lds + COEF_OFF);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int kg = lane >> 5, c = lane & 31;
+  const bool dwave = wave < 4;                 // data-gradient wave (uniform)
+
+  for (int i = threadIdx.x; i < 128; i += LWG) {
+    s_coef[i] = gcoef[i];
+    s_coef[128 + i] = gcoef[128 + i];
+    s_coef[256 + i] = gcoef[256 + i];
+    s_coef[384 + i] = src_scale[i] * kLog2e;
+    s_coef[512 + i] = src_shift[i] * kLog2e;
+  }
+
+  const int64_t nslab = M / LSLAB;
+  const int rounds = (int)((nslab + gridDim.x - 1) / gridDim.x);
+  auto slab_of = [&](int r) -> int64_t { return (int64_t)r * gridDim.x + blockIdx.x; };
+  auto phys = [&](int64_t slab) -> int64_t {
+    const int64_t sl = slab < nslab ? slab : nslab - 1;        // past the end: re-read the last slab (never used)
+    return reverse ? nslab - 1 - sl : sl;
+  };
+
+  // ---- producer side: lane (prow, pq) owns columns 8 pq .. 8 pq + 7 of row prow of every slab
+  const int prow = 4 * wave + (lane >> 4), pq = lane & 15;
+  const int pswz = ((prow & 3) << 2) | ((prow >> 2) & 3);
+  const int p_img = prow * 256 + ((pq ^ pswz) << 4);           // within a plane
+  const int p_zs = prow * 512 + pq * 32;                       // within the Z_src image
+  struct Raw { float4 g0, g1, z0, z1, s0, s1; };
+  auto load_raw = [&](Raw& r, int64_t ps) {
+    // the loads reuse the registers `produce` has just consumed: nothing may be scheduled across this point, or the
+    // loop-carried value needs copies at the back edge and those wait for the loads (prefetch lost)
+    __builtin_amdgcn_sched_barrier(0);
+    const int64_t off = (ps * LSLAB + prow) * 128 + 8 * pq;
+    r.g0 = *reinterpret_cast<const float4*>(g + off);
+    r.g1 = *reinterpret_cast<const float4*>(g + off + 4);
+    r.z0 = *reinterpret_cast<const float4*>(gz + off);
+    r.z1 = *reinterpret_cast<const float4*>(gz + off + 4);
+    r.s0 = *reinterpret_cast<const float4*>(src_z + off);
+    r.s1 = *reinterpret_cast<const float4*>(src_z + off + 4);
+  };
+  float bias[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias[e] = 0.f;
+  auto produce = [&](const Raw& r, int buf, bool live) {
+    char* const base = lds + buf * BUF;
+    const float4* cf = reinterpret_cast<const float4*>(s_coef);
+    const float4 A0 = cf[2 * pq], A1 = cf[2 * pq + 1], Q0 = cf[32 + 2 * pq], Q1 = cf[32 + 2 * pq + 1];
+    const float4 P0 = cf[64 + 2 * pq], P1 = cf[64 + 2 * pq + 1];
+    const float4 C0 = cf[96 + 2 * pq], C1 = cf[96 + 2 * pq + 1], H0 = cf[128 + 2 * pq], H1 = cf[128 + 2 * pq + 1];
+    const float lv = live ? 1.f : 0.f;      // a slab past the end contributes nothing to dW / db
+    float v[8];
+    v[0] = fmaf(A0.x, r.g0.x, fmaf(Q0.x, r.z0.x, P0.x)) * lv; v[1] = fmaf(A0.y, r.g0.y, fmaf(Q0.y, r.z0.y, P0.y)) * lv;
+    v[2] = fmaf(A0.z, r.g0.z, fmaf(Q0.z, r.z0.z, P0.z)) * lv; v[3] = fmaf(A0.w, r.g0.w, fmaf(Q0.w, r.z0.w, P0.w)) * lv;
+    v[4] = fmaf(A1.x, r.g1.x, fmaf(Q1.x, r.z1.x, P1.x)) * lv; v[5] = fmaf(A1.y, r.g1.y, fmaf(Q1.y, r.z1.y, P1.y)) * lv;
+    v[6] = fmaf(A1.z, r.g1.z, fmaf(Q1.z, r.z1.z, P1.z)) * lv; v[7] = fmaf(A1.w, r.g1.w, fmaf(Q1.w, r.z1.w, P1.w)) * lv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[e] += v[e];
+    u32x4 p1, p2, p3;
+    split8(v, p1, p2, p3);
+    *reinterpret_cast<u32x4*>(base + p_img) = p1;
+    *reinterpret_cast<u32x4*>(base + PLANE + p_img) = p2;
+    *reinterpret_cast<u32x4*>(base + 2 * PLANE + p_img) = p3;
+    v[0] = softplus_log2(fmaf(C0.x, r.s0.x, H0.x)); v[1] = softplus_log2(fmaf(C0.y, r.s0.y, H0.y));
+    v[2] = softplus_log2(fmaf(C0.z, r.s0.z, H0.z)); v[3] = softplus_log2(fmaf(C0.w, r.s0.w, H0.w));
+    v[4] = softplus_log2(fmaf(C1.x, r.s1.x, H1.x)); v[5] = softplus_log2(fmaf(C1.y, r.s1.y, H1.y));
+    v[6] = softplus_log2(fmaf(C1.z, r.s1.z, H1.z)); v[7] = softplus_log2(fmaf(C1.w, r.s1.w, H1.w));
+    split8(v, p1, p2, p3);
+    *reinterpret_cast<u32x4*>(base + IMG + p_img) = p1;
+    *reinterpret_cast<u32x4*>(base + IMG + PLANE + p_img) = p2;
+    *reinterpret_cast<u32x4*>(base + IMG + 2 * PLANE + p_img) = p3;
+    if (SIG) {
+      *reinterpret_cast<float4*>(base + 2 * IMG + p_zs) = r.s0;
+      *reinterpret_cast<float4*>(base + 2 * IMG + p_zs + 16) = r.s1;
+    }
+  };
+
+  // ---- data-gradient consumer: lane (row c, k-group kg) of the A fragments; C layout column c of tile `wave`.
+  // Bw: the B fragments of W[:, 32 wave .. + 31] for all 8 k-steps, split once, register-resident.
+  const int dswz = ((c & 3) << 2) | ((c >> 2) & 3);
+  const int d_row = c * 256;
+  float csum = 0.f, csz = 0.f;
+  auto dgrad = [&](const u32x4 (&Bw)[8][3], float ssc, float ssh, int buf, int64_t ps, bool live) {
+    const char* const base = lds + buf * BUF;
+    float old[16];
+    float* const orow = out + (ps * LSLAB + 4 * kg) * 128 + 32 * wave + c;
+    if (ACCUM) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) old[r] = orow[((r & 3) + 8 * (r >> 2)) * 128];
+    }
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int at = d_row + (((2 * s + kg) ^ dswz) << 4);
+      const u32x4 a1 = *reinterpret_cast<const u32x4*>(base + at);
+      const u32x4 a2 = *reinterpret_cast<const u32x4*>(base + PLANE + at);
+      const u32x4 a3 = *reinterpret_cast<const u32x4*>(base + 2 * PLANE + at);
+      if (s & 1) GANET_SPLIT_PRODUCTS(acc1, a1, a2, a3, Bw[s][0], Bw[s][1], Bw[s][2]);
+      else GANET_SPLIT_PRODUCTS(acc0, a1, a2, a3, Bw[s][0], Bw[s][1], Bw[s][2]);
+    }
+    const float* zs = reinterpret_cast<const float*>(base + 2 * IMG) + (4 * kg) * 128 + 32 * wave + c;
+    if (live) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2);
+        float val = acc0[r] + acc1[r];
+        if (ACCUM) val += old[r];
+        if (SIG) {
+          const float zv = zs[row * 128];
+          val *= sigmoid_log2(fmaf(ssc, zv, ssh));
+          csum += val;
+          csz = fmaf(val, zv, csz);
+        }
+        orow[row * 128] = val;
+      }
+    }
+  };
+
+  // ---- weight-gradient consumer: quadrant (jn, ik) of dW; transposing reads of the dz and a images
+  const int wq = wave & 3, jn = wq >> 1, ik = wq & 1;
+  const int g16 = lane & 15, cc = (lane >> 4) & 1;
+  // byte offset (within a plane) of this lane's source element group for (tile, hi); + ms * 16 rows, + plane
+  auto tr_addr = [&](int tile, int hi) -> int {
+    const int m = 8 * kg + 4 * hi + (g16 >> 2);
+    const int q = 4 * tile + 2 * cc + ((g16 >> 1) & 1);
+    const int sw = ((g16 >> 2) << 2) | (2 * kg + hi);
+    return m * 256 + ((q ^ sw) << 4) + (g16 & 1) * 8;
+  };
+  int ta[2][2], tb[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi) {
+      ta[t][hi] = tr_addr(2 * jn + t, hi);
+      tb[t][hi] = IMG + tr_addr(2 * ik + t, hi);
+    }
+  auto wgrad = [&](f32x16 (&wacc)[2][2], int buf) {
+    const char* const base = lds + buf * BUF;
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+      u32x4 fa[2][3], fb[2][3];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const uint2 alo = read_tr(base + ta[t][0] + ms * 4096 + p * PLANE);
+          const uint2 ahi = read_tr(base + ta[t][1] + ms * 4096 + p * PLANE);
+          fa[t][p] = u32x4{alo.x, alo.y, ahi.x, ahi.y};
+          const uint2 blo = read_tr(base + tb[t][0] + ms * 4096 + p * PLANE);
+          const uint2 bhi = read_tr(base + tb[t][1] + ms * 4096 + p * PLANE);
+          fb[t][p] = u32x4{blo.x, blo.y, bhi.x, bhi.y};
+        }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          GANET_SPLIT_PRODUCTS(wacc[a][b], fa[a][0], fa[a][1], fa[a][2], fb[b][0], fb[b][1], fb[b][2]);
+    }
+  };
+
+  // ---- main loop. The two roles run separate loops (so that the register allocator sees either the 96 W-fragment
+  // registers or the 64 weight-gradient accumulators, not both) with the same barrier count.
+  Raw raw;
+  load_raw(raw, phys(slab_of(0)));
+  __syncthreads();                                   // coefficients staged
+  produce(raw, 0, slab_of(0) < nslab);
+  load_raw(raw, phys(slab_of(1)));
+  float* const wout = wpartial + (size_t)blockIdx.x * LTILE;
+  if (dwave) {
+    u32x4 Bw[8][3];
+    {
+      const float* wp = W + (size_t)(8 * kg) * ldw + 32 * wave + c;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = wp[(size_t)(16 * s + e) * ldw];
+        split8(v, Bw[s][0], Bw[s][1], Bw[s][2]);
+      }
+    }
+    const float ssc = SIG ? src_scale[32 * wave + c] * kLog2e : 0.f;
+    const float ssh = SIG ? src_shift[32 * wave + c] * kLog2e : 0.f;
+    __syncthreads();
+    for (int r = 0; r < rounds; ++r) {
+      const int buf = r & 1;
+      const bool live_next = slab_of(r + 1) < nslab && r + 1 < rounds;
+      if (GANET_LBWD_ORDER) {
+        produce(raw, buf ^ 1, live_next);
+        load_raw(raw, phys(slab_of(r + 2)));
+        dgrad(Bw, ssc, ssh, buf, phys(slab_of(r)), slab_of(r) < nslab);
+      } else {
+        dgrad(Bw, ssc, ssh, buf, phys(slab_of(r)), slab_of(r) < nslab);
+        produce(raw, buf ^ 1, live_next);
+        load_raw(raw, phys(slab_of(r + 2)));
+      }
+      __syncthreads();
+    }
+    if (SIG) {       // column sums of G_src and G_src z_src: one wave owns a column tile
+      const float s = csum + __shfl_xor(csum, 32);
+      const float q = csz + __shfl_xor(csz, 32);
+      if (kg == 0) {
+        col_part[(size_t)blockIdx.x * 256 + 32 * wave + c] = s;
+        col_part[(size_t)blockIdx.x * 256 + 128 + 32 * wave + c] = q;
+      }
+    }
+  } else {
+    f32x16 wacc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wacc[a][b][r] = 0.f;
+    __syncthreads();
+    for (int r = 0; r < rounds; ++r) {
+      const int buf = r & 1;
+      const bool live_next = slab_of(r + 1) < nslab && r + 1 < rounds;
+      wgrad(wacc, buf);
+      produce(raw, buf ^ 1, live_next);
+      load_raw(raw, phys(slab_of(r + 2)));
+      __syncthreads();
+    }
+    // dW quadrant straight from the accumulators (one wave owns a quadrant)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = (2 * jn + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+          wout[n * 128 + (2 * ik + b) * 32 + c] = wacc[a][b][r] * kLn2;     // a was in log2 units
+        }
+  }
+  // db: every lane holds 8 column sums over its rows
+  float* const s_red = reinterpret_cast<float*>(lds);        // [8 waves][128]; the slab buffers are dead
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float b = bias[e];
+    b += __shfl_xor(b, 16);
+    b += __shfl_xor(b, 32);
+    if (lane < 16) s_red[wave * 128 + 8 * pq + e] = b;
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < 128; n += LWG) {
+    float b = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) b += s_red[w * 128 + n];
+    wout[128 * 128 + n] = b;
+  }
+}
+
+}  // namespace
+
+}  // namespace ganet
+
+using namespace ganet;
+
+extern "C" {
+
+int32_t ganet_mlp_bwd_fused_parts(void) { return LBLOCKS; }
+
+size_t ganet_mlp_bwd_fused_workspace(void) { return (size_t)LBLOCKS * LTILE * sizeof(float); }
+
+int ganet_mlp_bwd_fused(int64_t M, const float* g, const float* gz, const float* gcoef, const float* W, int64_t ldw,
+                        float* out, int32_t accumulate, const float* src_z, const float* src_scale,
+                        const float* src_shift, int32_t apply_act, float* col_part, void* wgrad_workspace,
+                        size_t workspace_bytes, int32_t row_order, void* stream_) {
+  if (M <= 0 || (M % LSLAB) || !g || !gz || !gcoef || !W || ldw < 128 || !out || !src_z || !src_scale ||
+      !src_shift || (apply_act && !col_part) || !wgrad_workspace || !aligned16(g) || !aligned16(gz) ||
+      !aligned16(src_z)) {
+    set_error("ganet_mlp_bwd_fused: invalid arguments (M must be a multiple of %d, activations [M,128] contiguous "
+              "and 16-byte aligned, W [128, >=128] with row stride ldw)", LSLAB);
+    return 1;
+  }
+  if (workspace_bytes < ganet_mlp_bwd_fused_workspace()) {
+    set_error("ganet_mlp_bwd_fused: workspace too small (%zu < %zu)", workspace_bytes,
+              ganet_mlp_bwd_fused_workspace());
+    return 2;
+  }
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int reverse = row_order == GANET_ROWS_DOWN ? 1 : 0;
+  const int64_t nslab = M / LSLAB;
+  const int blocks = (int)(nslab < LBLOCKS ? nslab : LBLOCKS);
+  float* wp = static_cast<float*>(wgrad_workspace);
+  if (blocks < LBLOCKS)        // the reduction adds up all LBLOCKS partial tiles
+    if (check_hip(hipMemsetAsync(wp + (size_t)blocks * LTILE, 0, (size_t)(LBLOCKS - blocks) * LTILE * sizeof(float),
+                                 stream), "hipMemsetAsync")) return 3;
+  if (apply_act && blocks < LBLOCKS)
+    if (check_hip(hipMemsetAsync(col_part + (size_t)blocks * 256, 0, (size_t)(LBLOCKS - blocks) * 256 * sizeof(float),
+                                 stream), "hipMemsetAsync")) return 3;
+#define LAUNCH(AC, SG)                                                                                          \
+  do {                                                                                                          \
+    static bool attr_set = false;                                                                               \
+    if (!attr_set) {                                                                                            \
+      if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_bwd_kernel<AC, SG>),                \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES),            \
+                    "hipFuncSetAttribute")) return 3;                                                           \
+      attr_set = true;                                                                                          \
+    }                                                                                                           \
+    ProfScope prof_(K_LAYER_BWD, stream);                                                                       \
+    hipLaunchKernelGGL((layer_bwd_kernel<AC, SG>), dim3(blocks), dim3(LWG), LDS_BYTES, stream, M, g, gz, gcoef, \
+                       W, ldw, out, src_z, src_scale, src_shift, col_part, wp, reverse);                        \
+    return check_hip(hipGetLastError(), "layer_bwd_kernel");                                                    \
+  } while (0)
+  if (accumulate && apply_act) LAUNCH(true, true);
+  if (accumulate) LAUNCH(true, false);
+  if (apply_act) LAUNCH(false, true);
+  LAUNCH(false, false);
+#undef LAUNCH
+}
+
+}  // extern "C"

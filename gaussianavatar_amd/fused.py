@@ -478,13 +478,11 @@ def _decoder_bn_layers():
 # measured on MI355X: riding the head weight gradient on head_bwd is ~3 % SLOWER per iteration than the
 # separate ganet_wgrad_act pass (head_bwd turns VALU-bound), so it stays off; GA_HEAD_RIDE=1 selects it
 _HEAD_RIDE = os.environ.get("GA_HEAD_RIDE", "0") == "1"
-# hidden 128 -> 128 layers: data gradient + weight gradient in one pass over the activations
-# (ganet_mlp_bwd_fused: 4 instead of 7 [M,128] tensors through HBM). Measured on MI355X, M = 262,144
-# (tools/microbench_bwd_fused.py): 249-259 us fused vs 237-272 us for wgrad_act + mlp_bwd_data back to back —
-# no gain, because the pair was never HBM-bound (both sit at 45-55 % of the fp32-MFMA issue rate, and one
-# wave per SIMD with 320 accumulator registers leaves nothing to hide the operand waits). Parity-tested and
-# kept as an A/B switch (GA_FUSED_BWD=1); the two separate kernels stay the default.
-_FUSED_BWD = os.environ.get("GA_FUSED_BWD", "0") == "1"
+# hidden 128 -> 128 layers: data gradient + weight gradient in ONE pass over the activations
+# (ganet_mlp_bwd_fused, csrc/ganet_layer_bwd.hip): 4 instead of 7 [M,128] tensors through HBM. Used whenever the
+# row count is a multiple of 32; the separate kernels remain for ragged row counts and for the layers whose input
+# is the 72-column decoder input. (Tests switch it off to compare the two formulations.)
+_FUSED_BWD = True
 
 
 # The weight-gradient launches of the decoder backward are off its dependency chain (nothing reads dW before the
@@ -718,22 +716,26 @@ class _DecoderFn(torch.autograd.Function):
         if fuse_ok and n_fused * 256 > col_part.numel():
             col_part = torch.empty(n_fused * 256, dtype=torch.float32, device=dev)
 
-        def layer_bwd(i, src):
-            """hidden layer i (128 -> 128, input = act(bn(zs[src]))): d weight, d bias, and G of the source
-            layer written into a new tensor (with its column sums in col_part). One pass when the fused
-            kernel applies, else weight gradient + data gradient."""
-            Gs[src] = f32(M, 128)
+        def layer_bwd(i, src, W=None, out=None, accumulate=False, act=True):
+            """hidden layer i (input = act(bn(zs[src])) times W [128 out, 128 in], default conv_w[i]): d weight,
+            d bias, and out (+)= dz_i . W — with act: out = G of the source layer, its column sums in col_part.
+            One pass over the activations when the fused kernel applies, else weight gradient + data gradient.
+            Returns (dW, db, number of col_part rows)."""
+            W = conv_w[i] if W is None else W
+            if out is None:
+                out = Gs[src] = f32(M, 128)
             if not fuse_ok:
                 dW, db = wgrad(None, i, src)
-                data_grad(i, conv_w[i], Gs[src], False, src)
+                data_grad(i, W, out, accumulate, src if act else None)
                 return dW, db, n_data
             dW, db = f32(128, 128), f32(128)
             j = njobs[0]
             ws = wg_ws.data_ptr() + j * wg_bytes
-            W = conv_w[i].contiguous()
+            assert W.stride(1) == 1
             _native.ganet_check(lib.ganet_mlp_bwd_fused(
-                M, _ptr(Gs[i]), _ptr(zs[i]), _ptr(coefs[i]), _ptr(W), _ptr(Gs[src]), _ptr(zs[src]),
-                _ptr(stats[src][2]), _ptr(stats[src][3]), _ptr(col_part), ws, wg_bytes, sweep.next(), st))
+                M, _ptr(Gs[i]), _ptr(zs[i]), _ptr(coefs[i]), _ptr(W), W.stride(0), _ptr(out), int(accumulate),
+                _ptr(zs[src]), _ptr(stats[src][2]), _ptr(stats[src][3]), int(act), _ptr(col_part), ws, wg_bytes,
+                sweep.next(), st))
             jobs[j].workspace, jobs[j].M, jobs[j].N, jobs[j].K = ws, M, 128, 128
             jobs[j].dW, jobs[j].db, jobs[j].nblocks = dW.data_ptr(), db.data_ptr(), n_fused
             njobs[0] = j + 1
@@ -769,17 +771,15 @@ class _DecoderFn(torch.autograd.Function):
             g_conv_w[i7], g_conv_b[i7] = dW.unsqueeze(-1), db
             Gs[i7] = None
             finish(i6, nparts)
-            dW, db = wgrad(None, i6, 4)
-            g_conv_w[i6], g_conv_b[i6] = dW.unsqueeze(-1), db
             last = pos == len(heads) - 1
-            data_grad(i6, conv_w[i6], G5, pos > 0, 4 if last else None)
+            dW, db, nparts5 = layer_bwd(i6, 4, out=G5, accumulate=pos > 0, act=last)
+            g_conv_w[i6], g_conv_b[i6] = dW.unsqueeze(-1), db
             Gs[i6] = None
         dx = None
         if heads:
             Gs[4] = G5
-            finish(4, n_data)
+            finish(4, nparts5)
             w5 = conv_w[4]
-            dWy, db5 = wgrad(None, 4, 3)
             dWx, _ = wgrad(None, 4, None, _K1_PAD)
             need_dx = ctx.needs_input_grad[0]
             if need_dx:
@@ -787,10 +787,8 @@ class _DecoderFn(torch.autograd.Function):
                 # gradient are never read (they belong to a constant) and stay unwritten
                 dx = f32(M, ctx.x_cols)
                 data_grad(4, w5[:, :cin], dx, False, None)
-            Gs[3] = f32(M, 128)
-            data_grad(4, w5[:, cin:], Gs[3], False, 3)
+            dWy, db5, nparts = layer_bwd(4, 3, W=w5[:, cin:])
             Gs[4] = None
-            nparts = n_data
             for i in (3, 2, 1):
                 finish(i, nparts)
                 dW, db, nparts = layer_bwd(i, i - 1)

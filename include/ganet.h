@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GANET_ABI_VERSION 3
+#define GANET_ABI_VERSION 4
 #define GANET_MAX_TERMS 8
 
 /* ---- dW[N,K] = sum_m g[m,n] x[m,k] ; db[N] = sum_m g[m,n] (db may be NULL).
@@ -151,19 +151,23 @@ int ganet_wgrad_reduce_batch(int32_t n_jobs, const GanetWgradJob* jobs, void* st
  * (/root/reference/model/modules.py:554-582) without materialising dz or dL/dy. */
 int32_t ganet_mlp_bwd_data_parts(void);
 int32_t ganet_mlp_head_bwd_parts(void);
-/* ganet_mlp_bwd_fused (ganet_mlp_bwd_fused.hip): ganet_mlp_bwd_data (O = 128, src_z given, not accumulating) AND
- * the matching ganet_wgrad_act (N = K = 128, x = softplus(src_scale src_z + src_shift)) of a hidden 128 -> 128
- * layer in ONE pass over the activations: 4 instead of 7 [M,128] tensors through HBM. All tensors contiguous
- * ([M,128], W [128,128]), M a multiple of 32. col_part: [ganet_mlp_bwd_fused_parts()][2][128] partial column
- * sums of out and out . src_z; wgrad_workspace (ganet_mlp_bwd_fused_workspace() bytes) receives
+/* ganet_mlp_bwd_fused (ganet_layer_bwd.hip): the backward of a hidden 128 -> 128 layer in ONE pass over the
+ * activations — ganet_mlp_bwd_data (O = 128) AND the matching ganet_wgrad_act (N = K = 128, x = softplus(src_scale
+ * src_z + src_shift)): 4 instead of 7 [M,128] tensors through HBM (g, gz, src_z in; out written). Same arithmetic as
+ * the separate kernels (exactly split fp32 operands on the bf16 matrix pipe). g, gz, src_z, out: [M,128] contiguous,
+ * 16-byte aligned, M a multiple of 32; W [128, >= 128] with row stride ldw (a column slice of a wider weight is
+ * fine). accumulate: out += ...; apply_act: the result is multiplied by softplus'(src_scale src_z + src_shift) (out = G
+ * of the source layer) and col_part [ganet_mlp_bwd_fused_parts()][2][128] receives the partial column sums of out and
+ * out . src_z (apply_act = 0: out is the raw dL/dy contribution, col_part untouched — the pattern of several layers
+ * accumulating into one source). wgrad_workspace (ganet_mlp_bwd_fused_workspace() bytes) receives
  * ganet_mlp_bwd_fused_parts() partial tiles [128*128 + 128] for ganet_wgrad_reduce_batch (job.nblocks =
  * ganet_mlp_bwd_fused_parts()). */
 int32_t ganet_mlp_bwd_fused_parts(void);
 size_t ganet_mlp_bwd_fused_workspace(void);
-int ganet_mlp_bwd_fused(int64_t M, const float* g, const float* gz, const float* gcoef, const float* W,
-                        float* out, const float* src_z, const float* src_scale, const float* src_shift,
-                        float* col_part, void* wgrad_workspace, size_t workspace_bytes, int32_t row_order,
-                        void* stream);
+int ganet_mlp_bwd_fused(int64_t M, const float* g, const float* gz, const float* gcoef, const float* W, int64_t ldw,
+                        float* out, int32_t accumulate, const float* src_z, const float* src_scale,
+                        const float* src_shift, int32_t apply_act, float* col_part, void* wgrad_workspace,
+                        size_t workspace_bytes, int32_t row_order, void* stream);
 int ganet_mlp_bwd_data(int64_t M, int32_t O, const float* g, int64_t ldg, const float* gz, int64_t ldgz,
                        const float* gcoef, const float* W, int64_t ldw, float* out, int64_t ldo,
                        int32_t accumulate,

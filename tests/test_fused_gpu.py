@@ -253,7 +253,8 @@ def test_fused_decoder_equals_per_layer_formulation(M, one_pass, monkeypatch):
     """The whole-decoder function on the fused layer kernels (reference widths: 66 -> 128 x 5 -> three
     heads) against the per-layer formulation (vendor GEMM + fused BN kernels) on the same device:
     outputs, every parameter gradient, the input gradient and the BatchNorm running statistics.
-    one_pass: the opt-in single-pass hidden-layer backward (ganet_mlp_bwd_fused, GA_FUSED_BWD=1)."""
+    one_pass: the single-pass hidden-layer backward (ganet_mlp_bwd_fused, the default when M % 32 == 0) vs the
+    separate weight- / data-gradient kernels."""
     import copy
     from gaussianavatar_amd import fused
     from gaussianavatar_amd.network import ShapeDecoder
@@ -597,10 +598,13 @@ def test_l1_ssim_pair_cache_respects_grad_mode():
 
 
 @pytest.mark.parametrize("row_order", [0, 2])
-@pytest.mark.parametrize("M", [262144, 32 * 1031, 64])
-def test_mlp_bwd_fused_matches_float64(M, row_order):
-    """ganet_mlp_bwd_fused: data gradient (-> G_src with its column sums) AND weight / bias gradient of a hidden
-    128 -> 128 layer in one pass, against float64 torch."""
+@pytest.mark.parametrize("M,accumulate,act,wslice", [(262144, False, True, False), (32 * 1031, True, True, True),
+                                                     (32 * 700, True, False, False), (32 * 257, False, False, True),
+                                                     (64, False, True, False), (32, True, True, True)])
+def test_mlp_bwd_fused_matches_float64(M, accumulate, act, wslice, row_order):
+    """ganet_mlp_bwd_fused (csrc/ganet_layer_bwd.hip): data gradient (accumulating or not; with act: -> G_src and
+    its column sums) AND weight / bias gradient of a hidden 128 -> 128 layer in one pass over the activations,
+    against float64 torch. wslice: W is a column slice of a wider weight (row stride 194, as conv5's)."""
     from gaussianavatar_amd import _native, fused
     lib = _native.ganet()
     torch.manual_seed(M % 29)
@@ -608,18 +612,22 @@ def test_mlp_bwd_fused_matches_float64(M, row_order):
     G = torch.randn(M, 128, device=dev)
     z = torch.randn(M, 128, device=dev) * 2
     coef = torch.randn(3, 128, device=dev)
-    W = torch.randn(128, 128, device=dev) * 0.1                  # [out n, in o]
+    Wfull = torch.randn(128, 194, device=dev) * 0.1               # [out n, in]
+    W = Wfull[:, 66:] if wslice else Wfull[:, :128].contiguous()
     src_z = torch.randn(M, 128, device=dev) * 2
     sc = torch.empty(128, device=dev).uniform_(0.3, 2.0)
     sh = torch.empty(128, device=dev).uniform_(-12, 25)
-    out = torch.full((M, 128), float("nan"), device=dev)
+    out = torch.randn(M, 128, device=dev) if accumulate else torch.full((M, 128), float("nan"), device=dev)
+    prev = out.clone()
     parts = lib.ganet_mlp_bwd_fused_parts()
-    part = torch.zeros(parts * 256, device=dev)
+    part = torch.full((parts * 256,), float("nan"), device=dev)
     wsb = lib.ganet_mlp_bwd_fused_workspace()
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    ws.view(torch.float32).fill_(float("nan"))
     _native.ganet_check(lib.ganet_mlp_bwd_fused(M, fused._ptr(G), fused._ptr(z), fused._ptr(coef), fused._ptr(W),
-                                                fused._ptr(out), fused._ptr(src_z), fused._ptr(sc), fused._ptr(sh),
-                                                fused._ptr(part), ws.data_ptr(), wsb, row_order, fused._stream(dev)))
+                                                W.stride(0), fused._ptr(out), int(accumulate), fused._ptr(src_z),
+                                                fused._ptr(sc), fused._ptr(sh), int(act), fused._ptr(part),
+                                                ws.data_ptr(), wsb, row_order, fused._stream(dev)))
     dW, db = torch.empty(128, 128, device=dev), torch.empty(128, device=dev)
     jobs = (_native.GanetWgradJob * 1)()
     jobs[0].workspace, jobs[0].M, jobs[0].N, jobs[0].K = ws.data_ptr(), M, 128, 128
@@ -627,12 +635,17 @@ def test_mlp_bwd_fused_matches_float64(M, row_order):
     _native.ganet_check(lib.ganet_wgrad_reduce_batch(1, jobs, fused._stream(dev)))
     dz = coef[0].double() * G.double() + coef[1].double() * z.double() + coef[2].double()
     u = src_z.double() * sc.double() + sh.double()
-    ref = (dz @ W.double()) * torch.where(u > 20, torch.ones_like(u), torch.sigmoid(u))
+    ref = dz @ W.double()
+    if accumulate:
+        ref = ref + prev.double()
+    if act:
+        ref = ref * torch.where(u > 20, torch.ones_like(u), torch.sigmoid(u))
     assert float((out.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 2e-5
-    p = part.reshape(parts, 2, 128).double().sum(0)
-    assert float((p[0] - ref.sum(0)).abs().max()) <= 1e-4 * float(ref.abs().sum(0).max()) + 1e-3
-    r2 = (ref * src_z.double()).sum(0)
-    assert float((p[1] - r2).abs().max()) <= 1e-4 * float((ref * src_z.double()).abs().sum(0).max()) + 1e-3
+    if act:
+        p = part.reshape(parts, 2, 128).double().sum(0)
+        assert float((p[0] - ref.sum(0)).abs().max()) <= 1e-4 * float(ref.abs().sum(0).max()) + 1e-3
+        r2 = (ref * src_z.double()).sum(0)
+        assert float((p[1] - r2).abs().max()) <= 1e-4 * float((ref * src_z.double()).abs().sum(0).max()) + 1e-3
     x = torch.nn.functional.softplus(u)
     refW = dz.t() @ x
     assert float((dW.double() - refW).abs().max()) <= 2e-5 * float(refW.abs().max()) + 1e-4

@@ -20,7 +20,7 @@ def sep():
     _native.ganet_check(lib.ganet_wgrad_act(M, 128, 128, P(G), 128, P(z), 128, P(coef), P(sz), 128, P(sc), P(sh), None, None, ws.data_ptr(), wsb, 1, st))
     _native.ganet_check(lib.ganet_mlp_bwd_data(M, 128, P(G), 128, P(z), 128, P(coef), P(W), 128, P(out), 128, 0, P(sz), 128, P(sc), P(sh), P(part), 2, st))
 def fus():
-    _native.ganet_check(lib.ganet_mlp_bwd_fused(M, P(G), P(z), P(coef), P(W), P(out), P(sz), P(sc), P(sh), P(part), ws.data_ptr(), wsb, 1, st))
+    _native.ganet_check(lib.ganet_mlp_bwd_fused(M, P(G), P(z), P(coef), P(W), 128, P(out), 0, P(sz), P(sc), P(sh), 1, P(part), ws.data_ptr(), wsb, 1, st))
 for name, fn in (("separate", sep), ("fused", fus), ("separate", sep), ("fused", fus)):
     for _ in range(5): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
