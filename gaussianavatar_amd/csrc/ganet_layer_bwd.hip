@@ -18,16 +18,23 @@
 // bf16 planes of dz and of a ROW-major in LDS (ds_write_b128 by the lanes that computed them); the data-gradient
 // waves read rows (ds_read_b128), the weight-gradient waves read columns (ds_read_b64_tr_b16), nobody converts twice.
 //
-// Workgroup = 8 waves on one CU, one 32-row slab per round, LDS double-buffered, ONE barrier per round:
-//   * produce (all 8 waves, slab r + 1): wave w takes rows 4 w .. 4 w + 3: per lane 8 consecutive columns of G, Z,
-//     Z_src (six 16-byte loads, issued a round ahead), dz and a in fp32, exact three-way split, three ds_write_b128
-//     per operand; Z_src itself goes to LDS as fp32 for the epilogue;
-//   * consume (slab r): waves 0-3 = data gradient of output columns 32 w .. 32 w + 31 (48 MFMAs; the W fragments
-//     of that column tile — 8 k-steps x 3 planes — live in 96 registers for the whole kernel, so W needs no LDS);
-//     waves 4-7 = weight-gradient quadrant (64 x 64 of dW, 64 accumulator registers, 48 MFMAs, 48 transposing
-//     reads). Waves w and w + 4 share a SIMD: one data-gradient and one weight-gradient wave each; they run their
-//     round in opposite order (produce -> consume vs consume -> produce), so that one wave's VALU phase lies beside
-//     the other's MFMA phase.
+// Workgroup = 8 waves on one CU, one 32-row slab per round, LDS double-buffered, ONE barrier per round, the round's
+// VALU work and its MFMA work on DIFFERENT waves of a SIMD (the matrix pipe and the vector ALU are separate pipes,
+// but one wave issues in program order: a first version in which every wave produced AND multiplied measured 43 % of
+// wave time stalled at issue with the matrix pipe busy 34 %):
+//   * waves 4-7 = producers (slab r + 1): wave w takes rows 8 (w - 4) .. + 7: per lane 8 consecutive columns of two
+//     rows of G, Z, Z_src (twelve 16-byte loads, issued two slabs ahead), dz and a in fp32, exact three-way split,
+//     three ds_write_b128 per operand; Z_src itself goes to LDS as fp32 for the epilogue. They also store the
+//     finished output tile, which the consumers hand back through LDS;
+//   * waves 0-3 = consumers (slab r): wave w = data gradient of output columns 32 w .. 32 w + 31 (48 MFMAs; the W
+//     fragments of that column tile — 8 k-steps x 3 planes — live in 96 registers for the whole kernel, so W needs no
+//     LDS) AND weight-gradient quadrant (w >> 1, w & 1) (64 x 64 of dW, 64 accumulator registers, 48 MFMAs, 48
+//     transposing reads), the LDS reads of a group of MFMAs issued before the previous group's MFMAs; then the
+//     epilogue of its output tile (softplus', column sums), written over the slab's Z_src image.
+//   Waves w and w + 4 share a SIMD: one consumer and one producer each.
+// Measured (M = 262,144, MI355X, tools/lbwd_trace.py = s_memtime stamps per phase): round 6.7 k cycles = consumer
+// 3.0 k (data gradient: one dependent accumulator chain) + 1.9 k (weight gradient) + 1.1 k (epilogue), producer 5.9 k;
+// 120-135 us per launch against 185-210 us for the two separate kernels, 4.1-4.6 TB/s of algorithmic traffic.
 // LDS image of a plane: [32 rows][256 B], 16-byte chunk q of row m stored at chunk q ^ swz(m), swz(m) =
 // ((m & 3) << 2) | ((m >> 2) & 3): 16 rows of one chunk column cover the 16 chunk slots (ds_read_b128 of the data
 // gradient: conflict-free), and the 4 rows x 4 chunks of a transposing half-wave read do too.
@@ -53,11 +60,18 @@ constexpr int COEF_OFF = 2 * BUF;           // A | q | p | scale log2e | shift l
 constexpr int LDS_BYTES = COEF_OFF + 5 * 128 * 4;
 constexpr int LTILE = 128 * 128 + 128;      // partial tile + bias, as wgrad_split writes it
 
-#ifndef GANET_LBWD_ORDER
-#define GANET_LBWD_ORDER 1                  // 1: data-gradient waves produce first, weight-gradient waves consume first
+
+#ifdef GANET_LBWD_TRACE
+// development: phase time stamps (s_memtime) of block 0's consumer wave 0 and producer wave 4, 16 stamps per round
+__device__ unsigned long long g_lbwd_trace[2][64][16];
+#define LBWD_STAMP(ROLE, R, I) do { if (blockIdx.x == 0 && lane == 0 && (R) < 64 && wave == ((ROLE) ? 4 : 0)) \
+    g_lbwd_trace[ROLE][R][I] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LBWD_STAMP(ROLE, R, I) do {} while (0)
 #endif
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
 __device__ __forceinline__ uint2 read_tr(const char* p) {
@@ -67,18 +81,19 @@ __device__ __forceinline__ uint2 read_tr(const char* p) {
 
 template <bool ACCUM, bool SIG>
 __global__ void __attribute__((amdgpu_flat_work_group_size(LWG, LWG), amdgpu_waves_per_eu(2, 2)))
-layer_bwd_kernel(int64_t M, const float* __restrict__ g, const float* __restrict__ gz,
-                 const float* __restrict__ gcoef, const float* __restrict__ W, int64_t ldw,
-                 float* __restrict__ out, const float* __restrict__ src_z, const float* __restrict__ src_scale,
-                 const float* __restrict__ src_shift, float* __restrict__ col_part, float* __restrict__ wpartial,
-                 int reverse) {
+layer_bwd_spec_kernel(int64_t M, const float* __restrict__ g, const float* __restrict__ gz,
+                      const float* __restrict__ gcoef, const float* __restrict__ W, int64_t ldw,
+                      float* __restrict__ out, const float* __restrict__ src_z, const float* __restrict__ src_scale,
+                      const float* __restrict__ src_shift, float* __restrict__ col_part, float* __restrict__ wpartial,
+                      int reverse) {
   extern __shared__ u32x4 s_mem[];
   char* const lds = reinterpret_cast<char*>(s_mem);
   float* const s_coef = reinterpret_cast<float*>(lds + COEF_OFF);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int kg = lane >> 5, c = lane & 31;
-  const bool dwave = wave < 4;                 // data-gradient wave (uniform)
+  const bool consumer = wave < 4;              // uniform
+  LBWD_STAMP(0, 63, 0); LBWD_STAMP(1, 63, 0);
 
   for (int i = threadIdx.x; i < 128; i += LWG) {
     s_coef[i] = gcoef[i];
@@ -87,7 +102,6 @@ layer_bwd_kernel(int64_t M, const float* __restrict__ g, const float* __restrict
     s_coef[384 + i] = src_scale[i] * kLog2e;
     s_coef[512 + i] = src_shift[i] * kLog2e;
   }
-
   const int64_t nslab = M / LSLAB;
   const int rounds = (int)((nslab + gridDim.x - 1) / gridDim.x);
   auto slab_of = [&](int r) -> int64_t { return (int64_t)r * gridDim.x + blockIdx.x; };
@@ -95,155 +109,132 @@ layer_bwd_kernel(int64_t M, const float* __restrict__ g, const float* __restrict
     const int64_t sl = slab < nslab ? slab : nslab - 1;        // past the end: re-read the last slab (never used)
     return reverse ? nslab - 1 - sl : sl;
   };
+  float* const wout = wpartial + (size_t)blockIdx.x * LTILE;
+  float* const s_red = reinterpret_cast<float*>(lds);          // [4 producer waves][128] after the loop
 
-  // ---- producer side: lane (prow, pq) owns columns 8 pq .. 8 pq + 7 of row prow of every slab
-  const int prow = 4 * wave + (lane >> 4), pq = lane & 15;
-  const int pswz = ((prow & 3) << 2) | ((prow >> 2) & 3);
-  const int p_img = prow * 256 + ((pq ^ pswz) << 4);           // within a plane
-  const int p_zs = prow * 512 + pq * 32;                       // within the Z_src image
-  struct Raw { float4 g0, g1, z0, z1, s0, s1; };
-  auto load_raw = [&](Raw& r, int64_t ps) {
-    // the loads reuse the registers `produce` has just consumed: nothing may be scheduled across this point, or the
-    // loop-carried value needs copies at the back edge and those wait for the loads (prefetch lost)
-    __builtin_amdgcn_sched_barrier(0);
-    const int64_t off = (ps * LSLAB + prow) * 128 + 8 * pq;
-    r.g0 = *reinterpret_cast<const float4*>(g + off);
-    r.g1 = *reinterpret_cast<const float4*>(g + off + 4);
-    r.z0 = *reinterpret_cast<const float4*>(gz + off);
-    r.z1 = *reinterpret_cast<const float4*>(gz + off + 4);
-    r.s0 = *reinterpret_cast<const float4*>(src_z + off);
-    r.s1 = *reinterpret_cast<const float4*>(src_z + off + 4);
-  };
-  float bias[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bias[e] = 0.f;
-  auto produce = [&](const Raw& r, int buf, bool live) {
-    char* const base = lds + buf * BUF;
+  if (!consumer) {
+    // ---- producer: lane (row group h, prow, pq) owns columns 8 pq .. + 7 of rows 8 pw + 4 h + (lane >> 4), h = 0, 1
+    const int pw = wave - 4, pq = lane & 15;
+    struct Raw { f32x4 g0, g1, z0, z1, s0, s1; };
+    auto row_of = [&](int h) { return 8 * pw + 4 * h + (lane >> 4); };
+    auto load_raw = [&](Raw& r, int64_t ps, int h) {
+      const int64_t off = (ps * LSLAB + row_of(h)) * 128 + 8 * pq;
+      r.g0 = *reinterpret_cast<const f32x4*>(g + off);
+      r.g1 = *reinterpret_cast<const f32x4*>(g + off + 4);
+      r.z0 = *reinterpret_cast<const f32x4*>(gz + off);
+      r.z1 = *reinterpret_cast<const f32x4*>(gz + off + 4);
+      r.s0 = *reinterpret_cast<const f32x4*>(src_z + off);
+      r.s1 = *reinterpret_cast<const f32x4*>(src_z + off + 4);
+    };
+    // per-column coefficients of this lane's 8 columns: registers (a producer holds little else)
+    __syncthreads();                                     // coefficients staged
     const float4* cf = reinterpret_cast<const float4*>(s_coef);
     const float4 A0 = cf[2 * pq], A1 = cf[2 * pq + 1], Q0 = cf[32 + 2 * pq], Q1 = cf[32 + 2 * pq + 1];
     const float4 P0 = cf[64 + 2 * pq], P1 = cf[64 + 2 * pq + 1];
     const float4 C0 = cf[96 + 2 * pq], C1 = cf[96 + 2 * pq + 1], H0 = cf[128 + 2 * pq], H1 = cf[128 + 2 * pq + 1];
-    const float lv = live ? 1.f : 0.f;      // a slab past the end contributes nothing to dW / db
-    float v[8];
-    v[0] = fmaf(A0.x, r.g0.x, fmaf(Q0.x, r.z0.x, P0.x)) * lv; v[1] = fmaf(A0.y, r.g0.y, fmaf(Q0.y, r.z0.y, P0.y)) * lv;
-    v[2] = fmaf(A0.z, r.g0.z, fmaf(Q0.z, r.z0.z, P0.z)) * lv; v[3] = fmaf(A0.w, r.g0.w, fmaf(Q0.w, r.z0.w, P0.w)) * lv;
-    v[4] = fmaf(A1.x, r.g1.x, fmaf(Q1.x, r.z1.x, P1.x)) * lv; v[5] = fmaf(A1.y, r.g1.y, fmaf(Q1.y, r.z1.y, P1.y)) * lv;
-    v[6] = fmaf(A1.z, r.g1.z, fmaf(Q1.z, r.z1.z, P1.z)) * lv; v[7] = fmaf(A1.w, r.g1.w, fmaf(Q1.w, r.z1.w, P1.w)) * lv;
+    float bias[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bias[e] += v[e];
-    u32x4 p1, p2, p3;
-    split8(v, p1, p2, p3);
-    *reinterpret_cast<u32x4*>(base + p_img) = p1;
-    *reinterpret_cast<u32x4*>(base + PLANE + p_img) = p2;
-    *reinterpret_cast<u32x4*>(base + 2 * PLANE + p_img) = p3;
-    v[0] = softplus_log2(fmaf(C0.x, r.s0.x, H0.x)); v[1] = softplus_log2(fmaf(C0.y, r.s0.y, H0.y));
-    v[2] = softplus_log2(fmaf(C0.z, r.s0.z, H0.z)); v[3] = softplus_log2(fmaf(C0.w, r.s0.w, H0.w));
-    v[4] = softplus_log2(fmaf(C1.x, r.s1.x, H1.x)); v[5] = softplus_log2(fmaf(C1.y, r.s1.y, H1.y));
-    v[6] = softplus_log2(fmaf(C1.z, r.s1.z, H1.z)); v[7] = softplus_log2(fmaf(C1.w, r.s1.w, H1.w));
-    split8(v, p1, p2, p3);
-    *reinterpret_cast<u32x4*>(base + IMG + p_img) = p1;
-    *reinterpret_cast<u32x4*>(base + IMG + PLANE + p_img) = p2;
-    *reinterpret_cast<u32x4*>(base + IMG + 2 * PLANE + p_img) = p3;
-    if (SIG) {
-      *reinterpret_cast<float4*>(base + 2 * IMG + p_zs) = r.s0;
-      *reinterpret_cast<float4*>(base + 2 * IMG + p_zs + 16) = r.s1;
-    }
-  };
-
-  // ---- data-gradient consumer: lane (row c, k-group kg) of the A fragments; C layout column c of tile `wave`.
-  // Bw: the B fragments of W[:, 32 wave .. + 31] for all 8 k-steps, split once, register-resident.
-  const int dswz = ((c & 3) << 2) | ((c >> 2) & 3);
-  const int d_row = c * 256;
-  float csum = 0.f, csz = 0.f;
-  auto dgrad = [&](const u32x4 (&Bw)[8][3], float ssc, float ssh, int buf, int64_t ps, bool live) {
-    const char* const base = lds + buf * BUF;
-    float old[16];
-    float* const orow = out + (ps * LSLAB + 4 * kg) * 128 + 32 * wave + c;
-    if (ACCUM) {
+    for (int e = 0; e < 8; ++e) bias[e] = 0.f;
+    auto produce = [&](const Raw& r, int buf, int h, bool live) {
+      char* const base = lds + buf * BUF;
+      const int prow = row_of(h);
+      const int pswz = ((prow & 3) << 2) | ((prow >> 2) & 3);
+      const int p_img = prow * 256 + ((pq ^ pswz) << 4);
+      const int p_zs = prow * 512 + pq * 32;
+      const float lv = live ? 1.f : 0.f;      // a slab past the end contributes nothing to dW / db
+      float v[8];
+      v[0] = fmaf(A0.x, r.g0.x, fmaf(Q0.x, r.z0.x, P0.x)) * lv; v[1] = fmaf(A0.y, r.g0.y, fmaf(Q0.y, r.z0.y, P0.y)) * lv;
+      v[2] = fmaf(A0.z, r.g0.z, fmaf(Q0.z, r.z0.z, P0.z)) * lv; v[3] = fmaf(A0.w, r.g0.w, fmaf(Q0.w, r.z0.w, P0.w)) * lv;
+      v[4] = fmaf(A1.x, r.g1.x, fmaf(Q1.x, r.z1.x, P1.x)) * lv; v[5] = fmaf(A1.y, r.g1.y, fmaf(Q1.y, r.z1.y, P1.y)) * lv;
+      v[6] = fmaf(A1.z, r.g1.z, fmaf(Q1.z, r.z1.z, P1.z)) * lv; v[7] = fmaf(A1.w, r.g1.w, fmaf(Q1.w, r.z1.w, P1.w)) * lv;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) old[r] = orow[((r & 3) + 8 * (r >> 2)) * 128];
-    }
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int at = d_row + (((2 * s + kg) ^ dswz) << 4);
-      const u32x4 a1 = *reinterpret_cast<const u32x4*>(base + at);
-      const u32x4 a2 = *reinterpret_cast<const u32x4*>(base + PLANE + at);
-      const u32x4 a3 = *reinterpret_cast<const u32x4*>(base + 2 * PLANE + at);
-      if (s & 1) GANET_SPLIT_PRODUCTS(acc1, a1, a2, a3, Bw[s][0], Bw[s][1], Bw[s][2]);
-      else GANET_SPLIT_PRODUCTS(acc0, a1, a2, a3, Bw[s][0], Bw[s][1], Bw[s][2]);
-    }
-    const float* zs = reinterpret_cast<const float*>(base + 2 * IMG) + (4 * kg) * 128 + 32 * wave + c;
-    if (live) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2);
-        float val = acc0[r] + acc1[r];
-        if (ACCUM) val += old[r];
-        if (SIG) {
-          const float zv = zs[row * 128];
-          val *= sigmoid_log2(fmaf(ssc, zv, ssh));
-          csum += val;
-          csz = fmaf(val, zv, csz);
-        }
-        orow[row * 128] = val;
+      for (int e = 0; e < 8; ++e) bias[e] += v[e];
+      u32x4 p1, p2, p3;
+      split8(v, p1, p2, p3);
+      *reinterpret_cast<u32x4*>(base + p_img) = p1;
+      *reinterpret_cast<u32x4*>(base + PLANE + p_img) = p2;
+      *reinterpret_cast<u32x4*>(base + 2 * PLANE + p_img) = p3;
+      v[0] = softplus_log2(fmaf(C0.x, r.s0.x, H0.x)); v[1] = softplus_log2(fmaf(C0.y, r.s0.y, H0.y));
+      v[2] = softplus_log2(fmaf(C0.z, r.s0.z, H0.z)); v[3] = softplus_log2(fmaf(C0.w, r.s0.w, H0.w));
+      v[4] = softplus_log2(fmaf(C1.x, r.s1.x, H1.x)); v[5] = softplus_log2(fmaf(C1.y, r.s1.y, H1.y));
+      v[6] = softplus_log2(fmaf(C1.z, r.s1.z, H1.z)); v[7] = softplus_log2(fmaf(C1.w, r.s1.w, H1.w));
+      split8(v, p1, p2, p3);
+      *reinterpret_cast<u32x4*>(base + IMG + p_img) = p1;
+      *reinterpret_cast<u32x4*>(base + IMG + PLANE + p_img) = p2;
+      *reinterpret_cast<u32x4*>(base + IMG + 2 * PLANE + p_img) = p3;
+      if (SIG) {
+        *reinterpret_cast<f32x4*>(base + 2 * IMG + p_zs) = r.s0;
+        *reinterpret_cast<f32x4*>(base + 2 * IMG + p_zs + 16) = r.s1;
       }
+    };
+    // two slabs of raw rows in flight: sets (a0, a1) and (b0, b1); the round loop is unrolled by two so that a set is
+    // a fixed group of registers (a loop-carried copy would wait for the loads)
+    Raw a0, a1, b0, b1;
+    load_raw(a0, phys(slab_of(0)), 0); load_raw(a1, phys(slab_of(0)), 1);
+    produce(a0, 0, 0, slab_of(0) < nslab); produce(a1, 0, 1, slab_of(0) < nslab);
+    load_raw(b0, phys(slab_of(1)), 0); load_raw(b1, phys(slab_of(1)), 1);
+    load_raw(a0, phys(slab_of(2)), 0); load_raw(a1, phys(slab_of(2)), 1);
+    __syncthreads();                                     // slab 0 in LDS
+    const int rounds2 = (rounds + 1) & ~1;
+    // The finished output tile comes back from the consumers through LDS (they wrote it over the slab's Z_src image,
+    // each value where its z was): the producer lane that owns those 32 bytes stores them with two 16-byte stores
+    // before it overwrites them with the next slab's Z_src. The consumers issue no global stores: a consumer blocked
+    // at a full store queue stalls the matrix pipe (measured: 3-4 k cycles per round), a producer has slack.
+    auto drain = [&](int r, int h) {                     // output tile of round r (buffer r & 1), row group h
+      if (r < 0 || !(slab_of(r) < nslab && r < rounds)) return;
+      const char* const zs = lds + (r & 1) * BUF + 2 * IMG + row_of(h) * 512 + pq * 32;
+      const float4 o0 = *reinterpret_cast<const float4*>(zs);
+      const float4 o1 = *reinterpret_cast<const float4*>(zs + 16);
+      float* const op = out + (phys(slab_of(r)) * LSLAB + row_of(h)) * 128 + 8 * pq;
+      *reinterpret_cast<float4*>(op) = o0;
+      *reinterpret_cast<float4*>(op + 4) = o1;
+    };
+    // the raw values are consumed from this point on — and not earlier: without the pin the compiler hoists the
+    // prologue arithmetic of all four produce calls of the unrolled body to its top and waits for every load there
+    auto pin = [&](Raw& s) {
+      asm volatile("" : "+v"(s.g0), "+v"(s.g1), "+v"(s.z0), "+v"(s.z1), "+v"(s.s0), "+v"(s.s1) :: "memory");
+    };
+    auto round = [&](Raw& s0, Raw& s1, int r) {          // slab r + 1 -> buffer (r + 1) & 1, then slab r + 3's loads
+      const bool live = slab_of(r + 1) < nslab && r + 1 < rounds;
+      LBWD_STAMP(1, r, 0);
+      drain(r - 1, 0);
+      pin(s0);
+      LBWD_STAMP(1, r, 1);
+      produce(s0, (r + 1) & 1, 0, live);
+      LBWD_STAMP(1, r, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      load_raw(s0, phys(slab_of(r + 3)), 0);
+      __builtin_amdgcn_sched_barrier(0);
+      LBWD_STAMP(1, r, 3);
+      drain(r - 1, 1);
+      pin(s1);
+      produce(s1, (r + 1) & 1, 1, live);
+      __builtin_amdgcn_sched_barrier(0);
+      LBWD_STAMP(1, r, 4);
+      load_raw(s1, phys(slab_of(r + 3)), 1);
+      __builtin_amdgcn_sched_barrier(0);
+      LBWD_STAMP(1, r, 5);
+      __syncthreads();
+      LBWD_STAMP(1, r, 6);
+    };
+    LBWD_STAMP(1, 63, 1);
+    for (int r = 0; r < rounds2; r += 2) {
+      round(b0, b1, r);
+      round(a0, a1, r + 1);
     }
-  };
-
-  // ---- weight-gradient consumer: quadrant (jn, ik) of dW; transposing reads of the dz and a images
-  const int wq = wave & 3, jn = wq >> 1, ik = wq & 1;
-  const int g16 = lane & 15, cc = (lane >> 4) & 1;
-  // byte offset (within a plane) of this lane's source element group for (tile, hi); + ms * 16 rows, + plane
-  auto tr_addr = [&](int tile, int hi) -> int {
-    const int m = 8 * kg + 4 * hi + (g16 >> 2);
-    const int q = 4 * tile + 2 * cc + ((g16 >> 1) & 1);
-    const int sw = ((g16 >> 2) << 2) | (2 * kg + hi);
-    return m * 256 + ((q ^ sw) << 4) + (g16 & 1) * 8;
-  };
-  int ta[2][2], tb[2][2];
+    LBWD_STAMP(1, 63, 2);
+    drain(rounds2 - 1, 0);
+    drain(rounds2 - 1, 1);
+    // db: every lane holds 8 column sums over its rows
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int hi = 0; hi < 2; ++hi) {
-      ta[t][hi] = tr_addr(2 * jn + t, hi);
-      tb[t][hi] = IMG + tr_addr(2 * ik + t, hi);
+    for (int e = 0; e < 8; ++e) {
+      float b = bias[e];
+      b += __shfl_xor(b, 16);
+      b += __shfl_xor(b, 32);
+      if (lane < 16) s_red[pw * 128 + 8 * pq + e] = b;
     }
-  auto wgrad = [&](f32x16 (&wacc)[2][2], int buf) {
-    const char* const base = lds + buf * BUF;
-#pragma unroll
-    for (int ms = 0; ms < 2; ++ms) {
-      u32x4 fa[2][3], fb[2][3];
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          const uint2 alo = read_tr(base + ta[t][0] + ms * 4096 + p * PLANE);
-          const uint2 ahi = read_tr(base + ta[t][1] + ms * 4096 + p * PLANE);
-          fa[t][p] = u32x4{alo.x, alo.y, ahi.x, ahi.y};
-          const uint2 blo = read_tr(base + tb[t][0] + ms * 4096 + p * PLANE);
-          const uint2 bhi = read_tr(base + tb[t][1] + ms * 4096 + p * PLANE);
-          fb[t][p] = u32x4{blo.x, blo.y, bhi.x, bhi.y};
-        }
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-          GANET_SPLIT_PRODUCTS(wacc[a][b], fa[a][0], fa[a][1], fa[a][2], fb[b][0], fb[b][1], fb[b][2]);
-    }
-  };
-
-  // ---- main loop. The two roles run separate loops (so that the register allocator sees either the 96 W-fragment
-  // registers or the 64 weight-gradient accumulators, not both) with the same barrier count.
-  Raw raw;
-  load_raw(raw, phys(slab_of(0)));
-  __syncthreads();                                   // coefficients staged
-  produce(raw, 0, slab_of(0) < nslab);
-  load_raw(raw, phys(slab_of(1)));
-  float* const wout = wpartial + (size_t)blockIdx.x * LTILE;
-  if (dwave) {
+  } else {
+    // ---- consumer
     u32x4 Bw[8][3];
     {
       const float* wp = W + (size_t)(8 * kg) * ldw + 32 * wave + c;
@@ -257,21 +248,119 @@ layer_bwd_kernel(int64_t M, const float* __restrict__ g, const float* __restrict
     }
     const float ssc = SIG ? src_scale[32 * wave + c] * kLog2e : 0.f;
     const float ssh = SIG ? src_shift[32 * wave + c] * kLog2e : 0.f;
-    __syncthreads();
-    for (int r = 0; r < rounds; ++r) {
-      const int buf = r & 1;
-      const bool live_next = slab_of(r + 1) < nslab && r + 1 < rounds;
-      if (GANET_LBWD_ORDER) {
-        produce(raw, buf ^ 1, live_next);
-        load_raw(raw, phys(slab_of(r + 2)));
-        dgrad(Bw, ssc, ssh, buf, phys(slab_of(r)), slab_of(r) < nslab);
-      } else {
-        dgrad(Bw, ssc, ssh, buf, phys(slab_of(r)), slab_of(r) < nslab);
-        produce(raw, buf ^ 1, live_next);
-        load_raw(raw, phys(slab_of(r + 2)));
+    const int dswz = ((c & 3) << 2) | ((c >> 2) & 3);
+    const int d_row = c * 256;
+    float csum = 0.f, csz = 0.f;
+    const int jn = wave >> 1, ik = wave & 1;
+    const int g16 = lane & 15, cc = (lane >> 4) & 1;
+    auto tr_addr = [&](int tile, int hi) -> int {
+      const int m = 8 * kg + 4 * hi + (g16 >> 2);
+      const int q = 4 * tile + 2 * cc + ((g16 >> 1) & 1);
+      const int sw = ((g16 >> 2) << 2) | (2 * kg + hi);
+      return m * 256 + ((q ^ sw) << 4) + (g16 & 1) * 8;
+    };
+    // one base address per image; the other tile of the pair flips chunk bit 2 (^ 64 bytes), the upper four rows of
+    // a k-group flip chunk bit 0 and lie 4 rows on (^ 16, + 1024): see tr_addr
+    const int ta0 = tr_addr(2 * jn, 0), tb0 = IMG + tr_addr(2 * ik, 0);
+    f32x16 wacc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wacc[a][b][r] = 0.f;
+    __syncthreads();                                     // coefficients staged (producers' barrier)
+    __syncthreads();                                     // slab 0 in LDS
+    const int rounds2 = (rounds + 1) & ~1;
+    LBWD_STAMP(0, 63, 1);
+    for (int r = 0; r < rounds2; ++r) {
+      const char* const base = lds + (r & 1) * BUF;
+      const int64_t ps = phys(slab_of(r));
+      const bool live = slab_of(r) < nslab && r < rounds;
+      LBWD_STAMP(0, r, 0);
+      float old[16];
+      // uniform base (scalar registers) + a 32-bit lane offset: no 64-bit per-lane pointer to keep (or spill: a
+      // reload is a VMEM operation, and waiting for it waits for the previous round's stores as well)
+      float* const obase = out + ps * (LSLAB * 128) + 32 * wave;
+      const int olane = (4 * kg) * 128 + c;
+      if (ACCUM) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) old[q] = obase[olane + ((q & 3) + 8 * (q >> 2)) * 128];
       }
+      // data gradient of this wave's 32 output columns, then the weight-gradient quadrant: 12 groups of MFMAs, the
+      // LDS reads of a group issued BEFORE the MFMAs of the previous one (fences: the compiler otherwise sinks every
+      // read to its use and the consumer — alone on its SIMD's matrix pipe — waits out each LDS round trip)
+      f32x16 acc;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+      auto read_a = [&](int s, u32x4 (&f)[3]) {
+        const int at = d_row + (((2 * s + kg) ^ dswz) << 4);
+        f[0] = *reinterpret_cast<const u32x4*>(base + at);
+        f[1] = *reinterpret_cast<const u32x4*>(base + PLANE + at);
+        f[2] = *reinterpret_cast<const u32x4*>(base + 2 * PLANE + at);
+      };
+      auto read_frag = [&](int adr0, int t, int ms, u32x4 (&f)[3]) {
+        const int lo_at = adr0 ^ (t * 64);
+        const int hi_at = (lo_at ^ 16) + 1024;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const uint2 lo = read_tr(base + lo_at + ms * 4096 + p * PLANE);
+          const uint2 hi = read_tr(base + hi_at + ms * 4096 + p * PLANE);
+          f[p] = u32x4{lo.x, lo.y, hi.x, hi.y};
+        }
+      };
+      u32x4 fcur[3], fnxt[3], fb[2][3];
+      read_a(0, fcur);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        if (s < 7) read_a(s + 1, fnxt);
+        else { read_frag(tb0, 0, 0, fb[0]); read_frag(tb0, 1, 0, fb[1]); read_frag(ta0, 0, 0, fnxt); }
+        __builtin_amdgcn_sched_barrier(0);
+        GANET_SPLIT_PRODUCTS(acc, fcur[0], fcur[1], fcur[2], Bw[s][0], Bw[s][1], Bw[s][2]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) fcur[p] = fnxt[p];
+      }
+      LBWD_STAMP(0, r, 1);
+      // weight-gradient quadrant: groups (ms, a); fcur = A fragments of the group, fb = the step's two B tiles
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int ms = gq >> 1, a = gq & 1;
+        if (gq == 0 || gq == 2) read_frag(ta0, 1, ms, fnxt);
+        else if (gq == 1) read_frag(ta0, 0, 1, fnxt);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          GANET_SPLIT_PRODUCTS(wacc[a][b], fcur[0], fcur[1], fcur[2], fb[b][0], fb[b][1], fb[b][2]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) fcur[p] = fnxt[p];
+        // the second row step's B tiles replace the first's (no registers for both: this read is waited for)
+        if (gq == 1) { read_frag(tb0, 0, 1, fb[0]); read_frag(tb0, 1, 1, fb[1]); }
+      }
+      LBWD_STAMP(0, r, 2);
+      // epilogue of the output tile: the result replaces z in the slab's Z_src image (the producers store it)
+      float* zs = reinterpret_cast<float*>(lds + (r & 1) * BUF + 2 * IMG) + (4 * kg) * 128 + 32 * wave + c;
+      if (live) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = (q & 3) + 8 * (q >> 2);
+          float val = acc[q];
+          if (ACCUM) val += old[q];
+          if (SIG) {
+            const float zv = zs[row * 128];
+            val *= sigmoid_log2(fmaf(ssc, zv, ssh));
+            csum += val;
+            csz = fmaf(val, zv, csz);
+          }
+          zs[row * 128] = val;
+        }
+      }
+      LBWD_STAMP(0, r, 3);
       __syncthreads();
+      LBWD_STAMP(0, r, 4);
     }
+    LBWD_STAMP(0, 63, 2);
     if (SIG) {       // column sums of G_src and G_src z_src: one wave owns a column tile
       const float s = csum + __shfl_xor(csum, 32);
       const float q = csz + __shfl_xor(csz, 32);
@@ -280,50 +369,19 @@ layer_bwd_kernel(int64_t M, const float* __restrict__ g, const float* __restrict
         col_part[(size_t)blockIdx.x * 256 + 128 + 32 * wave + c] = q;
       }
     }
-  } else {
-    f32x16 wacc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) wacc[a][b][r] = 0.f;
-    __syncthreads();
-    for (int r = 0; r < rounds; ++r) {
-      const int buf = r & 1;
-      const bool live_next = slab_of(r + 1) < nslab && r + 1 < rounds;
-      wgrad(wacc, buf);
-      produce(raw, buf ^ 1, live_next);
-      load_raw(raw, phys(slab_of(r + 2)));
-      __syncthreads();
-    }
-    // dW quadrant straight from the accumulators (one wave owns a quadrant)
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int n = (2 * jn + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-          wout[n * 128 + (2 * ik + b) * 32 + c] = wacc[a][b][r] * kLn2;     // a was in log2 units
+        for (int q = 0; q < 16; ++q) {
+          const int n = (2 * jn + a) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kg;
+          wout[n * 128 + (2 * ik + b) * 32 + c] = wacc[a][b][q] * kLn2;     // a was in log2 units
         }
   }
-  // db: every lane holds 8 column sums over its rows
-  float* const s_red = reinterpret_cast<float*>(lds);        // [8 waves][128]; the slab buffers are dead
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    float b = bias[e];
-    b += __shfl_xor(b, 16);
-    b += __shfl_xor(b, 32);
-    if (lane < 16) s_red[wave * 128 + 8 * pq + e] = b;
-  }
   __syncthreads();
-  for (int n = threadIdx.x; n < 128; n += LWG) {
-    float b = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) b += s_red[w * 128 + n];
-    wout[128 * 128 + n] = b;
-  }
+  for (int n = threadIdx.x; n < 128; n += LWG) wout[128 * 128 + n] = (s_red[n] + s_red[128 + n]) + (s_red[256 + n] + s_red[384 + n]);
+  LBWD_STAMP(0, 63, 3); LBWD_STAMP(1, 63, 3);
 }
 
 }  // namespace
@@ -334,6 +392,9 @@ using namespace ganet;
 
 extern "C" {
 
+#ifdef GANET_LBWD_TRACE
+int ganet_dev_lbwd_trace(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lbwd_trace), sizeof(g_lbwd_trace)); }
+#endif
 int32_t ganet_mlp_bwd_fused_parts(void) { return LBLOCKS; }
 
 size_t ganet_mlp_bwd_fused_workspace(void) { return (size_t)LBLOCKS * LTILE * sizeof(float); }
@@ -369,13 +430,13 @@ int ganet_mlp_bwd_fused(int64_t M, const float* g, const float* gz, const float*
   do {                                                                                                          \
     static bool attr_set = false;                                                                               \
     if (!attr_set) {                                                                                            \
-      if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_bwd_kernel<AC, SG>),                \
+      if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_bwd_spec_kernel<AC, SG>),                \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES),            \
                     "hipFuncSetAttribute")) return 3;                                                           \
       attr_set = true;                                                                                          \
     }                                                                                                           \
     ProfScope prof_(K_LAYER_BWD, stream);                                                                       \
-    hipLaunchKernelGGL((layer_bwd_kernel<AC, SG>), dim3(blocks), dim3(LWG), LDS_BYTES, stream, M, g, gz, gcoef, \
+    hipLaunchKernelGGL((layer_bwd_spec_kernel<AC, SG>), dim3(blocks), dim3(LWG), LDS_BYTES, stream, M, g, gz, gcoef, \
                        W, ldw, out, src_z, src_scale, src_shift, col_part, wp, reverse);                        \
     return check_hip(hipGetLastError(), "layer_bwd_kernel");                                                    \
   } while (0)
