@@ -279,6 +279,9 @@ def main():
                     help="stage-1 data parallelism (gaussianavatar_amd/parallel.py): frames = every rank evaluates the "
                          "batch-invariant decoder (default for weak scaling); texels = the decoder is sharded by UV "
                          "texels (default with --global-batch: fixed total work)")
+    ap.add_argument("--series", type=int, default=0,
+                    help="also report iters/s per window of this many timed steps (HIP events on the loop's stream: "
+                         "sustained vs burst rate) under config.series")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket rasterizer kernels with HIP events in the timed region")
@@ -393,7 +396,12 @@ def main():
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    marks = []
     for i in range(args.steps):
+        if args.series and i % args.series == 0:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append(ev)
         sample = dom_lib is not None and i % every == 0
         if sample:
             dom_lib.profile_enable([dom_family])
@@ -405,6 +413,9 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     elapsed = parallel.max_over_ranks(elapsed, dev)
+    series = None
+    if args.series and len(marks) > 1:
+        series = [round(args.series / (a.elapsed_time(b) * 1e-3), 2) for a, b in zip(marks, marks[1:])]
     timed = dom_lib.profile_read(reset=True) if dom_lib is not None else {}
     rasterizer.profile_enable(False)
     fused.profile_enable(False)
@@ -437,6 +448,7 @@ def main():
                                    f"frame-sharded dp{world}, one all-reduce of [N,7] output grads"
                                    + ("" if args.stage == 1 else ", synchronised BatchNorm, parameter gradients averaged")),
                    "mean_tile_pairs_per_frame": mean_pairs, "final_loss": final_loss,
+                   **({"series": {"window_steps": args.series, "iters_per_s": series}} if series else {}),
                    "decoder_gemm_arithmetic": (
                        "fp32 in / fp32 out; operands split exactly into three bf16 pieces, six bf16 MFMA products per "
                        "fp32 product accumulated in fp32 (csrc/ganet_split.h; error vs float64 <= that of the "

@@ -147,6 +147,8 @@ GANET_SYMBOLS = ["ganet_linear_wgrad_workspace", "ganet_linear_wgrad", "ganet_bn
                  "ganet_wgrad_act_workspace", "ganet_wgrad_act", "ganet_wgrad_reduce_batch", "ganet_adam_step", "ganet_mlp_bwd_data_parts",
                  "ganet_mlp_head_bwd_parts", "ganet_mlp_bwd_data", "ganet_mlp_head_bwd", "ganet_mlp_bwd_stats",
                  "ganet_mlp_bwd_fused_parts", "ganet_mlp_bwd_fused_workspace", "ganet_mlp_bwd_fused",
+                 "ganet_decoder_saved_floats", "ganet_decoder_fwd_workspace", "ganet_decoder_fwd",
+                 "ganet_decoder_bwd_workspace", "ganet_decoder_bwd",
                  "ganet_decode_pack_fwd", "ganet_decode_pack_bwd", "ganet_mean_sq_fwd", "ganet_mean_sq_bwd", "ganet_weighted_sum_fwd", "ganet_weighted_sum_bwd", "ganet_upsample_cat_fwd", "ganet_upsample_cat_bwd", "ganet_profile_enable", "ganet_profile_count", "ganet_profile_read", "ganet_profile_kernel_name",
                  "ganet_conv5_packed_bytes", "ganet_conv5_pack", "ganet_conv5_apply",
                  "ganet_conv5_wgrad_workspace", "ganet_conv5_wgrad", "ganet_get_mfma_mode", "ganet_set_mfma_mode", "ganet_last_error", "ganet_abi_version"]
@@ -156,6 +158,25 @@ class GanetWgradJob(ctypes.Structure):
     """include/ganet.h GanetWgradJob"""
     _fields_ = [("workspace", ctypes.c_void_p), ("M", ctypes.c_int64), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
                 ("dW", ctypes.c_void_p), ("db", ctypes.c_void_p), ("nblocks", ctypes.c_int32)]
+
+
+GANET_DEC_LAYERS = 11
+
+
+class GanetDecoderParams(ctypes.Structure):
+    """include/ganet.h GanetDecoderParams"""
+    _L = GANET_DEC_LAYERS
+    _fields_ = [("cin", c_int32), ("W", c_void_p * _L), ("bias", c_void_p * _L), ("gamma", c_void_p * _L),
+                ("beta", c_void_p * _L), ("running_mean", c_void_p * _L), ("running_var", c_void_p * _L),
+                ("num_batches_tracked", c_void_p * _L), ("eps", c_float * _L), ("momentum", c_float * _L),
+                ("W8", c_void_p * 3), ("b8", c_void_p * 3), ("n8", c_int32 * 3)]
+
+
+class GanetDecoderGrads(ctypes.Structure):
+    """include/ganet.h GanetDecoderGrads"""
+    _L = GANET_DEC_LAYERS
+    _fields_ = [("dW", c_void_p * _L), ("db", c_void_p * _L), ("dgamma", c_void_p * _L), ("dbeta", c_void_p * _L),
+                ("dW8", c_void_p * 3), ("db8", c_void_p * 3), ("dx", c_void_p), ("x_cols", c_int32)]
 
 
 class GanetAdamTensor(ctypes.Structure):
@@ -207,6 +228,15 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_mlp_bwd_fused.restype = c_int
         lib.ganet_mlp_bwd_fused.argtypes = [c_int64, P, P, P, P, c_int64, P, c_int32, P, P, P, c_int32, P, P, c_size_t,
                                             c_int32, P]
+        lib.ganet_decoder_saved_floats.restype = c_size_t
+        lib.ganet_decoder_saved_floats.argtypes = [c_int64]
+        lib.ganet_decoder_fwd_workspace.restype = c_size_t
+        lib.ganet_decoder_fwd.restype = c_int
+        lib.ganet_decoder_fwd.argtypes = [c_int64, P, P, P, P, P, c_size_t, P]
+        lib.ganet_decoder_bwd_workspace.restype = c_size_t
+        lib.ganet_decoder_bwd_workspace.argtypes = [c_int64]
+        lib.ganet_decoder_bwd.restype = c_int
+        lib.ganet_decoder_bwd.argtypes = [c_int64, P, P, P, P, P, P, c_size_t, P, P]
         lib.ganet_mlp_head_bwd.restype = c_int
         lib.ganet_mlp_head_bwd.argtypes = [c_int64, c_int32, P, P, P, c_int64, P, P, P, c_int64, P, P, P]
         lib.ganet_mlp_bwd_stats.restype = c_int

@@ -528,6 +528,44 @@ def _mlp_fwd(lib, M, N, x1, x2, scale, shift, W, bias, col_part, dev, row_order=
     return z
 
 
+# The whole decoder as one native call each way (csrc/ganet_decoder.hip: the same launch sequence as _DecoderFn below,
+# issued from C). Training mode, single-rank BatchNorm statistics, row count a multiple of 32; everything else — and the
+# tests that compare the two — takes the per-layer path. (Tests switch it off to exercise the per-layer path.)
+_NATIVE_DECODER = True
+
+
+def _native_decoder_ok(dec, M, sync) -> bool:
+    if not (_NATIVE_DECODER and _FUSED_BWD and dec.training and not sync and M % 32 == 0):
+        return False
+    tracks = [getattr(dec, bn).track_running_stats for _, bn in _decoder_bn_layers()]
+    return all(tracks) or not any(tracks)
+
+
+def _native_decoder_params(dec, params, nl):
+    """GanetDecoderParams for the module's current tensors (and the tensors it points at, to keep them alive)."""
+    from ._native import GanetDecoderParams
+    P = GanetDecoderParams()
+    P.cin = dec.in_size
+    layers = _decoder_bn_layers()
+    keep = []
+    for i, (_, bn_name) in enumerate(layers):
+        bn = getattr(dec, bn_name)
+        w, b, ga, be = (params[4 * i + k] for k in range(4))
+        w = w if w.is_contiguous() else w.contiguous()
+        keep += [w, b, ga, be]
+        P.W[i], P.bias[i], P.gamma[i], P.beta[i] = w.data_ptr(), b.data_ptr(), ga.data_ptr(), be.data_ptr()
+        if bn.track_running_stats:
+            P.running_mean[i], P.running_var[i] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            P.num_batches_tracked[i] = bn.num_batches_tracked.data_ptr()
+        P.eps[i], P.momentum[i] = float(bn.eps), float(bn.momentum)
+    for j in range(3):
+        w, b = params[4 * nl + 2 * j], params[4 * nl + 2 * j + 1]
+        w = w if w.is_contiguous() else w.contiguous()
+        keep += [w, b]
+        P.W8[j], P.b8[j], P.n8[j] = w.data_ptr(), b.data_ptr(), w.shape[0]
+    return P, keep
+
+
 class _DecoderFn(torch.autograd.Function):
     """(x [M,in], flat parameter list) -> (residual [M,3], scale logits [M,1], colour logits [M,3]).
     Parameter order: for every (conv, bn) of _decoder_bn_layers(): conv.weight, conv.bias,
@@ -559,6 +597,19 @@ class _DecoderFn(torch.autograd.Function):
             xp = torch.zeros((M, _K1_PAD), dtype=torch.float32, device=dev)
             xp[:, :cin] = x
         ctx.x_cols = x.shape[1]
+        ctx.native = _native_decoder_ok(dec, M, sync)
+        if ctx.native:
+            P, keep = _native_decoder_params(dec, params, nl)
+            saved = torch.empty(lib.ganet_decoder_saved_floats(M), dtype=torch.float32, device=dev)
+            outs = [torch.empty((M, P.n8[j]), dtype=torch.float32, device=dev) for j in range(3)]
+            wsb = lib.ganet_decoder_fwd_workspace()
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            optrs = (ctypes.c_void_p * 3)(*[o.data_ptr() for o in outs])
+            _native.ganet_check(lib.ganet_decoder_fwd(M, _ptr(xp), ctypes.byref(P), _ptr(saved), optrs, _ptr(ws), wsb,
+                                                      _stream(dev)))
+            ctx.dec, ctx.cin, ctx.nl = dec, cin, nl
+            ctx.save_for_backward(xp, saved, *params)
+            return tuple(outs)
         pad_w = lambda w: torch.cat([w, w.new_zeros(w.shape[0], _K1_PAD - cin)], 1).contiguous()
         col_part = torch.empty(lib.ganet_mlp_stats_floats(128), dtype=torch.float32, device=dev) if training else None
 
@@ -630,6 +681,11 @@ class _DecoderFn(torch.autograd.Function):
         lib = _native.ganet()
         nl, cin = ctx.nl, ctx.cin
         sv = ctx.saved_tensors
+        if ctx.native and all(d is not None for d in d_outs):
+            return _DecoderFn._backward_native(ctx, lib, sv, d_outs)
+        if ctx.native:
+            raise RuntimeError("fused decoder: every head needs a gradient on the one-call path "
+                               "(set fused._NATIVE_DECODER = False for partial objectives)")
         xp = sv[0]
         zs = sv[1:1 + nl]
         fs = sv[1 + nl:1 + 5 * nl]
@@ -811,6 +867,45 @@ class _DecoderFn(torch.autograd.Function):
         for j in range(3):
             grads += [g_out_w[j], g_out_b[j]]
         return (dx, None, None) + tuple(grads)
+
+
+def _decoder_bwd_native(ctx, lib, sv, d_outs):
+    from ._native import GanetDecoderGrads
+    nl, cin, dec = ctx.nl, ctx.cin, ctx.dec
+    xp, saved, params = sv[0], sv[1], sv[2:]
+    dev, M = xp.device, xp.shape[0]
+    P, keep = _native_decoder_params(dec, params, nl)
+    # every parameter gradient is a view of ONE buffer (a single allocation instead of ~50)
+    shapes = [tuple(p.shape) for p in params]
+    sizes = [(p.numel() + 3) // 4 * 4 for p in params]            # 16-byte aligned pieces
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+    views, off = [], 0
+    for shp, n, p in zip(shapes, sizes, params):
+        views.append(flat[off:off + p.numel()].view(shp))
+        off += n
+    G = GanetDecoderGrads()
+    for i in range(nl):
+        G.dW[i], G.db[i], G.dgamma[i], G.dbeta[i] = (views[4 * i + k].data_ptr() for k in range(4))
+    for j in range(3):
+        G.dW8[j], G.db8[j] = views[4 * nl + 2 * j].data_ptr(), views[4 * nl + 2 * j + 1].data_ptr()
+    dx = None
+    if ctx.needs_input_grad[0]:
+        # [M, x_cols]: the pad columns of a zero-padded input belong to a constant and stay unwritten
+        dx = torch.empty((M, ctx.x_cols), dtype=torch.float32, device=dev)
+        G.dx, G.x_cols = dx.data_ptr(), ctx.x_cols
+    douts = [d.contiguous() for d in d_outs]
+    dptrs = (ctypes.c_void_p * 3)(*[d.data_ptr() for d in douts])
+    wsb = lib.ganet_decoder_bwd_workspace(M)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    side = _side_stream(dev) if (_WGRAD_STREAM and not _profiling) else None
+    # (the side stream's launches are ordered against the main stream inside the call, events both ways: every buffer is
+    # free again in main-stream order, no record_stream needed — it would only delay the reuse of the workspace)
+    _native.ganet_check(lib.ganet_decoder_bwd(M, _ptr(xp), ctypes.byref(P), _ptr(saved), dptrs, ctypes.byref(G), _ptr(ws),
+                                              wsb, _stream(dev), None if side is None else ctypes.c_void_p(side.cuda_stream)))
+    return (dx, None, None) + tuple(views)
+
+
+_DecoderFn._backward_native = staticmethod(_decoder_bwd_native)
 
 
 def _allreduce_partials(col_part: torch.Tensor, width: int) -> None:

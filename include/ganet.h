@@ -180,6 +180,53 @@ int ganet_mlp_bwd_stats(int64_t M, int32_t nparts, const float* col_part, const 
                         const float* rstd, const float* scale, float* coef, float* dgamma,
                         float* dbeta, void* stream);
 
+/* ---- the whole decoder MLP as ONE call each way (ganet_decoder.hip): the fixed launch sequence of the layer kernels
+ * above for the reference's ShapeDecoder (/root/reference/model/modules.py:508-582; forward :554-582) in training mode —
+ * what gaussianavatar_amd/fused.py::_DecoderFn otherwise issues one call at a time from Python (~70 calls per
+ * iteration). Layer order: 0..4 = conv1..conv5 (conv5 = [x | act(conv4)]), then per head h = 0, 1, 2 (residual, scale,
+ * colour): 5 + 2h = conv6*, 6 + 2h = conv7*; W8/b8 = conv8* ([n8,128], n8 <= 4). All pointers device memory; weights in
+ * nn.Conv1d layout ([out, in] contiguous). x: [M,72] (the cin input columns, zero padded). running_mean /
+ * running_var / num_batches_tracked NULL = statistics not tracked; they are updated like
+ * F.batch_norm(training=True). saved (ganet_decoder_saved_floats(M) floats) keeps every layer's pre-activation and
+ * BatchNorm statistics for the backward pass. out[h]: [M, n8[h]] logits. */
+#define GANET_DEC_LAYERS 11
+typedef struct GanetDecoderParams {
+  int32_t cin;
+  const float* W[GANET_DEC_LAYERS];
+  const float* bias[GANET_DEC_LAYERS];
+  const float* gamma[GANET_DEC_LAYERS];
+  const float* beta[GANET_DEC_LAYERS];
+  float* running_mean[GANET_DEC_LAYERS];
+  float* running_var[GANET_DEC_LAYERS];
+  int64_t* num_batches_tracked[GANET_DEC_LAYERS];
+  float eps[GANET_DEC_LAYERS];
+  float momentum[GANET_DEC_LAYERS];
+  const float* W8[3];
+  const float* b8[3];
+  int32_t n8[3];
+} GanetDecoderParams;
+typedef struct GanetDecoderGrads {
+  float* dW[GANET_DEC_LAYERS];      /* laid out like W */
+  float* db[GANET_DEC_LAYERS];
+  float* dgamma[GANET_DEC_LAYERS];
+  float* dbeta[GANET_DEC_LAYERS];
+  float* dW8[3];
+  float* db8[3];
+  float* dx;                        /* [M, x_cols] (columns >= cin stay unwritten) or NULL */
+  int32_t x_cols;
+} GanetDecoderGrads;
+size_t ganet_decoder_saved_floats(int64_t M);
+size_t ganet_decoder_fwd_workspace(void);
+int ganet_decoder_fwd(int64_t M, const float* x, const GanetDecoderParams* params, float* saved, float* const* out,
+                      void* workspace, size_t workspace_bytes, void* stream);
+/* Backward: d_out[h] [M, n8[h]] (all three required), M a multiple of 32. side_stream (may be NULL): a second stream
+ * for the weight-gradient launches that are off the dependency chain; the call orders it against `stream` with events
+ * on both sides, so the caller only has to keep the buffers alive in `stream` order. */
+size_t ganet_decoder_bwd_workspace(int64_t M);
+int ganet_decoder_bwd(int64_t M, const float* x, const GanetDecoderParams* params, const float* saved,
+                      const float* const* d_out, const GanetDecoderGrads* grads, void* workspace,
+                      size_t workspace_bytes, void* stream, void* side_stream);
+
 /* ---- decoder heads -> per-Gaussian records (ganet_pack.hip) ----------------------------------------
  * One kernel for pred_res * res_scale, the two sigmoid heads (x scale_mult for the scale warm-up), the
  * gather of the N valid texels (valid_index [N], int64, texel index in [0,HW)) and the two regulariser

@@ -248,17 +248,20 @@ def test_wgrad_act_matches_torch(M, N, K, act, row_order):
     assert float((db.double() - rb).abs().max()) <= 2e-5 * float(rb.abs().max()) + 1e-4
 
 
-@pytest.mark.parametrize("M,one_pass", [(20000, False), (4099, False), (20000 // 32 * 32, True)])
-def test_fused_decoder_equals_per_layer_formulation(M, one_pass, monkeypatch):
+@pytest.mark.parametrize("M,one_pass,native", [(20000, False, False), (4099, False, False), (20000 // 32 * 32, True, False),
+                                               (20000 // 32 * 32, True, True), (262144, True, True)])
+def test_fused_decoder_equals_per_layer_formulation(M, one_pass, native, monkeypatch):
     """The whole-decoder function on the fused layer kernels (reference widths: 66 -> 128 x 5 -> three
     heads) against the per-layer formulation (vendor GEMM + fused BN kernels) on the same device:
     outputs, every parameter gradient, the input gradient and the BatchNorm running statistics.
     one_pass: the single-pass hidden-layer backward (ganet_mlp_bwd_fused, the default when M % 32 == 0) vs the
-    separate weight- / data-gradient kernels."""
+    separate weight- / data-gradient kernels. native: the whole decoder as one C call each way
+    (csrc/ganet_decoder.hip) vs the same launches issued one by one from Python."""
     import copy
     from gaussianavatar_amd import fused
     from gaussianavatar_amd.network import ShapeDecoder
     monkeypatch.setattr(fused, "_FUSED_BWD", one_pass)
+    monkeypatch.setattr(fused, "_NATIVE_DECODER", native)
     torch.manual_seed(1)
     dec_a = ShapeDecoder(66, 128).cuda().train()
     with torch.no_grad():
@@ -290,6 +293,7 @@ def test_fused_decoder_equals_per_layer_formulation(M, one_pass, monkeypatch):
     with torch.no_grad():
         monkeypatch.undo()
         monkeypatch.setattr(fused, "_FUSED_BWD", one_pass)
+        monkeypatch.setattr(fused, "_NATIVE_DECODER", native)
         assert fused.decoder_supported(dec_a, x_a.detach())
         e_a = dec_a.forward_points(x_a.detach())
         monkeypatch.setattr(fused, "decoder_supported", lambda dec, x: False)
