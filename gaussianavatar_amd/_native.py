@@ -43,8 +43,8 @@ class GsrBatch(ctypes.Structure):
 
 _LAYOUT_FIELDS = ["total_bytes", "depth", "xy", "conic_opacity", "rgb", "cov3d", "rect",
                   "tiles_touched", "clamped", "tile_count", "tile_offset", "tile_cursor",
-                  "pair_key", "point_list", "pair_tmp", "final_T", "n_contrib", "grad_acc", "status",
-                  "seg_counters", "xyext", "seg_entries", "seg_ckpt", "seg_info", "pix_accum"]
+                  "pair_key", "point_list", "pair_tmp", "final_T", "n_contrib", "grad_acc", "status", "seg_heads",
+                  "seg_count", "xyext", "seg_entries", "seg_ckpt", "seg_info", "pix_accum", "pair_grad", "seg_list"]
 
 
 class GsrLayout(ctypes.Structure):
@@ -110,7 +110,7 @@ def gsr() -> ctypes.CDLL:
         lib.gsr_profile_read.argtypes = [P, P, c_int]
         lib.gsr_profile_kernel_name.restype = c_char_p
         lib.gsr_profile_kernel_name.argtypes = [c_int]
-        if lib.gsr_abi_version() != 3:
+        if lib.gsr_abi_version() != 4:
             raise RuntimeError("libgsr_hip.so ABI version mismatch; rebuild")
         _gsr = lib
     return _gsr

@@ -81,12 +81,15 @@ int compute_layout(int P, int W, int H, int64_t max_pairs, GsrLayout* out) {
   out->n_contrib = take(npix * 4);
   out->grad_acc = take(Pn * GSR_GRAD_STRIDE * 4);
   out->status = take(8 * 4);
-  out->seg_counters = take(GSR_SEG_COUNTERS * GSR_SEG_COUNTER_STRIDE * 4);     // directly behind status: one clear
+  out->seg_heads = take(8 * 64 * 4);            // directly behind status: one clear
+  out->seg_count = take((uint64_t)d.T * GSR_SEG_BLOCKS * 4);
   out->xyext = take(Pn * 16);
   out->seg_entries = take((uint64_t)d.seg_cap * GSR_WAVE * 8);
   out->seg_ckpt = take((uint64_t)d.seg_cap * GSR_SEG_PIX * 16);
   out->seg_info = take((uint64_t)d.seg_cap * 8);
   out->pix_accum = take(npix * 16);
+  out->pair_grad = take(cap * GSR_PAIR_GRAD * 4);
+  out->seg_list = take(8 * (uint64_t)d.seg_cap * 4);
   out->total_bytes = off;
   return 0;
 }
@@ -112,12 +115,15 @@ Workspace resolve(void* base, const GsrLayout& L) {
   w.n_contrib = reinterpret_cast<uint32_t*>(b + L.n_contrib);
   w.grad_acc = reinterpret_cast<float*>(b + L.grad_acc);
   w.status = reinterpret_cast<int32_t*>(b + L.status);
-  w.seg_counters = reinterpret_cast<int32_t*>(b + L.seg_counters);
+  w.seg_heads = reinterpret_cast<int32_t*>(b + L.seg_heads);
+  w.seg_count = reinterpret_cast<uint32_t*>(b + L.seg_count);
   w.xyext = reinterpret_cast<float4*>(b + L.xyext);
   w.seg_entries = reinterpret_cast<uint2*>(b + L.seg_entries);
   w.seg_ckpt = reinterpret_cast<float4*>(b + L.seg_ckpt);
   w.seg_info = reinterpret_cast<uint2*>(b + L.seg_info);
   w.pix_accum = reinterpret_cast<float4*>(b + L.pix_accum);
+  w.pair_grad = reinterpret_cast<float*>(b + L.pair_grad);
+  w.seg_list = reinterpret_cast<uint32_t*>(b + L.seg_list);
   return w;
 }
 
@@ -294,7 +300,7 @@ int gsr_forward_batch(const GsrSettings* s, const GsrBatch* batch, int32_t P, co
   // tile_count .. tile_cursor are contiguous in the layout: one launch clears the histogram and the
   // status words of every frame
   if ((rc = check_hip(clear_frames(workspace, bt.ws_stride, bt.frames, stream, ws.tile_count,
-                                   L.tile_cursor - L.tile_count, ws.status, (size_t)(L.xyext - L.status)),
+                                   L.tile_cursor - L.tile_count, ws.status, (size_t)(L.seg_count - L.status)),
                       "clear tile_count/status")))
     return rc;
   if ((rc = check_hip(launch_preprocess(*s, d, means3D, colors_precomp, opacities, scales,

@@ -10,7 +10,8 @@
 //                                     through HBM for lists that do not fit) -> point_list
 //   K5 render_fwd      per 4x4 block: cull the tile list, blend 64 survivors at a time (entry-parallel,
 //                                     DPP wave scans); records the consumed segments
-//   K6 render_bwd      per segment  : forward-order gradients, per-entry sums in registers
+//   K6 render_bwd      per tile     : the tile's recorded segments, forward-order gradients summed per list entry in
+//                                     LDS, one atomic record per (tile, Gaussian) pair
 //   K7 preprocess_bwd  per Gaussian : screen-space grads -> means3D / scales / rotations
 //
 // Behavioural spec: SURVEY.md Appendix A (the reference's rasterizer is the un-vendored
@@ -32,10 +33,8 @@
 #ifndef GSR_BWD_BLOCKS
 #define GSR_BWD_BLOCKS 2048                  // persistent workgroups of render_bwd (256 CUs x 8)
 #endif
-#define GSR_SEG_COUNTERS 64                  // segment slots are handed out by 64 counters on separate 256-byte
-                                             // lines: 20k returning atomics on ONE address serialise at ~9-11 ns
-                                             // each (measured 200 us per frame), on one LINE barely better
-#define GSR_SEG_COUNTER_STRIDE 64            // int32 words between counters
+#define GSR_SEG_BLOCKS 16                    // 4x4 pixel blocks of a tile
+#define GSR_PAIR_GRAD 9                      // floats of a per-pair gradient record (dxy2, dconic3, dopac1, drgb3)
 
 namespace gsr {
 
@@ -45,14 +44,16 @@ struct Dims {
   int seg_cap;        // capacity of the forward pass's segment records (see seg_capacity)
 };
 
-// Segment slots (64 survivors of one 4x4 block each) the forward pass may record. The exact bound is
-// 16*D/64 (every list entry surviving in all 16 blocks) plus a partial segment per block; sized for ~4
-// surviving blocks per (tile, Gaussian) pair on average (avatar scenes measure 1.5-2.5); running out is
-// reported through status[1] like a pair-buffer overflow.
+// Segment slots (64 survivors of one 4x4 block each) the forward pass may record. A block of a tile with n list
+// entries records at most ceil(n / 64) segments; the 16 blocks of tile t (list [o, o + n)) own the slots
+//   16 (o / 64 + t) + b c + s,   c = (o + n) / 64 - o / 64 + 1 >= ceil(n / 64)     (integer divisions)
+// — disjoint between tiles, no counters, no overflow: sum over tiles <= 16 (D / 64 + T).
 inline int seg_capacity(int T, int64_t max_pairs) {
-  const int64_t c = max_pairs / 16 + 16 * (int64_t)T;
+  const int64_t c = max_pairs / 4 + 16 * (int64_t)T + 16;
   return (int)(c > 0x3fffffff ? 0x3fffffff : c);
 }
+__host__ __device__ inline int seg_block_capacity(int64_t start, int64_t end) { return (int)((end >> 6) - (start >> 6)) + 1; }
+__host__ __device__ inline int64_t seg_first_slot(int64_t start, int tile) { return 16 * ((start >> 6) + tile); }
 
 inline Dims make_dims(int P, int W, int H, int64_t max_pairs) {
   Dims d;
@@ -86,11 +87,14 @@ struct Workspace {
   uint32_t* n_contrib;
   float* grad_acc;
   int32_t* status;
-  int32_t* seg_counters;
+  int32_t* seg_heads;
+  uint32_t* seg_count;
   uint2* seg_entries;
   float4* seg_ckpt;
   uint2* seg_info;
   float4* pix_accum;
+  float* pair_grad;
+  uint32_t* seg_list;
 };
 
 // Batched launches: blockIdx.y = frame. Element strides between frames (0 = shared by all
@@ -105,8 +109,8 @@ __host__ __device__ inline Workspace frame_ws(Workspace w, size_t bytes) {
   auto mv = [bytes](auto*& p) { p = reinterpret_cast<std::remove_reference_t<decltype(p)>>(reinterpret_cast<char*>(p) + bytes); };
   mv(w.depth); mv(w.xy); mv(w.xyext); mv(w.conic_opacity); mv(w.rgb); mv(w.cov3d); mv(w.rect); mv(w.tiles_touched);
   mv(w.clamped); mv(w.tile_count); mv(w.tile_offset); mv(w.tile_cursor); mv(w.pair_key);
-  mv(w.point_list); mv(w.pair_tmp); mv(w.final_T); mv(w.n_contrib); mv(w.grad_acc); mv(w.status); mv(w.seg_counters);
-  mv(w.seg_entries); mv(w.seg_ckpt); mv(w.seg_info); mv(w.pix_accum);
+  mv(w.point_list); mv(w.pair_tmp); mv(w.final_T); mv(w.n_contrib); mv(w.grad_acc); mv(w.status); mv(w.seg_heads); mv(w.seg_count);
+  mv(w.seg_entries); mv(w.seg_ckpt); mv(w.seg_info); mv(w.pix_accum); mv(w.pair_grad); mv(w.seg_list);
   return w;
 }
 

@@ -152,16 +152,6 @@ __device__ __forceinline__ int wave_scan_add_i(int x) {
   x += dpp_i<0x143, 0xc>(x);
   return x;
 }
-// Segment slots are handed out by 64 counters (one 256-byte line each): slot = count * 64 + r for counter r.
-// XCD affinity (speed only, MI355X_MICROARCH.md: block b is observed on XCD b % 8, each XCD has its own
-// 4 MiB L2): the forward pass runs all blocks of a tile on one XCD x and draws their slots from the 8
-// counters r with (r >> 2) % 8 == x; the backward pass's persistent waves stride over the slots so that
-// slot s is processed by workgroup (s % 64) / 4 (mod 8) = the same XCD. A tile's ~37 segments reference the
-// same ~1000 Gaussians: their records are then fetched into ONE L2 instead of eight.
-static_assert(GSR_SEG_COUNTERS == 64, "lane l <-> counter l in the backward pass");
-__device__ __forceinline__ int32_t* seg_counter(int32_t* counters, int r) { return counters + r * GSR_SEG_COUNTER_STRIDE; }
-__device__ __forceinline__ int seg_counter_of(int xcd, int rot) { return 4 * xcd + (rot & 3) + 32 * ((rot >> 2) & 1); }
-
 __device__ __forceinline__ float read_lane(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
@@ -209,16 +199,17 @@ render_fwd_kernel(int W, int H, int gx, int T, int64_t max_pairs, int seg_cap, c
                   const float* __restrict__ bg, float* __restrict__ out_color,
                   float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                   uint2* __restrict__ seg_entries, float4* __restrict__ seg_ckpt, uint2* __restrict__ seg_info,
-                  float4* __restrict__ pix_accum, int32_t* __restrict__ status, int32_t* __restrict__ seg_counters,
-                  int flags, size_t ws_stride) {
+                  float4* __restrict__ pix_accum, uint32_t* __restrict__ seg_count, int32_t* __restrict__ seg_heads,
+                  uint32_t* __restrict__ seg_list, int flags, size_t ws_stride) {
   {   // batched launch: blockIdx.y = frame
     const size_t off = (size_t)blockIdx.y * ws_stride;
-    tile_order = shift(tile_order, off); seg_counters = shift_mut(seg_counters, off);
+    tile_order = shift(tile_order, off); seg_count = shift_mut(seg_count, off);
     tile_offset = shift(tile_offset, off); point_list = shift(point_list, off); xyext = shift(xyext, off);
     conic_opacity = shift(conic_opacity, off); rgb = shift(rgb, off);
     final_T = shift_mut(final_T, off); n_contrib = shift_mut(n_contrib, off);
     seg_entries = shift_mut(seg_entries, off); seg_ckpt = shift_mut(seg_ckpt, off);
-    seg_info = shift_mut(seg_info, off); pix_accum = shift_mut(pix_accum, off); status = shift_mut(status, off);
+    seg_info = shift_mut(seg_info, off); pix_accum = shift_mut(pix_accum, off); seg_heads = shift_mut(seg_heads, off);
+    seg_list = shift_mut(seg_list, off);
     out_color += (size_t)blockIdx.y * 3 * H * W;
   }
   __shared__ uint32_t s_idx[WAVES][RING];
@@ -236,6 +227,9 @@ render_fwd_kernel(int W, int H, int gx, int T, int64_t max_pairs, int seg_cap, c
   const int64_t start = min((int64_t)tile_offset[tile], max_pairs);
   const int64_t end = min((int64_t)tile_offset[tile + 1], max_pairs);
   const int n = (int)(end - start);
+  // this block's segment slots (gsr_common.h: seg_first_slot): no counter, no overflow
+  const int blk16 = (jb & 3) * WAVES + wave;
+  const int64_t slot0 = seg_first_slot(start, tile) + (int64_t)blk16 * seg_block_capacity(start, end);
   const float fbx = (float)g.bx0, fby = (float)g.by0;
   // lane p < 16 <-> pixel p of the block (row-major 4x4)
   const int ppx = g.bx0 + (lane & (SUB - 1)), ppy = g.by0 + ((lane >> 2) & (SUB - 1));
@@ -260,7 +254,7 @@ render_fwd_kernel(int W, int H, int gx, int T, int64_t max_pairs, int seg_cap, c
     int b0 = 0, head = 0, count = 0;
     bool more = true, pending = false;
     // the pending segment
-    int take = 0, e_k = 0, cidx = 0, cr = 0;
+    int take = 0, e_k = 0;
     uint32_t e_idx = 0;
     float4 c = make_float4(0.f, 0.f, 0.f, 0.f), co = c, col = c, ckpt = c;
     while (true) {
@@ -277,10 +271,6 @@ render_fwd_kernel(int W, int H, int gx, int T, int64_t max_pairs, int seg_cap, c
         head = (head + take) & (RING - 1);
         count -= take;
         __builtin_amdgcn_wave_barrier();
-        // a slot for the segment's record: the returning atomic flies while the next batch is culled
-        cr = seg_counter_of(xcd, wave + recorded + jb);
-        cidx = 0;
-        if (!(flags & 2) && lane == 0) cidx = atomicAdd(seg_counter(seg_counters, cr), 1);
         ckpt = make_float4(vT, vC0, vC1, vC2);      // the pixels' state at the segment's start
         pending = true;
       }
@@ -344,15 +334,11 @@ render_fwd_kernel(int W, int H, int gx, int T, int64_t max_pairs, int seg_cap, c
       }
       // record the segment for the backward pass
       if (!(flags & 2)) {
-        const int slot = __builtin_amdgcn_readfirstlane(cidx) * GSR_SEG_COUNTERS + cr;
-        if (slot < seg_cap) {
-          seg_entries[(size_t)slot * GSR_WAVE + lane] = make_uint2(e_idx, (uint32_t)e_k);
-          if (lane < NPIX) seg_ckpt[(size_t)slot * NPIX + lane] = ckpt;
-          if (lane == 0) seg_info[slot] = make_uint2((uint32_t)g.bx0 | ((uint32_t)g.by0 << 16), (uint32_t)take);
-          ++recorded;
-        } else if (lane == 0) {
-          status[1] = 1;      // the backward pass would miss this segment: report as overflow
-        }
+        const size_t slot = (size_t)(slot0 + recorded);
+        seg_entries[slot * GSR_WAVE + lane] = make_uint2(e_idx, (uint32_t)e_k);
+        if (lane < NPIX) seg_ckpt[slot * NPIX + lane] = ckpt;
+        if (lane == 0) seg_info[slot] = make_uint2((uint32_t)g.bx0 | ((uint32_t)g.by0 << 16), (uint32_t)take);
+        ++recorded;
       }
       if (!alive) break;
     }
@@ -367,29 +353,44 @@ render_fwd_kernel(int W, int H, int gx, int T, int64_t max_pairs, int seg_cap, c
     out_color[2 * plane + pix] = fmaf(vT, bg[2], vC2);
     if (recorded) pix_accum[pix] = make_float4(vC0, vC1, vC2, vT);
   }
+  if (lane == 0) seg_count[tile * GSR_SEG_BLOCKS + blk16] = (uint32_t)recorded;
+  // The segment-parallel backward pass strides over dense lists of slot ids, one per XCD class (this block ran on XCD
+  // `xcd`, so will the waves that take its segments): one returning atomic per block claims a range of the class's list
+  // (seg_heads[64 xcd] = the class count, one 256-byte line per counter: ~1 k returning atomics per address and
+  // frame, spread over the whole launch; eight counters on ONE line measured +135 us).
+  if (recorded > 0) {
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&seg_heads[64 * xcd], recorded);
+    base = __builtin_amdgcn_readfirstlane(base);
+    uint32_t* list = seg_list + (size_t)xcd * seg_cap;
+    for (int sgm = lane; sgm < recorded; sgm += GSR_WAVE) list[base + sgm] = (uint32_t)(slot0 + sgm);
+  }
 }
 
 // ------------------------------------------------------------------------------------ backward
-constexpr int NCOMP = 9;     // dxy2 (scaled by W/2, H/2), dconic3, dopacity1, drgb3
+constexpr int NCOMP = GSR_PAIR_GRAD;   // dxy2 (scaled by W/2, H/2), dconic3, dopacity1, drgb3
+struct SegRec { uint2 info; uint2 ent; float4 ck; };
 
 // What a backward wave loads for one segment, in two dependent levels: the record itself (addressed by the
 // slot), then the Gaussians it names and the pixels of its block.
-struct SegRec { uint2 info; uint2 ent; float4 ck; };
+
 struct SegData { float2 c; float4 co; float4 col; float4 pa; int last; float g0, g1, g2; };
 
 __global__ void __launch_bounds__(GSR_TILE_PIX)
-render_bwd_kernel(int W, int H, int seg_cap, const float2* __restrict__ xy,
+render_bwd_kernel(int W, int H, int list_cap, const float2* __restrict__ xy,
                   const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb,
                   const float* __restrict__ bg, const uint32_t* __restrict__ n_contrib,
                   const uint2* __restrict__ seg_entries, const float4* __restrict__ seg_ckpt,
                   const uint2* __restrict__ seg_info, const float4* __restrict__ pix_accum,
-                  const int32_t* __restrict__ seg_counters, const float* __restrict__ dL_dout,
-                  float* __restrict__ grad_acc, int flags, size_t ws_stride) {
+                  const uint32_t* __restrict__ seg_list, const int32_t* __restrict__ seg_heads,
+                  const float* __restrict__ dL_dout,
+                  float* __restrict__ grad_acc, size_t ws_stride) {
   {   // batched launch: blockIdx.y = frame
     const size_t off = (size_t)blockIdx.y * ws_stride;
     xy = shift(xy, off); conic_opacity = shift(conic_opacity, off); rgb = shift(rgb, off);
     n_contrib = shift(n_contrib, off); seg_entries = shift(seg_entries, off); seg_ckpt = shift(seg_ckpt, off);
-    seg_info = shift(seg_info, off); pix_accum = shift(pix_accum, off); seg_counters = shift(seg_counters, off);
+    seg_info = shift(seg_info, off); pix_accum = shift(pix_accum, off); seg_list = shift(seg_list, off);
+    seg_heads = shift(seg_heads, off);
     grad_acc = shift_mut(grad_acc, off);
     dL_dout += (size_t)blockIdx.y * 3 * H * W;
   }
@@ -398,22 +399,27 @@ render_bwd_kernel(int W, int H, int seg_cap, const float2* __restrict__ xy,
   __shared__ uint32_t s_gi[WAVES][GSR_WAVE];
   const int lane = threadIdx.x & (GSR_WAVE - 1);
   const int wave = threadIdx.x / GSR_WAVE;
-  const int wave_id = blockIdx.x * WAVES + wave;
   const int nwaves = gridDim.x * WAVES;
-  // persistent waves (nwaves is a multiple of 64): wave w takes slots w, w + nwaves, ... — all from counter
-  // w % 64, i.e. recorded on the XCD this workgroup runs on. Slot count * 64 + r exists for count < counter r.
-  const int mine = min(seg_counters[(wave_id & (GSR_SEG_COUNTERS - 1)) * GSR_SEG_COUNTER_STRIDE] * GSR_SEG_COUNTERS,
-                       seg_cap);
+  // persistent waves (nwaves is a multiple of 32): the forward pass listed its segments per XCD class (the tiles of
+  // rank = x mod 8 ran on XCD x: render_fwd's tail); workgroup b runs on XCD b % 8 and its wave takes the
+  // entries j = (its index among that XCD's waves), += (waves per XCD) of list x: a tile's segments fetch their
+  // Gaussians' records into ONE L2
+  const int xcd = blockIdx.x & 7;
+  const uint32_t* my_list = seg_list + (size_t)xcd * list_cap;
+  const int mine = min(seg_heads[64 * xcd], list_cap);
+  const int wpx = nwaves / 8;                                    // waves per XCD
+  const int my_first = (blockIdx.x >> 3) * WAVES + wave;
   const float half_w = 0.5f * (float)W, half_h = 0.5f * (float)H;
   const size_t plane = (size_t)H * W;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
   const int p_l = lane & (NPIX - 1);
 
-  auto load_rec = [&](int seg) {
+  auto load_rec = [&](int j) {
     SegRec r;
+    const size_t seg = my_list[j];
     r.info = seg_info[seg];
-    r.ent = seg_entries[(size_t)seg * GSR_WAVE + lane];
-    r.ck = seg_ckpt[(size_t)seg * NPIX + p_l];                   // T, C of the block's pixels at the segment's start
+    r.ent = seg_entries[seg * GSR_WAVE + lane];
+    r.ck = seg_ckpt[seg * NPIX + p_l];                   // T, C of the block's pixels at the segment's start
     return r;
   };
   auto load_data = [&](const SegRec& r) {
@@ -435,13 +441,13 @@ render_bwd_kernel(int W, int H, int seg_cap, const float2* __restrict__ xy,
 
   // Two-level software pipeline: a wave's memory latency (record -> Gaussians/pixels, two dependent round
   // trips of microseconds under load) overlaps with the pixel loop of its previous segment.
-  int seg = wave_id;
+  int seg = my_first;
   if (seg >= mine) return;
   SegRec rec = load_rec(seg);
   SegData dat = load_data(rec);
-  bool have_next = seg + nwaves < mine;
+  bool have_next = seg + wpx < mine;
   SegRec rec_n = rec;
-  if (have_next) rec_n = load_rec(seg + nwaves);
+  if (have_next) rec_n = load_rec(seg + wpx);
   while (true) {
     const int bx0 = (int)(rec.info.x & 0xffffu), by0 = (int)(rec.info.x >> 16), cnt = (int)rec.info.y;
     const bool valid = lane < cnt;
@@ -460,7 +466,7 @@ render_bwd_kernel(int W, int H, int seg_cap, const float2* __restrict__ xy,
     const float fbx = (float)bx0, fby = (float)by0;
     const int kmin = __builtin_amdgcn_readfirstlane(k);            // entries are in list order
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;
-    if (!(flags & 8)) {
+    {
 #pragma unroll
       for (int p = 0; p < NPIX; ++p) {
         const int lastp = __builtin_amdgcn_readlane(vLast, p);
@@ -508,7 +514,7 @@ render_bwd_kernel(int W, int H, int seg_cap, const float2* __restrict__ xy,
     sg[lane * NCOMP + 6] = v6; sg[lane * NCOMP + 7] = v7; sg[lane * NCOMP + 8] = v8;
     s_gi[wave][lane] = valid ? idx : 0xffffffffu;
     __builtin_amdgcn_wave_barrier();
-    if (!(flags & 1)) {
+    {
 #pragma unroll 3
       for (int r = 0; r < NCOMP; ++r) {
         const int fl = r * GSR_WAVE + lane;
@@ -521,22 +527,276 @@ render_bwd_kernel(int W, int H, int seg_cap, const float2* __restrict__ xy,
     }
     __builtin_amdgcn_wave_barrier();
     if (!have_next) break;
-    seg += nwaves;
+    seg += wpx;
     rec = rec_n;
     dat = dat_n;
-    have_next = seg + nwaves < mine;
-    if (have_next) rec_n = load_rec(seg + nwaves);
+    have_next = seg + wpx < mine;
+    if (have_next) rec_n = load_rec(seg + wpx);
   }
 }
 
-// status[2] = segment slots the forward pass asked for (sum of the counters), for the
-// host's capacity bookkeeping; one wave per frame.
-__global__ void __launch_bounds__(GSR_WAVE)
-seg_total_kernel(int32_t* __restrict__ status, const int32_t* __restrict__ seg_counters, size_t ws_stride) {
-  status = shift_mut(status, (size_t)blockIdx.x * ws_stride);
-  seg_counters = shift(seg_counters, (size_t)blockIdx.x * ws_stride);
-  const int total = wave_scan_add_i(seg_counters[(int)threadIdx.x * GSR_SEG_COUNTER_STRIDE]);
-  if (threadIdx.x == GSR_WAVE - 1) status[2] = total;
+
+constexpr int BWD_WG = 1024;           // 16 waves: one workgroup per CU (LDS), all of a tile's segments on it
+constexpr int NCAP = 3072;             // list entries whose gradient rows fit the LDS table (9 floats each: 108 KiB)
+
+// Tile-grouped variant of K6: one workgroup per TILE walks the tile's recorded segments, sums each list entry's
+// gradients in an LDS table indexed by list position and flushes the table once per tile (one record per (tile,
+// Gaussian) pair). Two uses:
+//   * DET (settings.debug, the reference's debug knob /root/reference/gaussian_renderer/__init__.py:33): ONE wave per
+//     tile takes the segments in their fixed order, the rows go to per-pair records instead of atomics, and
+//     gather_pair_grads_kernel sums a Gaussian's pairs in tile order: bitwise repeatable, several times slower;
+//   * !DET with 16 waves per tile is the layout round 2's review asked for (per-tile LDS staging, one atomic record
+//     per pair). Built and measured (profiles/r03_render_bwd_tile.md): 290-320 us per 2-frame launch against 150 for
+//     the segment-parallel kernel above — ds_add_f32 retires about one lane per clock and CU, so the 14.7 M
+//     per-entry adds of a launch cost as much in LDS as they do as memory-side atomics, the flush is a second,
+//     serialised round of atomics per tile, and a tile is a much coarser unit than a segment (the largest tile is
+//     the launch's tail). Kept compiled for the record; the default path is the segment-parallel kernel.
+// Lists longer than NCAP entries are handled in passes over position ranges (a segment is replayed in every pass its
+// entries reach into).
+template <bool DET>
+__global__ void __launch_bounds__(DET ? GSR_WAVE : BWD_WG)
+render_bwd_tile_kernel(int W, int H, int gx, int T, int64_t max_pairs, const uint32_t* __restrict__ tile_order,
+                       const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ point_list,
+                       const float2* __restrict__ xy, const float4* __restrict__ conic_opacity,
+                       const float4* __restrict__ rgb, const float* __restrict__ bg,
+                       const uint32_t* __restrict__ n_contrib, const uint2* __restrict__ seg_entries,
+                       const float4* __restrict__ seg_ckpt, const uint2* __restrict__ seg_info,
+                       const float4* __restrict__ pix_accum, const uint32_t* __restrict__ seg_count,
+                       const float* __restrict__ dL_dout, float* __restrict__ grad_acc,
+                       float* __restrict__ pair_grad, size_t ws_stride) {
+  {   // batched launch: blockIdx.y = frame
+    const size_t off = (size_t)blockIdx.y * ws_stride;
+    tile_order = shift(tile_order, off); tile_offset = shift(tile_offset, off); point_list = shift(point_list, off);
+    xy = shift(xy, off); conic_opacity = shift(conic_opacity, off); rgb = shift(rgb, off);
+    n_contrib = shift(n_contrib, off); seg_entries = shift(seg_entries, off); seg_ckpt = shift(seg_ckpt, off);
+    seg_info = shift(seg_info, off); pix_accum = shift(pix_accum, off); seg_count = shift(seg_count, off);
+    grad_acc = shift_mut(grad_acc, off); pair_grad = shift_mut(pair_grad, off);
+    dL_dout += (size_t)blockIdx.y * 3 * H * W;
+  }
+  extern __shared__ float s_dyn[];                 // gradient table [rows][NCOMP]
+  __shared__ float4 s_pa[GSR_TILE_PIX];            // C_total.rgb, T_final per pixel of the tile
+  __shared__ float4 s_g[GSR_TILE_PIX];             // dL/dpixel.rgb, .w = last contributor (as float bits)
+  __shared__ int s_pre[GSR_SEG_BLOCKS + 1];
+  __shared__ int s_kmax;
+  const int tid = threadIdx.x;
+  const int lane = tid & (GSR_WAVE - 1);
+  const int wave = tid / GSR_WAVE;
+  const int nwaves = blockDim.x / GSR_WAVE;
+  const float half_w = 0.5f * (float)W, half_h = 0.5f * (float)H;
+  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+  const int p_l = lane & (NPIX - 1);
+  const size_t plane = (size_t)H * W;
+  // persistent workgroups: rank = blockIdx.x, += gridDim.x over the size-ordered tiles (gridDim.x is a multiple of 8:
+  // the XCD of a rank is kept); the first empty tile ends the walk — launching one workgroup per tile would dispatch
+  // thousands of 110 KiB-LDS workgroups that find their tile empty
+  for (int rank = blockIdx.x; rank < T; rank += gridDim.x) {
+  const int tile = (int)tile_order[rank];
+  const int64_t start = min((int64_t)tile_offset[tile], max_pairs);
+  const int64_t end = min((int64_t)tile_offset[tile + 1], max_pairs);
+  const int n = (int)(end - start);
+  if (n == 0) break;
+  __syncthreads();                                 // the previous tile's LDS is free
+  // segments per block -> exclusive prefix (wave 0)
+  if (tid < GSR_WAVE) {
+    const int c = lane < GSR_SEG_BLOCKS ? (int)seg_count[tile * GSR_SEG_BLOCKS + lane] : 0;
+    const int incl = wave_scan_add_i(c);
+    if (lane < GSR_SEG_BLOCKS) s_pre[lane + 1] = incl;
+    if (lane == 0) { s_pre[0] = 0; s_kmax = 0; }
+  }
+  __syncthreads();
+  const int total = s_pre[GSR_SEG_BLOCKS];
+  if (total == 0) {
+    if (DET) {      // no segment was recorded: every pair of the tile has a zero record
+      float* out = pair_grad + (size_t)start * NCOMP;
+      for (int e = tid; e < n * NCOMP; e += blockDim.x) out[e] = 0.f;
+    }
+    continue;
+  }
+  const int capb = seg_block_capacity(start, end);
+  const int64_t slot_tile = seg_first_slot(start, tile);
+  const int tx0 = (tile % gx) * GSR_TILE, ty0 = (tile / gx) * GSR_TILE;
+  // the tile's pixels, block-major: entry 16 b + p = pixel p of 4x4 block b (b = quadrant * 4 + wave of the forward)
+  for (int e = tid; e < GSR_TILE_PIX; e += blockDim.x) {
+    const int b = e >> 4, p = e & 15;
+    const int px = tx0 + ((b >> 2) & 1) * 8 + (b & 1) * SUB + (p & (SUB - 1));
+    const int py = ty0 + (b >> 3) * 8 + ((b >> 1) & 1) * SUB + (p >> 2);
+    const bool inside = px < W && py < H;
+    const size_t pix = inside ? (size_t)py * W + px : 0;
+    const int last = inside ? (int)n_contrib[pix] : 0;
+    s_pa[e] = pix_accum[pix];
+    s_g[e] = make_float4(inside ? dL_dout[pix] : 0.f, inside ? dL_dout[plane + pix] : 0.f,
+                         inside ? dL_dout[2 * plane + pix] : 0.f, __int_as_float(last));
+    if (last > 0) atomicMax(&s_kmax, last);
+  }
+  __syncthreads();
+  const int kmax = min(s_kmax, n);                 // entries at positions >= kmax were never blended
+
+  auto slot_of = [&](int i) -> size_t {            // i-th segment of the tile: block by the prefix, then its index
+    int b = 0;
+#pragma unroll
+    for (int j = 1; j < GSR_SEG_BLOCKS; ++j) b += (i >= s_pre[j]) ? 1 : 0;
+    return (size_t)(slot_tile + (int64_t)b * capb + (i - s_pre[b]));
+  };
+  auto load_rec = [&](int i) {
+    SegRec r;
+    const size_t seg = slot_of(i);
+    r.info = seg_info[seg];
+    r.ent = seg_entries[seg * GSR_WAVE + lane];
+    r.ck = seg_ckpt[seg * NPIX + p_l];             // T, C of the block's pixels at the segment's start
+    return r;
+  };
+
+  for (int k0 = 0; k0 < kmax; k0 += NCAP) {
+    const int rows = min(NCAP, kmax - k0);
+    for (int e = tid; e < rows * NCOMP; e += blockDim.x) s_dyn[e] = 0.f;
+    __syncthreads();
+    // two-level software pipeline, as in the forward pass: the record of segment i + 2 nw and the Gaussians of
+    // segment i + nw are in flight while segment i is evaluated
+    struct SegGauss { float2 c; float4 co, col; };
+    auto load_gauss = [&](const SegRec& r) {
+      SegGauss d;
+      const uint32_t idx = lane < (int)r.info.y ? r.ent.x : 0u;
+      d.c = xy[idx]; d.co = conic_opacity[idx]; d.col = rgb[idx];
+      return d;
+    };
+    int i = wave;
+    SegRec rec_c{}, rec_n{};
+    SegGauss dat_c{};
+    if (i < total) { rec_c = load_rec(i); dat_c = load_gauss(rec_c); }
+    if (i + nwaves < total) rec_n = load_rec(i + nwaves);
+    for (; i < total; i += nwaves) {
+      const SegRec rec = rec_c;
+      const SegGauss dat = dat_c;
+      rec_c = rec_n;
+      if (i + nwaves < total) dat_c = load_gauss(rec_c);
+      if (i + 2 * nwaves < total) rec_n = load_rec(i + 2 * nwaves);
+      const int cnt = (int)rec.info.y;
+      const bool valid = lane < cnt;
+      const int k = valid ? (int)rec.ent.y : 0x7fffffff;
+      const int kfirst = __builtin_amdgcn_readfirstlane(k);                       // entries are in list order
+      const int klast = __builtin_amdgcn_readlane(k, cnt - 1);
+      if (klast < k0 || kfirst >= k0 + rows) continue;                            // not in this pass
+      const float2 c = dat.c;
+      const float4 co = dat.co;
+      const float4 col = dat.col;
+      const int bx0 = (int)(rec.info.x & 0xffffu), by0 = (int)(rec.info.x >> 16);
+      const int b = (((by0 - ty0) >> 3) << 3) | (((bx0 - tx0) >> 3) << 2) | ((((by0 - ty0) >> 2) & 1) << 1) | (((bx0 - tx0) >> 2) & 1);
+      const float4 pa = s_pa[16 * b + p_l];
+      const float4 gp = s_g[16 * b + p_l];
+      const float4 ck = rec.ck;
+      const int vLast = __float_as_int(gp.w);
+      const float vg0 = gp.x, vg1 = gp.y, vg2 = gp.z;
+      const float vTs = ck.x;
+      // R = (C_total - C_start).g + T_final (bg.g): what lies behind the segment's first entry
+      const float vR = (pa.x - ck.y) * vg0 + (pa.y - ck.z) * vg1 + (pa.z - ck.w) * vg2 +
+                       pa.w * (bg0 * vg0 + bg1 * vg1 + bg2 * vg2);
+      const float fbx = (float)bx0, fby = (float)by0;
+      float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;
+#pragma unroll
+      for (int p = 0; p < NPIX; ++p) {
+        const int lastp = __builtin_amdgcn_readlane(vLast, p);
+        if (lastp <= kfirst) continue;                              // the pixel saturated in front of this segment
+        const float dx = c.x - (fbx + (float)(p & (SUB - 1)));
+        const float dy = c.y - (fby + (float)(p >> 2));
+        const float power = eval_power(co, dx, dy);
+        const float G = __expf(power);
+        const float alpha = fminf(ALPHA_MAX, co.w * G);
+        const float a = ((k < lastp) & (power <= 0.0f) & (alpha >= ALPHA_MIN)) ? alpha : 0.f;
+        if (__ballot(a > 0.f) == 0ull) continue;
+        const float g0 = read_lane(vg0, p), g1 = read_lane(vg1, p), g2 = read_lane(vg2, p);
+        const float om = 1.0f - a;
+        const float Tk = read_lane(vTs, p) * wave_shr1(1.0f, wave_scan_mul(om));   // in front of this entry
+        const float cg = col.x * g0 + col.y * g1 + col.z * g2;
+        const float w = a * Tk;
+        const float Sincl = wave_scan_add(cg * w);                   // (C_<=k - C_start).g
+        const float rc = __builtin_amdgcn_rcpf(om);                  // a <= 0.99
+        float dL_dalpha = fmaf(Tk, cg, -rc * (read_lane(vR, p) - Sincl));
+        dL_dalpha = (a > 0.f) ? dL_dalpha : 0.f;
+        const float dL_dG = co.w * dL_dalpha;
+        const float gdx = G * dx, gdy = G * dy;
+        const float dG_ddx = -gdx * co.x - gdy * co.y;
+        const float dG_ddy = -gdy * co.z - gdx * co.y;
+        v0 = fmaf(dL_dG, dG_ddx, v0);
+        v1 = fmaf(dL_dG, dG_ddy, v1);
+        v2 = fmaf(-0.5f * gdx * dx, dL_dG, v2);
+        v3 = fmaf(-gdx * dy, dL_dG, v3);
+        v4 = fmaf(-0.5f * gdy * dy, dL_dG, v4);
+        v5 = fmaf(G, dL_dalpha, v5);
+        v6 = fmaf(w, g0, v6);
+        v7 = fmaf(w, g1, v7);
+        v8 = fmaf(w, g2, v8);
+      }
+      // the entry's sums over the block's pixels -> its row of the tile's table
+      if (valid && k >= k0 && k < k0 + rows) {
+        float* row = s_dyn + (size_t)(k - k0) * NCOMP;
+        atomicAdd(row + 0, v0 * half_w); atomicAdd(row + 1, v1 * half_h); atomicAdd(row + 2, v2);
+        atomicAdd(row + 3, v3); atomicAdd(row + 4, v4); atomicAdd(row + 5, v5);
+        atomicAdd(row + 6, v6); atomicAdd(row + 7, v7); atomicAdd(row + 8, v8);
+      }
+    }
+    __syncthreads();
+    // flush the pass's rows: consecutive threads take consecutive floats of the table (a wave's atomic instruction
+    // covers 7 whole 64-byte gradient records)
+    const uint32_t* pl = point_list + start + k0;
+    if (DET) {
+      float* out = pair_grad + (size_t)(start + k0) * NCOMP;
+      for (int e = tid; e < rows * NCOMP; e += blockDim.x) out[e] = s_dyn[e];
+    } else {
+      for (int e = tid; e < rows * NCOMP; e += blockDim.x) {
+        const float val = s_dyn[e];
+        if (val != 0.f) {
+          const int kk = (int)(((unsigned)e * 7282u) >> 16);         // e / 9 for e < 3072 * 9
+          unsafeAtomicAdd(&grad_acc[(size_t)pl[kk] * GSR_GRAD_STRIDE + (e - kk * NCOMP)], val);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (DET) {      // rows beyond kmax: nothing was blended there
+    float* out = pair_grad + (size_t)start * NCOMP;
+    for (int e = kmax * NCOMP + tid; e < n * NCOMP; e += blockDim.x) out[e] = 0.f;
+  }
+  }   // persistent walk over the tiles
+}
+
+// DET: a Gaussian's gradient record = the sum of its pairs' records in tile order (row-major over its rectangle).
+// Its position in a tile's list is found by binary search on the sort key (depth bits, index).
+__global__ void __launch_bounds__(256)
+gather_pair_grads_kernel(int P, int gx, int64_t max_pairs, const int4* __restrict__ rect,
+                         const float* __restrict__ depth, const uint32_t* __restrict__ tile_offset,
+                         const uint32_t* __restrict__ point_list, const float* __restrict__ pair_grad,
+                         float* __restrict__ grad_acc, size_t ws_stride) {
+  {
+    const size_t off = (size_t)blockIdx.y * ws_stride;
+    rect = shift(rect, off); depth = shift(depth, off); tile_offset = shift(tile_offset, off);
+    point_list = shift(point_list, off); pair_grad = shift(pair_grad, off); grad_acc = shift_mut(grad_acc, off);
+  }
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const int4 rc = rect[i];
+  if ((rc.z - rc.x) * (rc.w - rc.y) <= 0) return;
+  const uint64_t key = ((uint64_t)__float_as_uint(depth[i]) << 32) | (uint32_t)i;
+  float acc[NCOMP];
+#pragma unroll
+  for (int q = 0; q < NCOMP; ++q) acc[q] = 0.f;
+  for (int ty = rc.y; ty < rc.w; ++ty)
+    for (int tx = rc.x; tx < rc.z; ++tx) {
+      const int t = ty * gx + tx;
+      int64_t lo = min((int64_t)tile_offset[t], max_pairs), hi = min((int64_t)tile_offset[t + 1], max_pairs);
+      const int64_t e = hi;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        const uint32_t j = point_list[mid];
+        const uint64_t kj = ((uint64_t)__float_as_uint(depth[j]) << 32) | j;
+        if (kj < key) lo = mid + 1; else hi = mid;
+      }
+      if (lo < e && point_list[lo] == (uint32_t)i) {
+#pragma unroll
+        for (int q = 0; q < NCOMP; ++q) acc[q] += pair_grad[(size_t)lo * NCOMP + q];
+      }
+    }
+#pragma unroll
+  for (int q = 0; q < NCOMP; ++q) grad_acc[(size_t)i * GSR_GRAD_STRIDE + q] = acc[q];
 }
 
 }  // namespace
@@ -549,9 +809,7 @@ hipError_t launch_render_fwd(const GsrSettings& s, const Dims& d, const Workspac
     hipLaunchKernelGGL(render_fwd_kernel, dim3(32 * ((d.T + 7) / 8), bt.frames), dim3(GSR_TILE_PIX), 0, stream, d.W,
                        d.H, d.gx, d.T, d.max_pairs, d.seg_cap, ws.tile_count, ws.tile_offset, ws.point_list, ws.xyext,
                        ws.conic_opacity, ws.rgb, s.bg, out_color, ws.final_T, ws.n_contrib, ws.seg_entries,
-                       ws.seg_ckpt, ws.seg_info, ws.pix_accum, ws.status, ws.seg_counters, ablate_flags(), bt.ws_stride);
-    hipLaunchKernelGGL(seg_total_kernel, dim3(bt.frames), dim3(GSR_WAVE), 0, stream, ws.status, ws.seg_counters,
-                       bt.ws_stride);
+                       ws.seg_ckpt, ws.seg_info, ws.pix_accum, ws.seg_count, ws.seg_heads, ws.seg_list, ablate_flags(), bt.ws_stride);
   }
   return hipGetLastError();
 }
@@ -559,16 +817,31 @@ hipError_t launch_render_fwd(const GsrSettings& s, const Dims& d, const Workspac
 hipError_t launch_render_bwd(const GsrSettings& s, const Dims& d, const Workspace& ws,
                              const float* dL_dout, const Batch& bt, hipStream_t stream) {
   if (d.T == 0 || d.P == 0) return hipSuccess;
-  {
-    ProfScope prof_(K_RENDER_BWD, stream);
-    // persistent grid: enough workgroups to fill the chip at the kernel's occupancy; each wave strides
-    // over the recorded segments (their count is only known on the device, status[8..])
-    const int per_frame = max(16, (GSR_BWD_BLOCKS / bt.frames) & ~15);      // waves per frame: a multiple of 64
-    hipLaunchKernelGGL(render_bwd_kernel, dim3(per_frame, bt.frames), dim3(GSR_TILE_PIX), 0, stream, d.W,
-                       d.H, d.seg_cap, ws.xy, ws.conic_opacity, ws.rgb, s.bg, ws.n_contrib, ws.seg_entries,
-                       ws.seg_ckpt, ws.seg_info, ws.pix_accum, ws.seg_counters, dL_dout, ws.grad_acc, ablate_flags(),
+  ProfScope prof_(K_RENDER_BWD, stream);
+  if (s.debug) {
+    // deterministic: one wave per tile, per-pair records, per-Gaussian gather in tile order
+    const size_t lds = (size_t)NCAP * NCOMP * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(render_bwd_tile_kernel<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(render_bwd_tile_kernel<true>, dim3(d.T < 2048 ? d.T : 2048, bt.frames), dim3(GSR_WAVE), lds, stream,
+                       d.W, d.H, d.gx, d.T, d.max_pairs, ws.tile_count, ws.tile_offset, ws.point_list, ws.xy,
+                       ws.conic_opacity, ws.rgb, s.bg, ws.n_contrib, ws.seg_entries, ws.seg_ckpt, ws.seg_info,
+                       ws.pix_accum, ws.seg_count, dL_dout, ws.grad_acc, ws.pair_grad, bt.ws_stride);
+    hipLaunchKernelGGL(gather_pair_grads_kernel, dim3((d.P + 255) / 256, bt.frames), dim3(256), 0, stream, d.P, d.gx,
+                       d.max_pairs, ws.rect, ws.depth, ws.tile_offset, ws.point_list, ws.pair_grad, ws.grad_acc,
                        bt.ws_stride);
+    return hipGetLastError();
   }
+  // one persistent wave per few segments of the per-XCD lists the forward pass left
+  const int per_frame = max(16, (GSR_BWD_BLOCKS / bt.frames) & ~15);      // waves per frame: a multiple of 64
+  hipLaunchKernelGGL(render_bwd_kernel, dim3(per_frame, bt.frames), dim3(GSR_TILE_PIX), 0, stream, d.W, d.H, d.seg_cap, ws.xy,
+                     ws.conic_opacity, ws.rgb, s.bg, ws.n_contrib, ws.seg_entries, ws.seg_ckpt, ws.seg_info,
+                     ws.pix_accum, ws.seg_list, ws.seg_heads, dL_dout, ws.grad_acc, bt.ws_stride);
   return hipGetLastError();
 }
 

@@ -109,14 +109,10 @@ class _PairCapacity:
         needed, overflow = int(host[0]), int(host[1])
         self.last_status = host.tolist()
         self.pool.append(host)
-        # the forward pass also records segments for the backward pass (status[2]; capacity
-        # max_pairs/16 + 16*tiles): express their demand as the pair capacity that would hold them
-        tiles = ((key[1] + 15) // 16) * ((key[2] + 15) // 16)
-        seg_pairs = 16 * max(0, int(host[2]) - 16 * tiles)
-        self.seen[key] = max(self.seen.get(key, 0), needed, seg_pairs)
+        # (the segment records the forward pass leaves for the backward pass cannot overflow: their slots are an
+        # exact function of the tile lists, include/gsr.h GsrLayout.seg_entries — the pair buffer is the only capacity)
+        self.seen[key] = max(self.seen.get(key, 0), needed)
         if overflow and cap is not None:
-            # e.g. one slot range of the segment records ran full while the totals still fit: whatever
-            # overflowed, the next capacity (2 x seen) must be larger than the one that was too small
             self.seen[key] = max(self.seen[key], int(cap))
         self.stamp[key] = time.monotonic()
         frames = int(host[5]) if int(host[5]) > 0 else 1          # batched launches report totals
@@ -256,7 +252,7 @@ def workspace_views(workspace: torch.Tensor, P: int, W: int, H: int, max_pairs: 
     L = _native.GsrLayout()
     _native.gsr_check(lib.gsr_workspace_layout(P, W, H, max_pairs, ctypes.byref(L)))
     T = ((W + 15) // 16) * ((H + 15) // 16)
-    S = max_pairs // 16 + 16 * T                 # segment slots (gsr_common.h: seg_capacity)
+    S = max_pairs // 4 + 16 * T + 16             # segment slots (gsr_common.h: seg_capacity)
 
     def view(off, nbytes, dtype, shape):
         return workspace[off:off + nbytes].view(dtype).reshape(shape)
@@ -280,6 +276,7 @@ def workspace_views(workspace: torch.Tensor, P: int, W: int, H: int, max_pairs: 
         seg_ckpt=view(L.seg_ckpt, S * 256, torch.float32, (S, 16, 4)),
         seg_info=view(L.seg_info, S * 8, torch.int32, (S, 2)),
         pix_accum=view(L.pix_accum, W * H * 16, torch.float32, (H * W, 4)),
+        seg_count=view(L.seg_count, T * 64, torch.int32, (T, 16)),
     )
 
 

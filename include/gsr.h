@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 3
+#define GSR_ABI_VERSION 4
 #define GSR_TILE 16              /* tile edge in pixels (BLOCK_X = BLOCK_Y = 16)       */
 #define GSR_NUM_CHANNELS 3
 
@@ -95,18 +95,25 @@ typedef struct GsrLayout {
   /* backward scratch: per-Gaussian screen-space gradient accumulators */
   uint64_t grad_acc;       /* float   [P,16] (dxy2, dconic3, dopac1, drgb3, pad7): one 64-byte line each */
   /* status words */
-  uint64_t status;         /* int32   [8]  [0]=pairs needed (D) [1]=overflow flag (pairs or segment slots)
-                                           [2]=segment slots the forward pass allocated
-                                           [3]=max pairs in one tile                          */
-  uint64_t seg_counters;   /* int32   [64,64] slot counters of the segment records (word 0 of each row)  */
+  uint64_t status;         /* int32   [8]  [0]=pairs needed (D) [1]=overflow flag (pair buffer)
+                                           [2]=unused  [3]=max pairs in one tile              */
+  uint64_t seg_heads;      /* int32   [8,64] word 0 of row x = recorded segments of XCD class x (entries of
+                                           seg_list[x]); one 256-byte line per counter         */
+  uint64_t seg_count;      /* uint32  [T,16] segments the forward pass recorded per (tile, 4x4 block)     */
   uint64_t xyext;          /* float4  [P]    (pixel-space centre, half extents of the alpha>=1/255 box) */
-  /* what the forward pass consumed, for the segment-parallel backward pass: S = max_pairs/16 + 16*T
-   * segments of up to 64 list entries that survived the cull of one 4x4 pixel block */
+  /* what the forward pass consumed, for the backward pass: segments of up to 64 list entries that survived the
+   * cull of one 4x4 pixel block. Slots are addressed without counters: the 16 blocks of tile t own the slots
+   * 16 (tile_offset[t] / 64 + t) + b c + s  (block b, its s-th segment, c = the tile's per-block capacity) — an
+   * exact bound, S = max_pairs / 4 + 16 T + 16 slots, so recording never overflows */
   uint64_t seg_entries;    /* uint32  [S,64,2] (Gaussian index, position in the tile's list)  */
   uint64_t seg_ckpt;       /* float   [S,16,4] (T, C.rgb) of the block's pixels at the segment's start */
   uint64_t seg_info;       /* uint32  [S,2]    (block x0 | y0<<16, entries in the segment)    */
   uint64_t pix_accum;      /* float   [H*W,4]  (C.rgb without background, final T); written for blocks
                                               with at least one segment                      */
+  uint64_t pair_grad;      /* float   [cap,9]  per (tile, Gaussian) pair gradient records of the deterministic
+                                              (settings.debug) backward pass                 */
+  uint64_t seg_list;       /* uint32  [8,S]  the recorded segments as dense lists of slot ids, one per XCD class
+                                              (tiles of rank = x mod 8), what the segment-parallel backward strides over */
 } GsrLayout;
 
 /* Size in bytes of the workspace for P Gaussians, a W x H image and room for
