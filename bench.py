@@ -251,6 +251,61 @@ def _cpu_model() -> str:
     return "unknown"
 
 
+def fixed_global_batch_line(args, dev, rank, world, global_batch=8):
+    """The same stage-1 workload with a FIXED global batch of 8 frames (BASELINE.json configs[3]) spread over the
+    ranks — decoder sharded by UV texels, synchronised BatchNorm statistics — as a second, shorter measurement, so
+    that one driver run carries both the weak value (`value`) and a strong-scaling value."""
+    from gaussianavatar_amd import parallel, rasterizer
+    from gaussianavatar_amd.avatar_model import AvatarModel, collate_frames, default_params
+    from gaussianavatar_amd.losses import l1_loss_w, ssim, weighted_sum
+    if global_batch % world:
+        return None
+    B = global_batch // world
+    prev_mode = "texels" if parallel.texel_sharding() else "frames"
+    parallel.set_mode("texels")
+    torch.manual_seed(0)
+    mp, npar, op = default_params(batch_size=B, num_points=args.points, image_width=args.size,
+                                  image_height=args.height or args.size, num_frames=max(16, global_batch),
+                                  train_stage=1, smpl_type=args.smpl_type,
+                                  query_posmap_size=args.uv or (1024 if args.points > 512 * 512 else 512))
+    model = AvatarModel(mp, npar, op, train=True, device=dev)
+    model.training_setup()
+    model.net.train()
+    ds = model.train_dataset
+    W, H = args.size, args.height or args.size
+    gt = torch.ones(B, 3, H, W, device=dev)
+    gt[:, :, H // 5: 4 * H // 5, 2 * W // 5: 3 * W // 5] = 0.6
+    batches = [collate_frames([ds[(s * global_batch + rank * B + k) % len(ds)] for k in range(B)], dev) for s in range(2)]
+    l = op.lambda_dssim
+
+    def step(i):
+        image, points, offset_loss, geo_loss, scale_loss = model.train_stage1(batches[i % 2], args.iteration)
+        loss = weighted_sum([scale_loss, offset_loss, l1_loss_w(image, gt), ssim(image, gt), geo_loss],
+                            [op.lambda_scale, op.lambda_rgl, 1.0 - l, -l, 1.0], bias=l)
+        model.zero_grad(1)
+        loss.backward()
+        model.step(1)
+
+    steps, warm = min(args.steps, 50), min(args.warmup, 10)
+    for i in range(warm):
+        step(i)
+    rasterizer.check_overflow(block=True)
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warm + i)
+    parallel.barrier()
+    torch.cuda.synchronize()
+    el = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    parallel.set_mode(prev_mode)
+    return {"global_batch": global_batch, "frames_per_gpu": B, "steps": steps, "warmup": warm,
+            "value": steps / el, "unit": "iters/s (one iteration = the 8-frame global batch)",
+            "frames_per_s": global_batch * steps / el, "ms_per_step": 1e3 * el / steps, "scaling": "strong",
+            "parallelism": (f"frames sharded over dp{world}; decoder sharded by UV texels, synchronised BatchNorm "
+                            f"statistics, outputs assembled with one all-reduce" if world > 1 else "single GPU")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -282,6 +337,11 @@ def main():
     ap.add_argument("--series", type=int, default=0,
                     help="also report iters/s per window of this many timed steps (HIP events on the loop's stream: "
                          "sustained vs burst rate) under config.series")
+    ap.add_argument("--dist-backend", default="", choices=("", "nccl", "gloo"),
+                    help="development: gloo exercises the multi-rank path on a box with fewer GPUs than ranks")
+    ap.add_argument("--share-device0", action="store_true", help="development: every rank on GPU 0")
+    ap.add_argument("--no-fixed-batch", action="store_true",
+                    help="skip the second, shorter measurement with a fixed global batch of 8 frames (fixed_global_batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket rasterizer kernels with HIP events in the timed region")
@@ -297,14 +357,14 @@ def main():
         args.stage, args.smpl_type, args.points, args.size, args.height = 2, "smplx", 300_000, 1920, 1080
         args.global_batch = args.global_batch or 8
 
-    if args.stage == 1 and (args.dp_mode or args.global_batch):
-        os.environ["GA_DP_MODE"] = args.dp_mode or "texels"
     from gaussianavatar_amd import parallel
-    rank, world, local = parallel.init_from_env()
+    if args.stage == 1 and (args.dp_mode or args.global_batch):
+        parallel.set_mode(args.dp_mode or "texels")
+    rank, world, local = parallel.init_from_env(backend=args.dist_backend or None)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
-    if os.environ.get("GA_SHARE_DEVICE0"):       # development: several ranks on one GPU (with gloo)
+    if args.share_device0:       # development: several ranks on one GPU (with --dist-backend gloo)
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -421,10 +481,23 @@ def main():
     fused.profile_enable(False)
     ncalls, mean_pairs = rasterizer.pair_statistics(reset=True)
     final_loss = float(loss.detach())
+    backend = torch.distributed.get_backend() if (world > 1 and torch.distributed.is_initialized()) else None
+    if world > 1 and not args.dist_backend:
+        assert backend == "nccl", f"multi-GPU bench must run over RCCL (backend nccl), got {backend}"
+    dflops = decoder_flops(model, 1 if args.stage == 1 else B)
+    dbytes = decoder_bytes(model, 1 if args.stage == 1 else B)
+    fixed = None
+    if args.stage == 1 and not args.global_batch and args.config in (0, 3) and not args.no_fixed_batch:
+        Nq = model.query_points.shape[1]
+        del model, batches
+        torch.cuda.empty_cache()
+        fixed = fixed_global_batch_line(args, dev, rank, world)
+    else:
+        Nq = model.query_points.shape[1]
 
     if rank != 0:
         return
-    N = model.query_points.shape[1]
+    N = Nq
     # weak scaling (default): every GPU renders `frames_per_gpu` frames, value counts reference-sized
     # iterations (one per GPU and step). --global-batch: the job does ONE iteration of that many frames per
     # step whatever the GPU count ("strong"): value = steps / time.
@@ -435,6 +508,7 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": "strong" if args.global_batch else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "ranks": world, "dist_backend": backend, **({"fixed_global_batch": fixed} if fixed else {}),
         "config": {"workload": f"stage-{args.stage} train iteration (LBS + feature net + skinning + Gaussian rasterizer "
                                f"fwd+bwd + L1/DSSIM + Adam), {N} Gaussians, {W}x{H}, {B} frames per GPU "
                                + ("(BASELINE.json configs[2])" if (args.stage, N, W, H) == (1, 200_000, 1024, 1024)
@@ -451,22 +525,19 @@ def main():
                    **({"series": {"window_steps": args.series, "iters_per_s": series}} if series else {}),
                    "decoder_gemm_arithmetic": (
                        "fp32 in / fp32 out; operands split exactly into three bf16 pieces, six bf16 MFMA products per "
-                       "fp32 product accumulated in fp32 (csrc/ganet_split.h; error vs float64 <= that of the "
-                       "v_mfma_f32_32x32x2_f32 kernels, tests/test_fused_gpu.py::test_split_mfma_is_fp32_accurate)"
-                       if _native.ganet().ganet_get_mfma_mode() == 1 else "v_mfma_f32_32x32x2_f32 (GANET_MFMA=f32)")},
+                       "fp32 product accumulated in fp32 (csrc/ganet_split.h; error vs float64 ~4e-7 of the tensor's "
+                       "max, tests/test_fused_gpu.py::test_split_mfma_is_fp32_accurate)")},
     }
     if probe:
         # one launch of every rasterizer kernel processes all B frames of the rank's batch
         alg = {k: v * B for k, v in algorithmic_bytes(N, mean_pairs, H * W).items()}
-        dflops = decoder_flops(model, 1 if args.stage == 1 else B)
-        dbytes = decoder_bytes(model, 1 if args.stage == 1 else B)
         stage_of = {"preprocess": "preprocess", "tile_scan": "binning", "scatter": "binning", "tile_sort": "binning",
                     "render_fwd": "render_fwd", "render_bwd": "render_bwd", "preprocess_bwd": "preprocess_bwd"}
 
-        # the decoder GEMMs' matrix roof: exact fp32 on the bf16 pipe costs 6 bf16 MFMA flops per algorithmic flop
-        # (split mode, the default), so the algorithmic-flop peak is 2500 / 6 TFLOP/s; 157.3 with GANET_MFMA=f32
-        split = _native.ganet().ganet_get_mfma_mode() == 1
-        mfma_peak = MFMA_BF16_PEAK_TF / SPLIT_PRODUCTS if split else MFMA_F32_PEAK_TF
+        # the decoder GEMMs' matrix roof: exact fp32 on the bf16 pipe costs 6 bf16 MFMA flops per algorithmic flop,
+        # so the algorithmic-flop peak is 2500 / 6 TFLOP/s
+        split = True
+        mfma_peak = MFMA_BF16_PEAK_TF / SPLIT_PRODUCTS
 
         def describe(name, ms, n, iters):
             """per-kernel-family record: time, and its algorithmic work priced against its roofline"""

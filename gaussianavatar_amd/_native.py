@@ -53,8 +53,8 @@ class GsrLayout(ctypes.Structure):
 
 
 def _load(name: str) -> ctypes.CDLL:
-    # GA_LIB_DIR: development switch to A/B an alternative build of the libraries on the GPU box
-    path = os.path.join(os.environ.get("GA_LIB_DIR") or _LIBDIR, name)
+    from ._dev import knobs                     # GA_DEV=lib_dir=...: A/B an alternative build (development only)
+    path = os.path.join(knobs.lib_dir or _LIBDIR, name)
     if not os.path.exists(path):
         raise NativeLibraryMissing(
             f"{path} not found: the HIP extension is not built. Run "
@@ -151,7 +151,7 @@ GANET_SYMBOLS = ["ganet_linear_wgrad_workspace", "ganet_linear_wgrad", "ganet_bn
                  "ganet_decoder_bwd_workspace", "ganet_decoder_bwd",
                  "ganet_decode_pack_fwd", "ganet_decode_pack_bwd", "ganet_mean_sq_fwd", "ganet_mean_sq_bwd", "ganet_weighted_sum_fwd", "ganet_weighted_sum_bwd", "ganet_upsample_cat_fwd", "ganet_upsample_cat_bwd", "ganet_profile_enable", "ganet_profile_count", "ganet_profile_read", "ganet_profile_kernel_name",
                  "ganet_conv5_packed_bytes", "ganet_conv5_pack", "ganet_conv5_apply",
-                 "ganet_conv5_wgrad_workspace", "ganet_conv5_wgrad", "ganet_get_mfma_mode", "ganet_set_mfma_mode", "ganet_last_error", "ganet_abi_version"]
+                 "ganet_conv5_wgrad_workspace", "ganet_conv5_wgrad", "ganet_last_error", "ganet_abi_version"]
 
 
 class GanetWgradJob(ctypes.Structure):
@@ -276,9 +276,6 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_conv5_wgrad_workspace.argtypes = [c_int32, c_int32, c_int32]
         lib.ganet_conv5_wgrad.restype = c_int
         lib.ganet_conv5_wgrad.argtypes = [c_int32, c_int32, c_int32, P, P, P, P, c_size_t, P]
-        lib.ganet_get_mfma_mode.restype = c_int
-        lib.ganet_set_mfma_mode.argtypes = [c_int]
-        lib.ganet_set_mfma_mode.restype = None
         lib.ganet_last_error.restype = c_char_p
         lib.ganet_abi_version.restype = c_int
         if lib.ganet_abi_version() != 4:

@@ -223,7 +223,7 @@ class AvatarModel:
             if parallel.world_size() > 1 and self.device.type == "cuda":
                 # the frames of a batch are spread over the ranks: BatchNorm statistics over the global batch,
                 # as in the single-process reference (state-dict compatible)
-                self.pose_encoder = torch.nn.SyncBatchNorm.convert_sync_batchnorm(self.pose_encoder)
+                self.pose_encoder = torch.nn.SyncBatchNorm.convert_sync_batchnorm(self.pose_encoder, parallel.process_group())
         self.sync_replicas()
 
     def training_setup(self):
@@ -235,14 +235,12 @@ class AvatarModel:
             groups = [{"params": self.net.parameters(), "lr": o.lr_net * 0.1},
                       {"params": self.pose_encoder.parameters(), "lr": o.lr_net}]
         # same update rule as the reference's torch.optim.Adam (model/avatar_model.py:152-161); on a HIP
-        # device it is applied to every tensor of every group with one launch (optim.Adam;
-        # GA_FUSED_ADAM=torch selects torch's fused implementation, =0 its default one)
-        mode = os.environ.get("GA_FUSED_ADAM", "1") if self.geo_feature.is_cuda else "0"
-        if mode == "1":
+        # device it is applied to every tensor of every group with one launch (optim.Adam, state-dict compatible)
+        if self.geo_feature.is_cuda:
             from .optim import Adam
             self.optimizer = Adam(groups)
         else:
-            self.optimizer = torch.optim.Adam(groups, fused=True) if mode == "torch" else torch.optim.Adam(groups)
+            self.optimizer = torch.optim.Adam(groups)
         self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, o.sched_milestones, gamma=0.1)
 
     # ------------------------------------------------------------------ checkpoints
@@ -417,7 +415,7 @@ class AvatarModel:
         return offset_loss, scale_loss, point_res, scale1.expand(-1, -1, 3), pshs
 
     def _decode_texel_sharded(self, B, uv, scale_mult):
-        """Stage 1 with GA_DP_MODE=texels (parallel.py): this rank evaluates the decoder on its slice of the
+        """Stage 1 with parallel.set_mode("texels"): this rank evaluates the decoder on its slice of the
         UV map only (BatchNorm statistics synchronised over ranks), packs its valid texels, and the full
         [N,7] record buffer is assembled on every rank with one all-reduce. Returned losses carry the global
         values; their gradients reach this rank's slice only (parameter gradients are summed in step())."""

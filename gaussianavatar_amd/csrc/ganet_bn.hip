@@ -323,17 +323,6 @@ ProfScope::~ProfScope() {
   if (slot < (int)g_prof_recs.size()) (void)hipEventRecord(g_prof_recs[slot].stop, stream);
 }
 
-namespace {
-int g_mfma_mode = -1;
-}
-int mfma_mode() {
-  if (g_mfma_mode < 0) {
-    const char* e = getenv("GANET_MFMA");
-    g_mfma_mode = (e && (!strcmp(e, "f32") || !strcmp(e, "0"))) ? 0 : 1;
-  }
-  return g_mfma_mode;
-}
-
 int check_hip(hipError_t e, const char* what) {
   if (e == hipSuccess) return 0;
   set_error("%s: %s", what, hipGetErrorString(e));
@@ -436,8 +425,6 @@ const char* ganet_profile_kernel_name(int id) {
 }
 
 const char* ganet_last_error(void) { return g_err; }
-int ganet_get_mfma_mode(void) { return mfma_mode(); }
-void ganet_set_mfma_mode(int mode) { g_mfma_mode = mode ? 1 : 0; }
 int ganet_abi_version(void) { return GANET_ABI_VERSION; }
 
 }  // extern "C"

@@ -19,9 +19,6 @@ struct ProfScope {
   hipStream_t stream;
 };
 
-// 0 = exact fp32-MFMA decoder kernels, 1 = split-bf16 kernels (ganet_split.h) wherever a shape has one.
-// Default 1; the environment variable GANET_MFMA=f32 or ganet_set_mfma_mode(0) selects the fp32 kernels.
-int mfma_mode();
 // ganet_mlp_split.hip / ganet_wgrad_split.hip: return -1 when the shape has no split kernel
 int mlp_fwd_split(int64_t M, int N, int K1, int K2, const float* x1, int64_t ld1, const float* x2, int64_t ld2,
                   const float* in_scale, const float* in_shift, const float* W, const float* bias, float* z,

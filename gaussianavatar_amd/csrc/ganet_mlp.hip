@@ -1,4 +1,4 @@
-// ganet_mlp.hip — fused layers of the decoder MLP on fp32 MFMA ("tall-skinny" GEMMs).
+// ganet_mlp.hip — entry points of the fused decoder layers (include/ganet.h) and the kernels around the GEMMs:
 //
 //   Z[M,N] = [ X1 | softplus(scale . X2 + shift) ] [M, K1+K2] . W[N, K1+K2]^T + b
 //
@@ -11,19 +11,12 @@
 // pass over the [M,128] tensors exists any more. X1 is an un-activated operand (the decoder input,
 // and the DeepSDF-style skip of conv5 = cat[x, y4]).
 //
-// Mapping (v_mfma_f32_32x32x2_f32, exact fp32; a wave owns slabs of 32 rows x all N columns):
-//   * W stays in LDS for the whole kernel as [N][K+4] (the +4 makes ds_read_b128 conflict-free);
-//     one 512-thread workgroup per CU shares it (up to 104 KB of the 160 KB);
-//   * the A fragment of lane (row = lane & 31, h = lane >> 5) for k-block `b` is ONE 16-byte load
-//     X[row][8 b + 4 h .. +3]: the order of the reduction over k is free, so MFMA step t of the
-//     block pairs k = 8 b + t (h = 0) with k = 8 b + 4 + t (h = 1); the B fragment of that step is
-//     W[n][8 b + 4 h + t] — one ds_read_b128 per 32-column tile and k-block;
-//   * software pipeline without a second buffer: as soon as k-block b has been consumed its four
-//     registers are refilled with block b of the wave's NEXT slab, so every global load has a whole
-//     slab of MFMA work (~16k cycles) to land.
-//
-// The matching weight gradient (wgrad_act_kernel) recomputes the activation of X2 the same way:
-//   dW[n,k] = sum_m G[m,n] . softplus(scale_k X2[m,k] + shift_k),   db[n] = sum_m G[m,n]
+// The GEMMs themselves run on the bf16 matrix pipe with exactly split fp32 operands (ganet_split.h,
+// ganet_mlp_split.hip, ganet_wgrad_split.hip, ganet_layer_bwd.hip); round 1's v_mfma_f32_32x32x2_f32 forward and
+// data-gradient kernels were removed in round 3 (every shape they served has a split kernel, which is as accurate
+// and 1.5-1.6x faster). What is left here: the statistics kernel, the fp32-MFMA weight gradient wgrad_act_kernel —
+// the generic fallback for shapes without a split kernel (the 3/1/3-column heads: one 32-column tile) — and the
+// deterministic reductions of the weight-gradient partial tiles.
 #include <cstdint>
 
 #include "ganet.h"
@@ -34,212 +27,7 @@ namespace ganet {
 
 namespace {
 
-#ifndef GANET_FWD_WG
-#define GANET_FWD_WG 512
-#endif
-#ifndef GANET_FWD_WPE
-#define GANET_FWD_WPE 2
-#endif
-#ifndef GANET_FWD_BLOCKS
-#define GANET_FWD_BLOCKS 256
-#endif
-constexpr int WG = GANET_FWD_WG;      // 8 waves, one workgroup per CU
-constexpr int WAVES = WG / 64;
-constexpr int SLAB = 32;              // rows per wave step
-constexpr int FWD_BLOCKS = GANET_FWD_BLOCKS;
-template <int K1B, int K2B, int NT>
-__global__ void __attribute__((amdgpu_flat_work_group_size(WG, WG), amdgpu_waves_per_eu(GANET_FWD_WPE, GANET_FWD_WPE)))
-mlp_fwd_kernel(int64_t M, int N, const float* __restrict__ x1, int64_t ld1,
-               const float* __restrict__ x2, int64_t ld2, const float* __restrict__ in_scale,
-               const float* __restrict__ in_shift, const float* __restrict__ W,
-               const float* __restrict__ bias, float* __restrict__ z, int64_t ldz,
-               float* __restrict__ col_part, const float* __restrict__ stat_shift, int reverse) {
-  constexpr int KB = K1B + K2B;         // k-blocks of 8
-  constexpr int K = 8 * KB;
-  constexpr int LDW4 = K / 4 + 1;       // row stride of W in LDS, in float4
-  constexpr int NP = NT * 32;
-  extern __shared__ float4 s_mem[];     // W [NP][LDW4] | scale [2*K2B] | shift [2*K2B]   (float4 units)
-  float4* s_w = s_mem;
-  float4* s_sc = s_mem + NP * LDW4;
-  float4* s_sh = s_sc + 2 * K2B;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: slab loop on SGPRs
-  const int lane = threadIdx.x & 63;
-  const int h = lane >> 5, col = lane & 31;
-
-  {   // stage W: all global loads first (branch-free, clamped row), then the LDS stores
-    constexpr int PER = (NP * (K / 4) + WG - 1) / WG;
-    float4 wv[PER];
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int i = min((int)threadIdx.x + j * WG, NP * (K / 4) - 1);
-      const int n = i / (K / 4), k4 = i - n * (K / 4);
-      wv[j] = *reinterpret_cast<const float4*>(W + (size_t)min(n, N - 1) * K + 4 * k4);
-    }
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int i = threadIdx.x + j * WG;
-      const int n = i / (K / 4), k4 = i - n * (K / 4);
-      // columns of the activated operand carry the ln 2 of the log2-unit softplus (ganet_mlp_common.h)
-      const float f = (n < N) ? ((k4 >= 2 * K1B) ? kLn2 : 1.0f) : 0.0f;
-      if (i < NP * (K / 4)) s_w[n * LDW4 + k4] = make_float4(wv[j].x * f, wv[j].y * f, wv[j].z * f, wv[j].w * f);
-    }
-  }
-  for (int i = threadIdx.x; i < 2 * K2B; i += WG) {     // folded BatchNorm, pre-multiplied by log2(e)
-    const float4 a = *reinterpret_cast<const float4*>(in_scale + 4 * i);
-    const float4 c = *reinterpret_cast<const float4*>(in_shift + 4 * i);
-    s_sc[i] = make_float4(a.x * kLog2e, a.y * kLog2e, a.z * kLog2e, a.w * kLog2e);
-    s_sh[i] = make_float4(c.x * kLog2e, c.y * kLog2e, c.z * kLog2e, c.w * kLog2e);
-  }
-  __syncthreads();
-
-  float csum[NT], csq[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) { csum[t] = 0.f; csq[t] = 0.f; }
-
-  const int64_t nslab = (M + SLAB - 1) / SLAB;
-  const int64_t wave_global = (int64_t)blockIdx.x * WAVES + wave;
-  const int64_t wave_stride = (int64_t)gridDim.x * WAVES;
-
-  // A-operand pipeline: a ring of D k-blocks (float4 per lane each). Block i of the wave's block
-  // sequence (slab after slab) sits in slot i % D; as soon as it has been consumed the slot is
-  // refilled with block i + D (same slab, or the wave's next slab), so every global load has
-  // D x 16 MFMAs (>= 5k cycles) to land and the ring costs 4 D registers instead of 4 KB.
-  constexpr int D = (KB % 8 == 0) ? 8 : ((KB % 5 == 0) ? 5 : KB);
-  static_assert(KB % D == 0, "ring depth must divide the number of k-blocks");
-  const float *p1c = nullptr, *p2c = nullptr, *p1n = nullptr, *p2n = nullptr;
-  // reverse: the slabs are walked from the last row to the first (the caller alternates the direction
-  // from layer to layer so that a kernel starts on the rows the previous one touched last, which are
-  // the ones still resident in the 256 MiB Infinity Cache)
-  auto phys = [&](int64_t slab) { return reverse ? nslab - 1 - slab : slab; };
-  auto point_at = [&](int64_t slab, const float*& q1, const float*& q2) {
-    const int64_t row = min(phys(slab) * SLAB + col, M - 1);
-    if (K1B > 0) q1 = x1 + row * ld1 + 4 * h;
-    if (K2B > 0) q2 = x2 + row * ld2 + 4 * h;
-  };
-  auto load_block = [&](const float* q1, const float* q2, int b) -> float4 {
-    return b < K1B ? *reinterpret_cast<const float4*>(q1 + 8 * b)
-                   : *reinterpret_cast<const float4*>(q2 + 8 * (b - K1B));
-  };
-  float4 a[D];
-  point_at(min(wave_global, nslab - 1), p1c, p2c);
-#pragma unroll
-  for (int b = 0; b < D; ++b) a[b] = load_block(p1c, p2c, b);
-  float bias_r[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) bias_r[t] = (bias && t * 32 + col < N) ? bias[t * 32 + col] : 0.f;
-  // the column statistics are accumulated about a per-column shift (the BatchNorm layer's running mean):
-  // sum (z - s), sum (z - s)^2 — E[z^2] - mean^2 from raw fp32 sums cancels catastrophically once a
-  // column's |mean| is large against its standard deviation
-  float sshift[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) sshift[t] = (stat_shift && t * 32 + col < N) ? stat_shift[t * 32 + col] : 0.f;
-
-  for (int64_t slab = wave_global; slab < nslab; slab += wave_stride) {
-    point_at(min(slab + wave_stride, nslab - 1), p1n, p2n);   // branch-free prefetch target
-    // W's fragment is the same for every slab; it must stay in LDS (the offset is made opaque:
-    // the compiler would otherwise hoist all KB x NT ds_read_b128 out of this loop and spill)
-    int woff = col * LDW4 + h;
-    int soff = h;
-    asm volatile("" : "+v"(woff), "+v"(soff));
-    f32x16 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-#pragma unroll
-    for (int b = 0; b < KB; ++b) {
-      const int slot = b % D;
-      float av0 = a[slot].x, av1 = a[slot].y, av2 = a[slot].z, av3 = a[slot].w;
-      if (b >= K1B) {
-        const float4 sc = s_sc[soff + 2 * (b - K1B)];
-        const float4 sh = s_sh[soff + 2 * (b - K1B)];
-        av0 = softplus_log2(fmaf(sc.x, av0, sh.x));
-        av1 = softplus_log2(fmaf(sc.y, av1, sh.y));
-        av2 = softplus_log2(fmaf(sc.z, av2, sh.z));
-        av3 = softplus_log2(fmaf(sc.w, av3, sh.w));
-        // the raw values are dead now: refill the slot (activated blocks). The two scheduling
-        // barriers let VALU / LDS / scalar work flow across but pin the load between this block's
-        // and the previous block's MFMAs — left alone, the scheduler sinks the refills to just
-        // before their use and exposes the full HBM latency.
-        __builtin_amdgcn_sched_barrier(kSchedMask);
-        a[slot] = (b + D < KB) ? load_block(p1c, p2c, b + D) : load_block(p1n, p2n, b + D - KB);
-        __builtin_amdgcn_sched_barrier(kSchedMask);
-      }
-      float4 bw[NT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) bw[t] = s_w[woff + t * 32 * LDW4 + 2 * b];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bw[t].x, acc[t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bw[t].y, acc[t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av2, bw[t].z, acc[t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av3, bw[t].w, acc[t], 0, 0, 0);
-      // identity blocks feed the MFMAs straight from the slot: refill once they have been issued
-      if (b < K1B) {
-        __builtin_amdgcn_sched_barrier(kSchedMask);
-        a[slot] = (b + D < KB) ? load_block(p1c, p2c, b + D) : load_block(p1n, p2n, b + D - KB);
-        __builtin_amdgcn_sched_barrier(kSchedMask);
-      }
-    }
-    p1c = p1n; p2c = p2n;
-    // epilogue: + bias, store, column statistics. C/D layout of the 32x32 MFMA: column = lane & 31,
-    // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const int64_t row0 = phys(slab) * SLAB;
-    if (row0 + SLAB <= M && N == NP) {
-      float* zr = z + (row0 + 4 * h) * ldz + col;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const float bn_ = bias_r[t];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = acc[t][r] + bn_;
-          zr[((r & 3) + 8 * (r >> 2)) * ldz + t * 32] = v;
-          const float d = v - sshift[t];
-          csum[t] += d;
-          csq[t] = fmaf(d, d, csq[t]);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int n = t * 32 + col;
-        const float bn_ = bias_r[t];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (row < M && n < N) {
-            const float v = acc[t][r] + bn_;
-            z[row * ldz + n] = v;
-            const float d = v - sshift[t];
-            csum[t] += d;
-            csq[t] = fmaf(d, d, csq[t]);
-          }
-        }
-      }
-    }
-  }
-  if (col_part) {
-    // per-workgroup partial column sums -> [gridDim.x][2][NP]: the waves combine through LDS (W is
-    // dead by now), in fixed order
-    __syncthreads();
-    float* s_red = reinterpret_cast<float*>(s_mem);        // [WAVES][2 * NP]
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const float s = csum[t] + __shfl_xor(csum[t], 32);
-      const float q = csq[t] + __shfl_xor(csq[t], 32);
-      if (h == 0) { s_red[wave * 2 * NP + t * 32 + col] = s; s_red[wave * 2 * NP + NP + t * 32 + col] = q; }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * NP; i += WG) {
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < WAVES; ++w) v += s_red[w * 2 * NP + i];
-      col_part[(size_t)blockIdx.x * 2 * NP + i] = v;
-    }
-  }
-}
+constexpr int FWD_BLOCKS = 256;       // workgroups of the forward GEMM = rows of its column-sum partials
 
 // One workgroup per column: sum the per-workgroup partials in double, then mean / rstd, the folded
 // scale = gamma * rstd and shift = beta - mean * scale the next layer's prologue applies, and the
@@ -638,40 +426,13 @@ int ganet_mlp_fwd(int64_t M, int32_t N, int32_t K1, int32_t K2, const float* x1,
     return 1;
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (mfma_mode() == 1) {
-    const int rc = mlp_fwd_split(M, N, K1, K2, x1, ld1, x2, ld2, in_scale, in_shift, W, bias, z, ldz, col_part,
-                                 stat_shift, row_order == 2 ? 1 : 0, stream);
-    if (rc >= 0) return rc;
-  }
-  const int nt = (N + 31) / 32;
-  const dim3 grid(FWD_BLOCKS), block(WG);
-#define LAUNCH(A, B, T)                                                                            \
-  do {                                                                                             \
-    constexpr int Kc = 8 * ((A) + (B));                                                            \
-    const size_t lds = ((size_t)(T) * 32 * (Kc / 4 + 1) + 4 * (B)) * sizeof(float4);               \
-    static bool attr_set = false;                                                                  \
-    if (!attr_set) {                                                                               \
-      if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<A, B, T>),    \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),     \
-                    "hipFuncSetAttribute")) return 3;                                             \
-      attr_set = true;                                                                             \
-    }                                                                                              \
-    ProfScope prof_(K_MLP_FWD, stream);                                                            \
-    hipLaunchKernelGGL((mlp_fwd_kernel<A, B, T>), grid, block, lds, stream, M, N, x1, ld1, x2, ld2, \
-                       in_scale, in_shift, W, bias, z, ldz, col_part, stat_shift, row_order == 2 ? 1 : 0);     \
-  } while (0)
-  // the decoder's shapes: input layer (K1 = 72 = 66 padded), hidden layers (K2 = 128), the skip
-  // layer (72 + 128) and the 3/1/3-column output heads (one 32-column tile)
-  if (K1 == 72 && K2 == 0 && nt == 4) LAUNCH(9, 0, 4);
-  else if (K1 == 0 && K2 == 128 && nt == 4) LAUNCH(0, 16, 4);
-  else if (K1 == 72 && K2 == 128 && nt == 4) LAUNCH(9, 16, 4);
-  else if (K1 == 0 && K2 == 128 && nt == 1) LAUNCH(0, 16, 1);
-  else {
-    set_error("ganet_mlp_fwd: unsupported shape N=%d K1=%d K2=%d", N, K1, K2);
-    return 4;
-  }
-#undef LAUNCH
-  return check_hip(hipGetLastError(), "mlp_fwd_kernel");
+  // the decoder's shapes: input layer (K1 = 72 = 66 padded), hidden layers (K2 = 128), the skip layer (72 + 128)
+  // and the 3/1/3-column output heads (one 32-column tile)
+  const int rc = mlp_fwd_split(M, N, K1, K2, x1, ld1, x2, ld2, in_scale, in_shift, W, bias, z, ldz, col_part,
+                               stat_shift, row_order == 2 ? 1 : 0, stream);
+  if (rc >= 0) return rc;
+  set_error("ganet_mlp_fwd: unsupported shape N=%d K1=%d K2=%d", N, K1, K2);
+  return 4;
 }
 
 int ganet_mlp_stats(int64_t M, int32_t N, const float* col_part, const float* gamma,
@@ -724,9 +485,7 @@ int ganet_wgrad_act(int64_t M, int32_t N, int32_t K, const float* g, int64_t ldg
   const dim3 grid(nb), block(WG_W);
   const int nt = N > 32 ? 4 : 1, kt = K > 96 ? 4 : 3;
   const bool act = in_scale != nullptr, gpro = gz != nullptr;
-  int rc = -1;
-  if (mfma_mode() == 1)
-    rc = wgrad_split(M, N, K, g, ldg, gz, ldgz, gcoef, x, ldx, in_scale, in_shift, partial, nb, row_order, stream);
+  int rc = wgrad_split(M, N, K, g, ldg, gz, ldgz, gcoef, x, ldx, in_scale, in_shift, partial, nb, row_order, stream);
   if (rc > 0) return rc;
   if (rc < 0) {
 #define LAUNCH(T, KT_, A, G)                                                                       \

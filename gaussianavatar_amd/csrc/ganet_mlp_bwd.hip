@@ -11,8 +11,8 @@
 //
 // so once the two column sums sum_m G_i and sum_m G_i z_i are known, dz_i is a per-column affine
 // combination of the two stored tensors G_i and z_i and never has to be materialised:
-//   * mlp_bwd_kernel computes dL/dy_src = dz_i . W_i (same streamed-M MFMA pipeline as the forward
-//     kernel, A operand assembled from G_i and z_i on load) and, in its epilogue, multiplies by
+//   * the data-gradient kernel (mlp_bwd_split_kernel, ganet_mlp_split.hip; ganet_layer_bwd.hip where the weight
+//     gradient rides along) computes dL/dy_src = dz_i . W_i (A operand assembled from G_i and z_i on load) and, in its epilogue, multiplies by
 //     softplus'(u_src) — i.e. writes G_src — and accumulates sum G_src, sum G_src z_src;
 //   * bwd_stats_kernel turns those sums into (A, q, p) of the source layer plus d gamma / d beta;
 //   * the weight gradient (ganet_wgrad_act, GPRO variant) assembles dz_i the same way.
@@ -36,187 +36,6 @@ constexpr int SLAB = 32;
 constexpr int BWD_BLOCKS = 256;
 constexpr int HEAD_BLOCKS = 512;
 
-// out[M,O] (+)= (A G + q Z + p)[M,128] . W[128, 0:O] ; SIG: out *= softplus'(src_scale src_z + src_shift)
-template <int NT, bool ACCUM, bool SIG>
-__global__ void __attribute__((amdgpu_flat_work_group_size(WG, WG), amdgpu_waves_per_eu(2, 2)))
-mlp_bwd_kernel(int64_t M, int O, const float* __restrict__ g, int64_t ldg,
-               const float* __restrict__ gz, int64_t ldgz, const float* __restrict__ gcoef,
-               const float* __restrict__ W, int64_t ldw, float* __restrict__ out, int64_t ldo,
-               const float* __restrict__ src_z, int64_t ld_src, const float* __restrict__ src_scale,
-               const float* __restrict__ src_shift, float* __restrict__ col_part, int reverse) {
-  constexpr int KB = 16, K = 128;
-  constexpr int LDW4 = K / 4 + 1;
-  constexpr int NP = NT * 32;
-  constexpr int D = 4;                  // ring depth (k-blocks); two operands per slot
-  extern __shared__ float4 s_mem[];     // Wt [NP][LDW4] | A [32] | q [32] | p [32]   (float4 units)
-  float4* s_w = s_mem;
-  float4* s_cA = s_mem + NP * LDW4;
-  float4* s_cq = s_cA + 32;
-  float4* s_cp = s_cq + 32;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const int h = lane >> 5, col = lane & 31;
-
-  {   // stage W[128(n)][ldw] transposed into s_w[o][n] (row o of the LDS image = column o of W):
-      // all global loads first (scalar: W may be a column slice with any alignment), then LDS stores
-    constexpr int PER = (K * NP + WG - 1) / WG;            // elements per thread
-    float* s_wf = reinterpret_cast<float*>(s_w);
-    float wv[PER];
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int i = min((int)threadIdx.x + j * WG, K * NP - 1);
-      const int n = i / NP, o = i - n * NP;               // consecutive threads: consecutive columns o
-      wv[j] = W[(size_t)n * ldw + min(o, O - 1)];
-    }
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int i = threadIdx.x + j * WG;
-      const int n = i / NP, o = i - n * NP;
-      if (i < K * NP) s_wf[o * (4 * LDW4) + n] = o < O ? wv[j] : 0.f;
-    }
-  }
-  for (int i = threadIdx.x; i < 32; i += WG) {
-    s_cA[i] = *reinterpret_cast<const float4*>(gcoef + 4 * i);
-    s_cq[i] = *reinterpret_cast<const float4*>(gcoef + K + 4 * i);
-    s_cp[i] = *reinterpret_cast<const float4*>(gcoef + 2 * K + 4 * i);
-  }
-  __syncthreads();
-
-  float csum[NT], csz[NT], ssc[NT], ssh[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    csum[t] = 0.f; csz[t] = 0.f;
-    const int o = min(t * 32 + col, O - 1);
-    ssc[t] = SIG ? src_scale[o] * kLog2e : 0.f;          // log2 units (ganet_mlp_common.h)
-    ssh[t] = SIG ? src_shift[o] * kLog2e : 0.f;
-  }
-
-  const int64_t nslab = (M + SLAB - 1) / SLAB;
-  const int64_t wave_global = (int64_t)blockIdx.x * WAVES + wave;
-  const int64_t wave_stride = (int64_t)gridDim.x * WAVES;
-
-  const float *pgc, *pzc, *pgn, *pzn;
-  auto phys = [&](int64_t slab) { return reverse ? nslab - 1 - slab : slab; };   // see mlp_fwd_kernel
-  auto point_at = [&](int64_t slab, const float*& qg, const float*& qz) {
-    const int64_t row = min(phys(slab) * SLAB + col, M - 1);
-    qg = g + row * ldg + 4 * h;
-    qz = gz + row * ldgz + 4 * h;
-  };
-  float4 ag[D], az[D];
-  point_at(min(wave_global, nslab - 1), pgc, pzc);
-#pragma unroll
-  for (int b = 0; b < D; ++b) {
-    ag[b] = *reinterpret_cast<const float4*>(pgc + 8 * b);
-    az[b] = *reinterpret_cast<const float4*>(pzc + 8 * b);
-  }
-
-  for (int64_t slab = wave_global; slab < nslab; slab += wave_stride) {
-    point_at(min(slab + wave_stride, nslab - 1), pgn, pzn);
-    int woff = col * LDW4 + h;
-    int soff = h;
-    asm volatile("" : "+v"(woff), "+v"(soff));      // keep Wt's fragment in LDS (see ganet_mlp.hip)
-    f32x16 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-#pragma unroll
-    for (int b = 0; b < KB; ++b) {
-      const int slot = b % D;
-      const float4 cA = s_cA[soff + 2 * b], cq = s_cq[soff + 2 * b], cp = s_cp[soff + 2 * b];
-      const float av0 = fmaf(cA.x, ag[slot].x, fmaf(cq.x, az[slot].x, cp.x));
-      const float av1 = fmaf(cA.y, ag[slot].y, fmaf(cq.y, az[slot].y, cp.y));
-      const float av2 = fmaf(cA.z, ag[slot].z, fmaf(cq.z, az[slot].z, cp.z));
-      const float av3 = fmaf(cA.w, ag[slot].w, fmaf(cq.w, az[slot].w, cp.w));
-      // raw values dead: refill the slot, pinned between the MFMA groups (see ganet_mlp.hip)
-      __builtin_amdgcn_sched_barrier(kSchedMask);
-      if (b + D < KB) {
-        ag[slot] = *reinterpret_cast<const float4*>(pgc + 8 * (b + D));
-        az[slot] = *reinterpret_cast<const float4*>(pzc + 8 * (b + D));
-      } else {
-        ag[slot] = *reinterpret_cast<const float4*>(pgn + 8 * (b + D - KB));
-        az[slot] = *reinterpret_cast<const float4*>(pzn + 8 * (b + D - KB));
-      }
-      __builtin_amdgcn_sched_barrier(kSchedMask);
-      float4 bw[NT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) bw[t] = s_w[woff + t * 32 * LDW4 + 2 * b];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bw[t].x, acc[t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bw[t].y, acc[t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av2, bw[t].z, acc[t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av3, bw[t].w, acc[t], 0, 0, 0);
-    }
-    pgc = pgn; pzc = pzn;
-    // epilogue. C/D layout: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const int64_t row0 = phys(slab) * SLAB;
-    const bool full = row0 + SLAB <= M && O == NP;
-    // The source layer's pre-activations are not cached: issue the loads of ALL tiles before the
-    // first use, so that a slab pays one memory latency instead of one per tile.
-    constexpr bool PRELOAD = SIG && !ACCUM;     // (the accumulate variant would spill: per tile there)
-    float sz[PRELOAD ? NT : 1][16];
-    if (PRELOAD) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int o = t * 32 + col;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const bool ok = full || (row < M && o < O);
-          sz[t][r] = src_z[(ok ? row : 0) * ld_src + (ok ? o : 0)];
-        }
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int o = t * 32 + col;
-      float ex[16], szt[16];
-      if (ACCUM) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const bool ok = full || (row < M && o < O);
-          ex[r] = out[(ok ? row : 0) * ldo + (ok ? o : 0)];
-          if (SIG) szt[r] = src_z[(ok ? row : 0) * ld_src + (ok ? o : 0)];
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const bool ok = full || (row < M && o < O);
-        float v = acc[t][r];
-        if (ACCUM) v += ex[r];
-        if (SIG) {
-          const float zv = PRELOAD ? sz[PRELOAD ? t : 0][r] : szt[r];
-          v *= sigmoid_log2(fmaf(ssc[t], zv, ssh[t]));
-          if (ok) { csum[t] += v; csz[t] = fmaf(v, zv, csz[t]); }
-        }
-        if (ok) out[row * ldo + o] = v;
-      }
-    }
-  }
-  if (SIG && col_part) {
-    // per-workgroup partial sums -> [gridDim.x][2][128], combined through LDS in fixed order
-    __syncthreads();
-    float* s_red = reinterpret_cast<float*>(s_mem);        // [WAVES][256]
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const float s = csum[t] + __shfl_xor(csum[t], 32);
-      const float q = csz[t] + __shfl_xor(csz[t], 32);
-      if (h == 0) { s_red[wave * 256 + t * 32 + col] = s; s_red[wave * 256 + 128 + t * 32 + col] = q; }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 256; i += WG) {
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < WAVES; ++w) v += s_red[w * 256 + i];
-      col_part[(size_t)blockIdx.x * 256 + i] = v;
-    }
-  }
-}
 
 // Output heads (conv8*, N8 <= 4 columns): G[m,k] = (sum_n g[m,n] W8[n,k]) softplus'(scale_k z[m,k] +
 // shift_k) for the 128 columns of the head's last hidden layer, plus the two column sums.
@@ -377,18 +196,6 @@ bwd_stats_kernel(int nparts, int64_t M, const float* __restrict__ col_part,
 
 using namespace ganet;
 
-// Row sweep of the data-gradient kernels: -1 (default) = follow the call's row_order (GANET_ROWS_DOWN -> last row
-// first), 0 / 1 = force up / down (dev switch: ganet_dev_set_reverse_bwd, or GANET_BWD_SWEEP=up|down in the environment)
-int g_reverse_bwd = -2;
-extern "C" void ganet_dev_set_reverse_bwd(int r) { g_reverse_bwd = r; }
-static int bwd_reverse(int row_order) {
-  if (g_reverse_bwd == -2) {
-    const char* e = getenv("GANET_BWD_SWEEP");
-    g_reverse_bwd = !e ? -1 : (!strcmp(e, "up") ? 0 : (!strcmp(e, "down") ? 1 : -1));
-  }
-  return g_reverse_bwd >= 0 ? g_reverse_bwd : (row_order == 2 ? 1 : 0);
-}
-
 extern "C" {
 
 int32_t ganet_mlp_bwd_data_parts(void) { return BWD_BLOCKS; }
@@ -407,42 +214,12 @@ int ganet_mlp_bwd_data(int64_t M, int32_t O, const float* g, int64_t ldg, const 
     return 1;
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (mfma_mode() == 1) {
-    const int rc = mlp_bwd_split(M, O, g, ldg, gz, ldgz, gcoef, W, ldw, out, ldo, accumulate != 0, src_z, ld_src,
-                                 src_scale, src_shift, col_part, bwd_reverse(row_order), stream);
-    if (rc >= 0) return rc;
-  }
-  const dim3 grid(BWD_BLOCKS), block(WG);
-  const int nt = O > 96 ? 4 : 3;
-#define LAUNCH(T, AC, SG)                                                                          \
-  do {                                                                                             \
-    const size_t lds = ((size_t)(T) * 32 * 33 + 96) * sizeof(float4);                              \
-    static bool attr_set = false;                                                                  \
-    if (!attr_set) {                                                                               \
-      if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel<T, AC, SG>),  \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),     \
-                    "hipFuncSetAttribute")) return 3;                                              \
-      attr_set = true;                                                                             \
-    }                                                                                              \
-    ProfScope prof_(K_BWD_DATA, stream);                                                           \
-    hipLaunchKernelGGL((mlp_bwd_kernel<T, AC, SG>), grid, block, lds, stream, M, O, g, ldg, gz, ldgz, \
-                       gcoef, W, ldw, out, ldo, src_z, ld_src, src_scale, src_shift, col_part,     \
-                       bwd_reverse(row_order));                                                    \
-  } while (0)
-  const bool acc = accumulate != 0;
-  if (nt == 4 && !acc && sig) LAUNCH(4, false, true);
-  else if (nt == 4 && !acc && !sig) LAUNCH(4, false, false);
-  else if (nt == 4 && acc && !sig) LAUNCH(4, true, false);
-  else if (nt == 4 && acc && sig) LAUNCH(4, true, true);
-  else if (nt == 3 && !acc && !sig) LAUNCH(3, false, false);
-  else if (nt == 3 && acc && !sig) LAUNCH(3, true, false);
-  else {
-    set_error("ganet_mlp_bwd_data: unsupported combination O=%d accumulate=%d sig=%d", O, (int)acc,
-              (int)sig);
-    return 4;
-  }
-#undef LAUNCH
-  return check_hip(hipGetLastError(), "mlp_bwd_kernel");
+  const int rc = mlp_bwd_split(M, O, g, ldg, gz, ldgz, gcoef, W, ldw, out, ldo, accumulate != 0, src_z, ld_src,
+                               src_scale, src_shift, col_part, row_order == GANET_ROWS_DOWN ? 1 : 0, stream);
+  if (rc >= 0) return rc;
+  set_error("ganet_mlp_bwd_data: unsupported combination O=%d (64 < O <= 128) accumulate=%d src=%d", O,
+            (int)(accumulate != 0), (int)sig);
+  return 4;
 }
 
 int ganet_mlp_head_bwd(int64_t M, int32_t N8, const float* g, const float* W8, const float* z,

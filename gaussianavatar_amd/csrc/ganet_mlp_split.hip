@@ -1,6 +1,5 @@
 // ganet_mlp_split.hip — the streamed-M decoder GEMMs (forward layer, data gradient) on the bf16 matrix pipe
-// with exactly split fp32 operands (ganet_split.h). Same interfaces, prologues and epilogues as the fp32-MFMA
-// kernels of ganet_mlp.hip / ganet_mlp_bwd.hip (which stay as the GANET_MFMA=f32 reference):
+// with exactly split fp32 operands (ganet_split.h), behind the entry points of ganet_mlp.hip / ganet_mlp_bwd.hip:
 //
 //   forward        Z[M,N]  = [ X1 | softplus(scale . X2 + shift) ] . W^T + b,  column sums of Z in the epilogue
 //   data gradient  out[M,O] (+)= (A G + q Z + p)[M,128] . W[128, 0:O],  x softplus'(u_src), sums of G_src, G_src z_src

@@ -78,7 +78,5 @@ __device__ __forceinline__ int split_swizzle(int row) {
 template <int RU>
 __device__ __forceinline__ int split_unit(int row, int u) { return row * RU + (u ^ split_swizzle<RU>(row)); }
 
-// 0 = exact fp32 MFMA kernels, 1 = split-bf16 kernels where a shape has one (default; GANET_MFMA=f32 selects 0)
-int mfma_mode();
 
 }  // namespace ganet

@@ -1,6 +1,6 @@
 // ganet_wgrad_split.hip — weight gradient of a decoder layer on the bf16 matrix pipe with exactly split fp32
 // operands (ganet_split.h); same interface, operand prologues and partial-tile workspace as wgrad_act_kernel
-// (ganet_mlp.hip), which stays as the GANET_MFMA=f32 reference:
+// (ganet_mlp.hip: the fp32-MFMA weight gradient, kept for the shapes that have no split kernel):
 //
 //   dW[n,k] = sum_m dz[m,n] . a[m,k],   db[n] = sum_m dz[m,n]        n < 128, k < 32 KT, reduction over M rows
 //   dz = A G + q Z + p  (GPRO)  or  G;      a = softplus(scale x + shift)  (ACT)  or  x

@@ -163,19 +163,6 @@ __device__ __forceinline__ int write_lane_i(int v, int s, int lane) {
   return ((int)(threadIdx.x & (GSR_WAVE - 1)) == lane) ? s : v;
 }
 
-// Development aid, compiled in ONLY with -DGSR_ABLATE_BUILD (tools/build_variant.sh): the environment
-// variable GSR_ABLATE=<bits> then disables parts of the render kernels to attribute time (1 no global
-// atomics, 2 no segment records, 4 no culling, 8 no pixel loop; results are wrong with any bit set). The product library
-// ignores the variable: the flags are the constant 0.
-#ifdef GSR_ABLATE_BUILD
-inline int ablate_flags() {
-  static const int v = [] { const char* e = getenv("GSR_ABLATE"); return e ? atoi(e) : 0; }();
-  return v;
-}
-#else
-constexpr int ablate_flags() { return 0; }
-#endif
-
 struct WaveGeom {
   int wave, lane;
   int bx0, by0;      // the wave's pixel block
@@ -809,7 +796,7 @@ hipError_t launch_render_fwd(const GsrSettings& s, const Dims& d, const Workspac
     hipLaunchKernelGGL(render_fwd_kernel, dim3(32 * ((d.T + 7) / 8), bt.frames), dim3(GSR_TILE_PIX), 0, stream, d.W,
                        d.H, d.gx, d.T, d.max_pairs, d.seg_cap, ws.tile_count, ws.tile_offset, ws.point_list, ws.xyext,
                        ws.conic_opacity, ws.rgb, s.bg, out_color, ws.final_T, ws.n_contrib, ws.seg_entries,
-                       ws.seg_ckpt, ws.seg_info, ws.pix_accum, ws.seg_count, ws.seg_heads, ws.seg_list, ablate_flags(), bt.ws_stride);
+                       ws.seg_ckpt, ws.seg_info, ws.pix_accum, ws.seg_count, ws.seg_heads, ws.seg_list, 0, bt.ws_stride);
   }
   return hipGetLastError();
 }

@@ -8,12 +8,11 @@ exercise), so the two formulations are checked against each other on the GPU box
 from __future__ import annotations
 
 import ctypes
-import os
 
 import torch
 import torch.nn.functional as F
 
-from . import _native, parallel
+from . import _dev, _native, parallel
 
 
 def _ptr(t):
@@ -475,22 +474,19 @@ def _decoder_bn_layers():
     return out
 
 
-# measured on MI355X: riding the head weight gradient on head_bwd is ~3 % SLOWER per iteration than the
-# separate ganet_wgrad_act pass (head_bwd turns VALU-bound), so it stays off; GA_HEAD_RIDE=1 selects it
-_HEAD_RIDE = os.environ.get("GA_HEAD_RIDE", "0") == "1"
 # hidden 128 -> 128 layers: data gradient + weight gradient in ONE pass over the activations
 # (ganet_mlp_bwd_fused, csrc/ganet_layer_bwd.hip): 4 instead of 7 [M,128] tensors through HBM. Used whenever the
 # row count is a multiple of 32; the separate kernels remain for ragged row counts and for the layers whose input
 # is the 72-column decoder input. (Tests switch it off to compare the two formulations.)
-_FUSED_BWD = True
+_FUSED_BWD = _dev.knobs.one_pass_backward
 
 
 # The weight-gradient launches of the decoder backward are off its dependency chain (nothing reads dW before the
-# batched reduction at the end): they are issued on a side stream (GA_WGRAD_STREAM=0: on the main one), ordered by
+# batched reduction at the end): they are issued on a side stream (GA_DEV=wgrad_stream=0: on the main one), ordered by
 # events behind the statistics they need, so that their heads (weight staging, launch latency) fill the tails of the
 # data-gradient kernels. LDS keeps the two kernel families from sharing a CU, so they do not slow each other's main
 # loops. Measured: +1.3 % iterations/s.
-_WGRAD_STREAM = os.environ.get("GA_WGRAD_STREAM", "1") != "0"
+_WGRAD_STREAM = _dev.knobs.wgrad_stream
 _side_streams = {}
 
 
@@ -503,9 +499,8 @@ def _side_stream(device):
 
 class _RowSweep:
     """Alternates GANET_ROWS_UP / GANET_ROWS_DOWN between consecutive big launches of a pass (include/ganet.h:
-    each kernel starts on the rows its predecessor touched last, which are still in the Infinity Cache).
-    GA_ROW_SWEEP=0 keeps every kernel's default order (A/B switch)."""
-    enabled = os.environ.get("GA_ROW_SWEEP", "1") != "0"
+    each kernel starts on the rows its predecessor touched last, which are still in the Infinity Cache)."""
+    enabled = _dev.knobs.row_sweep
 
     def __init__(self):
         self.k = 0
@@ -531,7 +526,7 @@ def _mlp_fwd(lib, M, N, x1, x2, scale, shift, W, bias, col_part, dev, row_order=
 # The whole decoder as one native call each way (csrc/ganet_decoder.hip: the same launch sequence as _DecoderFn below,
 # issued from C). Training mode, single-rank BatchNorm statistics, row count a multiple of 32; everything else — and the
 # tests that compare the two — takes the per-layer path. (Tests switch it off to exercise the per-layer path.)
-_NATIVE_DECODER = True
+_NATIVE_DECODER = _dev.knobs.native_decoder
 
 
 def _native_decoder_ok(dec, M, sync) -> bool:
@@ -616,9 +611,19 @@ class _DecoderFn(torch.autograd.Function):
         zs, stats = [], []            # per BN layer: pre-activation, (mean, rstd, scale, shift)
         sweep = _RowSweep()
 
+        # Synchronised statistics all-reduce sums of (z - shift): every rank must subtract the SAME shift. The running
+        # means are equal on all ranks as long as the replicas were synchronised and stepped together — rather than
+        # rely on that, rank 0's are broadcast (one 11 x 128 message per forward pass) and used as the shifts.
+        sync_shift = None
+        if sync and training and all(getattr(dec, bn).track_running_stats for _, bn in layers):
+            sync_shift = torch.stack([getattr(dec, bn).running_mean for _, bn in layers]).contiguous()
+            parallel.broadcast_(sync_shift)
+
         def stat_shift_of(i):
             """BatchNorm statistics are accumulated about the layer's running mean (sum (z - s), sum (z - s)^2):
             raw fp32 sums would cancel in E[z^2] - mean^2 once |mean| >> std."""
+            if sync_shift is not None:
+                return sync_shift[i]
             bn = getattr(dec, layers[i][1])
             return bn.running_mean if (training and bn.track_running_stats) else None
 
@@ -804,20 +809,10 @@ class _DecoderFn(torch.autograd.Function):
             i6, i7 = 5 + 2 * j, 6 + 2 * j
             g = d_outs[j].contiguous()
             N8 = g.shape[1]
-            # optional (_HEAD_RIDE): the head's own weight gradient rides on head_bwd (same g and z rows)
-            # and its per-workgroup partials join the batched reduction
             Gs[i7] = f32(M, 128)
             _, _, sc7, sh7 = stats[i7]
-            if _HEAD_RIDE:
-                dW, db = f32(N8, 128), f32(N8)
-                jn = njobs[0]
-                ws = wg_ws.data_ptr() + jn * wg_bytes
-                jobs[jn].workspace, jobs[jn].M, jobs[jn].N, jobs[jn].K = ws, M, N8, 128
-                jobs[jn].dW, jobs[jn].db, jobs[jn].nblocks = dW.data_ptr(), db.data_ptr(), n_head
-                njobs[0] = jn + 1
-            else:
-                dW, db = wgrad(g, None, i7)
-                ws = None
+            dW, db = wgrad(g, None, i7)
+            ws = None
             g_out_w[j], g_out_b[j] = dW.unsqueeze(-1), db
             _native.ganet_check(lib.ganet_mlp_head_bwd(M, N8, _ptr(g), _ptr(out_w[j].contiguous()), _ptr(zs[i7]),
                                                        zs[i7].stride(0), _ptr(sc7), _ptr(sh7), _ptr(Gs[i7]),

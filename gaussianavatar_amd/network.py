@@ -109,7 +109,9 @@ class ShapeDecoder(nn.Module):
             # epilogue); the per-layer formulation below is the CPU / unsupported-shape path
             r, s, c = fused.decoder_mlp(self, x, m_global)
             return r, act(s), act(c)
-        if m_global is not None and int(m_global) != x.shape[0]:
+        if m_global is not None and int(m_global) != x.shape[0] and self.training:
+            # (evaluation mode normalises with the running statistics: nothing to synchronise, the per-layer
+            # formulation below serves a rank's share of the rows as it is)
             raise NotImplementedError("synchronised BatchNorm statistics need the fused decoder path "
                                       "(HIP device, hsize 128, softplus, training mode)")
         x1 = self._layer(x, "conv1", "bn1")

@@ -13,15 +13,16 @@ frame. What couples the ranks in stage 1 is only the shared decoder output, henc
            the net backward + Adam step then run redundantly and identically on every rank.
            No parameter-gradient all-reduce, no SyncBN, replicas stay bit-identical.
   stage 2  decoder inputs differ per frame; parameter gradients are averaged with one flat
-           all-reduce (net + pose encoder, ~19 MB). BatchNorm uses per-rank statistics
-           (documented deviation from a single-process global batch).
+           all-reduce (net + pose encoder, ~19 MB). BatchNorm statistics are synchronised over the ranks
+           (fused decoder: all-reduced column sums; pose encoder: SyncBatchNorm), i.e. those of the
+           single-process global batch.
   pose/transl embeddings (sparse, per frame): all-gather of the sparse rows when the pose
            optimiser is active.
 
 Losses are means over the local frames; averaging the exchanged gradients over ranks makes the
 update equal to the reference's update on the global batch (equal frames per rank).
 
-GA_DP_MODE=texels (stage 1) shards the batch-invariant decoder itself, for a FIXED global batch:
+set_mode("texels") (stage 1) shards the batch-invariant decoder itself, for a FIXED global batch:
   rank r evaluates rows [r, r+1) * S^2/R of the UV map; every BatchNorm layer's column sums are all-reduced
   (11 small messages forward, 11 backward), so the statistics are those of the whole map; the packed
   per-Gaussian outputs are assembled on every rank with one all-reduce (5.6 MB) and their gradients come back
@@ -39,6 +40,7 @@ import torch.distributed as dist
 
 _group = None
 _enabled = False
+_mode = "frames"           # stage-1 data parallelism: "frames" or "texels" (set_mode)
 
 
 def init_from_env(backend: Optional[str] = None) -> tuple:
@@ -52,9 +54,9 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            # GA_DIST_BACKEND=gloo lets the multi-rank code path be exercised on a box with
-            # fewer GPUs than ranks (development only; RCCL is the production backend)
-            backend = os.environ.get("GA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+            # (backend="gloo" lets the multi-rank code path be exercised on a box with fewer GPUs than ranks:
+            # development only; RCCL is the production backend)
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -65,6 +67,20 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
 def enable(flag: bool = True, group=None) -> None:
     global _enabled, _group
     _enabled, _group = flag, group
+
+
+def set_mode(mode: str) -> None:
+    """Stage-1 data parallelism: "frames" (default: every rank evaluates the batch-invariant decoder) or "texels"
+    (the decoder itself is sharded by UV texels: fixed global batch), see the module docstring."""
+    global _mode
+    if mode not in ("frames", "texels"):
+        raise ValueError(mode)
+    _mode = mode
+
+
+def process_group():
+    """The process group of the data-parallel ranks (None = the default group)."""
+    return _group
 
 
 def world_size() -> int:
@@ -185,14 +201,21 @@ class ShardedSampler(torch.utils.data.Sampler):
 
 
 def texel_sharding() -> bool:
-    """Stage-1 decoder sharded by UV texels over the ranks (GA_DP_MODE=texels), see the module docstring."""
-    return world_size() > 1 and os.environ.get("GA_DP_MODE", "frames") == "texels"
+    """Stage-1 decoder sharded by UV texels over the ranks (set_mode("texels")), see the module docstring."""
+    return world_size() > 1 and _mode == "texels"
 
 
 def shard_range(total: int) -> tuple:
     """Rows [r0, r1) of `total` owned by this rank (contiguous, sizes differ by at most one)."""
     W, r = world_size(), rank()
     return (total * r) // W, (total * (r + 1)) // W
+
+
+def broadcast_(t: torch.Tensor, src: int = 0) -> torch.Tensor:
+    """In-place broadcast from rank `src` of the data-parallel group."""
+    if world_size() > 1:
+        dist.broadcast(t, src=dist.get_global_rank(_group, src) if _group is not None else src, group=_group)
+    return t
 
 
 def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:

@@ -323,11 +323,9 @@ int ganet_profile_count(void);
 int ganet_profile_read(double* ms_sum, int64_t* launches, int reset);
 const char* ganet_profile_kernel_name(int id);
 
-/* Decoder GEMM arithmetic: 1 (default) = fp32 operands split exactly into three bf16 pieces, six bf16 MFMAs per
- * step accumulated in fp32 (csrc/ganet_split.h: fp32-accurate, 6/16 of the fp32-MFMA pipe time); 0 = the
- * v_mfma_f32_32x32x2_f32 kernels. Environment: GANET_MFMA=f32 selects 0 at first use. */
-int ganet_get_mfma_mode(void);
-void ganet_set_mfma_mode(int mode);
+/* Decoder GEMM arithmetic (not switchable: the library has no process-global state besides the optional profiling):
+ * fp32 operands split exactly into three bf16 pieces, six bf16 MFMAs per step accumulated in fp32 (csrc/ganet_split.h:
+ * fp32-accurate against float64, 6/16 of the fp32-MFMA pipe time). */
 const char* ganet_last_error(void);
 int ganet_abi_version(void);
 

@@ -101,10 +101,5 @@ def test_net_kernels_reject_bad_arguments_before_touching_the_device():
     assert lib.ganet_mlp_fwd(0, 128, 0, 128, None, 0, None, 0, None, None, None, None, None, 0, None, None, 0, None) == 1
     assert b"ganet_mlp_fwd" in lib.ganet_last_error()
     assert lib.ganet_wgrad_act_workspace(262144, 128, 128) == 256 * (128 * 128 + 128) * 4
-    # the arithmetic switch (no device needed): default = split operands on the bf16 pipe
-    mode = lib.ganet_get_mfma_mode()
-    assert mode in (0, 1)
-    lib.ganet_set_mfma_mode(0)
-    assert lib.ganet_get_mfma_mode() == 0
-    lib.ganet_set_mfma_mode(mode)
-    assert lib.ganet_get_mfma_mode() == mode
+    # no process-global arithmetic switch any more (round-2 review): the symbol must be gone
+    assert not hasattr(lib, "ganet_set_mfma_mode")

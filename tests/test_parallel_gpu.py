@@ -1,5 +1,5 @@
 """Multi-rank runs of the FULL hot path on the GPU: two processes share GPU 0 and talk over gloo
-(the collectives are the ones RCCL performs on a multi-GPU node; GA_SHARE_DEVICE0 / GA_DIST_BACKEND are
+(the collectives are the ones RCCL performs on a multi-GPU node; sharing GPU 0 with the gloo backend is
 the development switches of gaussianavatar_amd/parallel.py). Each rank runs AvatarModel.train_stage1 on its
 own frames — LBS -> feature net -> skinning -> rasterizer -> L1/DSSIM -> backward -> Adam — and the result
 must equal ONE process training on the global batch."""
@@ -76,11 +76,11 @@ def _iterate(m, op, frames, steps=2, stage=1):
 def _worker(rank, world, port, ret, mode, stage=1):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port), GA_SHARE_DEVICE0="1", GA_DIST_BACKEND="gloo")
-    if mode:
-        os.environ["GA_DP_MODE"] = mode
+                      MASTER_PORT=str(port))
     from gaussianavatar_amd import parallel
-    parallel.init_from_env()
+    if mode:
+        parallel.set_mode(mode)
+    parallel.init_from_env(backend="gloo")          # both ranks share GPU 0: gloo carries the collectives
     torch.cuda.set_device(0)
     torch.manual_seed(1000 + rank)                 # replicas start DIFFERENT: sync_replicas must fix that
     m, op = _build(2, stage)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/build_lbwd_variant.sh <outdir> [-D flags...]: libganet_hip.so with ganet_layer_bwd.hip rebuilt with the
-# flags (other objects from the product build); libgsr / libgalbs copied. Select with GA_LIB_DIR=<outdir>.
+# flags (other objects from the product build); libgsr / libgalbs copied. Select with GA_DEV=lib_dir=<outdir>.
 set -e
 out=$1; shift
 mkdir -p $out

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/build_variant.sh <outdir> [extra hipcc flags...]
 #   -> alternative libganet_hip.so AND libgsr_hip.so built with the extra flags, for A/B runs
-#      (select them on the GPU box with GA_LIB_DIR=<outdir>); libgalbs_hip.so is copied.
+#      (select them on the GPU box with GA_DEV=lib_dir=<outdir>); libgalbs_hip.so is copied.
 #   e.g. tools/build_variant.sh build_ablate -DGSR_ABLATE_BUILD   (then GSR_ABLATE=<bits> is honoured)
 set -e
 out=$1; shift

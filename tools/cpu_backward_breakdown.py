@@ -57,7 +57,7 @@ for i in range(N):
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-print("GA_WGRAD_STREAM", os.environ.get("GA_WGRAD_STREAM", "1"), " wall/iter %.3f ms  CPU loop %.3f ms  drain %.1f ms" % (1e3 * (t2 - t0) / N, 1e3 * (t1 - t0) / N, 1e3 * (t2 - t1)))
+print("GA_DEV", os.environ.get("GA_DEV", ""), " wall/iter %.3f ms  CPU loop %.3f ms  drain %.1f ms" % (1e3 * (t2 - t0) / N, 1e3 * (t1 - t0) / N, 1e3 * (t2 - t1)))
 print("  forward+loss %.3f  backward %.3f  optimizer %.3f ms" % tuple(1e3 * v / N for v in tb))
 for k, v in sorted(acc.items(), key=lambda kv: -kv[1])[:14]:
     print("  %-40s %.3f ms/iter" % (k, 1e3 * v / N))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Phase time stamps of ganet_layer_bwd's consumer wave 0 / producer wave 4 of block 0 (needs a -DGANET_LBWD_TRACE build:
-GA_LIB_DIR=build_v_trace). Prints cycles per phase, averaged over rounds 4..27."""
+GA_DEV=lib_dir=build_v_trace). Prints cycles per phase, averaged over rounds 4..27."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
