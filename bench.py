@@ -56,15 +56,14 @@ def decoder_flops(model, frames: int = 1) -> dict:
     hidden = cin * h + 3 * h * h + (h + cin) * h + 6 * h * h      # conv1, conv2-4, conv5, conv6/7 x 3 heads
     outs = h * (3 + 1 + 3)                                        # conv8 x 3 heads
     if _one_pass_backward(model, frames):
-        # ten hidden layers with a 128-column activated input (conv2-4, conv5's activated half, conv6/7 x 3): data
-        # gradient + weight gradient in one launch; the separate families keep conv1 / conv5's 66-column input operand
-        # (weight gradient, input gradient) and the heads' weight gradient
-        fused_layers = 10 * h * h
+        # every hidden layer takes the one-pass kernel (data gradient + weight gradient in one launch): the ten with a
+        # 128-column activated input (conv2-4, conv5's activated half, conv6/7 x 3) and the two fed by the raw input
+        # (conv1, conv5's input half); the separate weight-gradient family keeps the heads (conv8 x 3)
+        fused_layers = 10 * h * h + 2 * cin * h
         return {
             "mlp_fwd": 2.0 * M * (hidden + outs),
             "layer_bwd": 4.0 * M * fused_layers,
-            "wgrad_act": 2.0 * M * (2 * cin * h + outs),
-            "mlp_bwd_data": 2.0 * M * (2 * cin * h),
+            "wgrad_act": 2.0 * M * outs,
             "head_bwd": 2.0 * M * outs,
         }
     return {
@@ -96,11 +95,12 @@ def decoder_bytes(model, frames: int = 1) -> dict:
         layer = (3 * 4 * h                       # conv7 -> G6: G, z, src z in, out
                  + (4 * h) + (5 * h) + (5 * h)   # conv6 -> G5: first writes, then accumulates (out read + written)
                  + 4 * h                         # conv5's activated half -> G4
-                 + 3 * 4 * h)                    # conv4..2
-        wgrad = sum(o + h for o in outs) + 2 * (2 * h + xp)       # conv8 x 3; conv5 / conv1 input operand
-        bwd = (2 * h + cin) + (2 * h + 2 * cin)                   # conv5 -> d(input); conv1 -> d(input), accumulated
+                 + 3 * 4 * h                     # conv4..2
+                 + (2 * h + 2 * xp)              # conv5's input half: G, z, x in, d(input) out
+                 + (2 * h + 3 * xp))             # conv1: G, z, x in, d(input) read + written
+        wgrad = sum(o + h for o in outs)                          # conv8 x 3
         return {"mlp_fwd": 4.0 * M * fwd, "layer_bwd": 4.0 * M * layer, "wgrad_act": 4.0 * M * wgrad,
-                "mlp_bwd_data": 4.0 * M * bwd, "head_bwd": 4.0 * M * head, "backward_minimum": 4.0 * M * minimum}
+                "head_bwd": 4.0 * M * head, "backward_minimum": 4.0 * M * minimum}
     wgrad = (sum(o + h for o in outs)            # conv8: raw g + x
              + 6 * 3 * h                         # conv7, conv6 per head: G, z, x
              + 3 * h + (2 * h + xp)              # conv5: activated operand / input operand

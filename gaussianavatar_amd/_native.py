@@ -146,7 +146,7 @@ GANET_SYMBOLS = ["ganet_linear_wgrad_workspace", "ganet_linear_wgrad", "ganet_bn
                  "ganet_mlp_stats_floats", "ganet_mlp_fwd", "ganet_mlp_stats",
                  "ganet_wgrad_act_workspace", "ganet_wgrad_act", "ganet_wgrad_reduce_batch", "ganet_adam_step", "ganet_mlp_bwd_data_parts",
                  "ganet_mlp_head_bwd_parts", "ganet_mlp_bwd_data", "ganet_mlp_head_bwd", "ganet_mlp_bwd_stats",
-                 "ganet_mlp_bwd_fused_parts", "ganet_mlp_bwd_fused_workspace", "ganet_mlp_bwd_fused",
+                 "ganet_mlp_bwd_fused_parts", "ganet_mlp_bwd_fused_workspace", "ganet_mlp_bwd_fused", "ganet_mlp_bwd_fused_input",
                  "ganet_decoder_saved_floats", "ganet_decoder_fwd_workspace", "ganet_decoder_fwd",
                  "ganet_decoder_bwd_workspace", "ganet_decoder_bwd",
                  "ganet_decode_pack_fwd", "ganet_decode_pack_bwd", "ganet_mean_sq_fwd", "ganet_mean_sq_bwd", "ganet_weighted_sum_fwd", "ganet_weighted_sum_bwd", "ganet_upsample_cat_fwd", "ganet_upsample_cat_bwd", "ganet_profile_enable", "ganet_profile_count", "ganet_profile_read", "ganet_profile_kernel_name",
@@ -237,6 +237,9 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_decoder_bwd_workspace.argtypes = [c_int64]
         lib.ganet_decoder_bwd.restype = c_int
         lib.ganet_decoder_bwd.argtypes = [c_int64, P, P, P, P, P, P, c_size_t, P, P]
+        lib.ganet_mlp_bwd_fused_input.restype = c_int
+        lib.ganet_mlp_bwd_fused_input.argtypes = [c_int64, P, P, P, P, c_int64, c_int32, P, c_int64, c_int32, P, P, c_size_t,
+                                                  c_int32, P]
         lib.ganet_mlp_head_bwd.restype = c_int
         lib.ganet_mlp_head_bwd.argtypes = [c_int64, c_int32, P, P, P, c_int64, P, P, P, c_int64, P, P, P]
         lib.ganet_mlp_bwd_stats.restype = c_int

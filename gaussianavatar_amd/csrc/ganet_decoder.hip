@@ -36,15 +36,16 @@ __global__ void pad_weights_kernel(int cin, const float* __restrict__ W1, const 
   }
 }
 
-// dW1 [128, cin] <- dW0p [128, 72][:, :cin];  dW5 [128, cin + 128] <- [ dWx [128, 72][:, :cin] | dWy [128, 128] ]
-__global__ void assemble_wgrads_kernel(int cin, const float* __restrict__ dW0p, const float* __restrict__ dWx,
+// dW1 [128, cin] <- dW0p [128, ldp][:, :cin];  dW5 [128, cin + 128] <- [ dWx [128, ldp][:, :cin] | dWy [128, 128] ]
+// (ldp = 72 from the separate weight-gradient kernel, 128 from the one-pass kernel's 128 x 128 tile)
+__global__ void assemble_wgrads_kernel(int cin, int ldp, const float* __restrict__ dW0p, const float* __restrict__ dWx,
                                        const float* __restrict__ dWy, float* __restrict__ dW1,
                                        float* __restrict__ dW5) {
   const int n = blockIdx.x;
   for (int k = threadIdx.x; k < cin + H; k += blockDim.x) {
     if (k < cin) {
-      dW1[n * cin + k] = dW0p[n * XP + k];
-      dW5[n * (cin + H) + k] = dWx[n * XP + k];
+      dW1[n * cin + k] = dW0p[n * ldp + k];
+      dW5[n * (cin + H) + k] = dWx[n * ldp + k];
     } else {
       dW5[n * (cin + H) + k] = dWy[n * H + (k - cin)];
     }
@@ -156,7 +157,7 @@ size_t ganet_decoder_bwd_workspace(int64_t M) {
   b += (size_t)GANET_MAX_WGRAD_JOBS * wg;            // partial tiles of every weight gradient
   b += align_up((size_t)parts2 * 256 * sizeof(float), 256);   // column-sum partials
   b += (size_t)NL * 3 * H * sizeof(float);           // (A, q, p) per layer
-  b += ((size_t)2 * H * XP + (size_t)H * H) * sizeof(float);  // dW0p, dWx, dWy
+  b += (size_t)3 * H * H * sizeof(float);            // dW0p, dWx (128 x 72 or the left part of 128 x 128), dWy
   b += 2 * H * sizeof(float);                        // discarded bias gradients of the split conv5 / conv1 halves
   return b;
 }
@@ -190,8 +191,8 @@ int ganet_decoder_bwd(int64_t M, const float* x, const GanetDecoderParams* p, co
   float* col_part = reinterpret_cast<float*>(w); w += align_up((size_t)parts * 256 * sizeof(float), 256);
   float* coef[NL];
   for (int i = 0; i < NL; ++i) { coef[i] = reinterpret_cast<float*>(w); w += 3 * H * sizeof(float); }
-  float* dW0p = reinterpret_cast<float*>(w); w += (size_t)H * XP * sizeof(float);
-  float* dWx = reinterpret_cast<float*>(w); w += (size_t)H * XP * sizeof(float);
+  float* dW0p = reinterpret_cast<float*>(w); w += (size_t)H * H * sizeof(float);
+  float* dWx = reinterpret_cast<float*>(w); w += (size_t)H * H * sizeof(float);
   float* dWy = reinterpret_cast<float*>(w); w += (size_t)H * H * sizeof(float);
   float* db_dump = reinterpret_cast<float*>(w); w += 2 * H * sizeof(float);
 
@@ -268,9 +269,22 @@ int ganet_decoder_bwd(int64_t M, const float* x, const GanetDecoderParams* p, co
   GA_TRY(finish(4, nparts5));
   const float* W5 = p->W[4];
   const int64_t ld5 = cin + H;
-  GA_TRY(wgrad(nullptr, H, 4, G5, -1, XP, dWx, db_dump));
-  if (g->dx) GA_TRY(ganet_mlp_bwd_data(M, cin, G5, H, sv.z[4], H, coef[4], W5, ld5, g->dx, g->x_cols, 0, nullptr, 0,
-                                        nullptr, nullptr, nullptr, sweep.next(), stream));
+  // the layers fed by the raw input (conv5's input half, conv1): weight gradient + input gradient in one pass when the
+  // caller's input (and its gradient) is the zero-padded [M,72] layout, else the two separate kernels
+  const bool input_one_pass = g->dx && g->x_cols == XP;
+  const int ldp = input_one_pass ? H : XP;
+  auto input_bwd = [&](int i, const float* G, const float* W, int64_t ldw, int accumulate, float* dWp, float* db) -> int {
+    if (input_one_pass) {
+      void* ws = add_job(H, H, dWp, db, n_fused);
+      return ganet_mlp_bwd_fused_input(M, G, sv.z[i], coef[i], W, ldw, cin, g->dx, XP, accumulate, x, ws, wg,
+                                       sweep.next(), stream);
+    }
+    GA_TRY(wgrad(nullptr, H, i, G, -1, XP, dWp, db));
+    if (g->dx) GA_TRY(ganet_mlp_bwd_data(M, cin, G, H, sv.z[i], H, coef[i], W, ldw, g->dx, g->x_cols, accumulate, nullptr,
+                                          0, nullptr, nullptr, nullptr, sweep.next(), stream));
+    return 0;
+  };
+  GA_TRY(input_bwd(4, G5, W5, ld5, 0, dWx, db_dump));
   float* Gcur = Gbuf[0];
   GA_TRY(layer_bwd(4, G5, 3, W5 + cin, ld5, Gcur, 0, 1, dWy, g->db[4]));
   float* Gnext = Gbuf[1];
@@ -280,15 +294,13 @@ int ganet_decoder_bwd(int64_t M, const float* x, const GanetDecoderParams* p, co
     float* t = Gcur; Gcur = Gnext; Gnext = t;
   }
   GA_TRY(finish(0, n_fused));
-  GA_TRY(wgrad(nullptr, H, 0, Gcur, -1, XP, dW0p, g->db[0]));
-  if (g->dx) GA_TRY(ganet_mlp_bwd_data(M, cin, Gcur, H, sv.z[0], H, coef[0], p->W[0], cin, g->dx, g->x_cols, 1, nullptr,
-                                        0, nullptr, nullptr, nullptr, sweep.next(), stream));
+  GA_TRY(input_bwd(0, Gcur, p->W[0], cin, 1, dW0p, g->db[0]));
   if (side_used) {
     GA_TRY(check_hip(hipEventRecord(ev_side, side), "hipEventRecord"));
     GA_TRY(check_hip(hipStreamWaitEvent(stream, ev_side, 0), "hipStreamWaitEvent"));
   }
   GA_TRY(ganet_wgrad_reduce_batch(njobs, jobs, stream));
-  hipLaunchKernelGGL(assemble_wgrads_kernel, dim3(H), dim3(256), 0, stream, cin, dW0p, dWx, dWy, g->dW[0], g->dW[4]);
+  hipLaunchKernelGGL(assemble_wgrads_kernel, dim3(H), dim3(256), 0, stream, cin, ldp, dW0p, dWx, dWy, g->dW[0], g->dW[4]);
   return check_hip(hipGetLastError(), "assemble_wgrads_kernel");
 }
 

@@ -56,8 +56,7 @@ constexpr int PLANE = LSLAB * 256;          // bytes of one bf16 plane of a slab
 constexpr int IMG = 3 * PLANE;              // dz or a: 24 KB
 constexpr int ZSRC = LSLAB * 128 * 4;       // fp32 Z_src of the slab: 16 KB
 constexpr int BUF = 2 * IMG + ZSRC;         // 64 KB
-constexpr int COEF_OFF = 2 * BUF;           // A | q | p | scale log2e | shift log2e   (5 x 128 floats)
-constexpr int LDS_BYTES = COEF_OFF + 5 * 128 * 4;
+constexpr int BUF_ACC = BUF + ZSRC;         // accumulating variants: + the slab of `out` to add to (80 KB; 2 x 80 = all of LDS)
 constexpr int LTILE = 128 * 128 + 128;      // partial tile + bias, as wgrad_split writes it
 
 
@@ -79,28 +78,35 @@ __device__ __forceinline__ uint2 read_tr(const char* p) {
   return __builtin_bit_cast(uint2, v);
 }
 
-template <bool ACCUM, bool SIG>
+// KIN = 128: the layer's input is act(bn(src_z)) (a hidden layer); KIN = 72: the RAW decoder input x [M, 72] (conv1, and
+// the input half of conv5): `src_z` = x, no activation, O = the input's real column count (<= 72) output columns with
+// row stride ldo, no softplus' epilogue; dW comes out as the left 72 columns of the 128 x 128 partial tile.
+template <bool ACCUM, bool SIG, int KIN>
 __global__ void __attribute__((amdgpu_flat_work_group_size(LWG, LWG), amdgpu_waves_per_eu(2, 2)))
 layer_bwd_spec_kernel(int64_t M, const float* __restrict__ g, const float* __restrict__ gz,
-                      const float* __restrict__ gcoef, const float* __restrict__ W, int64_t ldw,
+                      const float* __restrict__ gcoef, const float* __restrict__ W, int64_t ldw, int O,
                       float* __restrict__ out, const float* __restrict__ src_z, const float* __restrict__ src_scale,
                       const float* __restrict__ src_shift, float* __restrict__ col_part, float* __restrict__ wpartial,
                       int reverse) {
   extern __shared__ u32x4 s_mem[];
   char* const lds = reinterpret_cast<char*>(s_mem);
-  float* const s_coef = reinterpret_cast<float*>(lds + COEF_OFF);
+  constexpr int BUFB = ACCUM ? BUF_ACC : BUF;  // bytes of one slab buffer
+  // the coefficient staging overlays the second slab buffer: the producers read it into registers behind the first
+  // barrier, the buffer is first written behind the second
+  float* const s_coef = reinterpret_cast<float*>(lds + BUFB);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int kg = lane >> 5, c = lane & 31;
   const bool consumer = wave < 4;              // uniform
+  constexpr int ldo = KIN == 128 ? 128 : KIN;  // row stride of `out`: [M,128], or [M,72] like the padded input
   LBWD_STAMP(0, 63, 0); LBWD_STAMP(1, 63, 0);
 
   for (int i = threadIdx.x; i < 128; i += LWG) {
     s_coef[i] = gcoef[i];
     s_coef[128 + i] = gcoef[128 + i];
     s_coef[256 + i] = gcoef[256 + i];
-    s_coef[384 + i] = src_scale[i] * kLog2e;
-    s_coef[512 + i] = src_shift[i] * kLog2e;
+    s_coef[384 + i] = KIN == 128 ? src_scale[i] * kLog2e : 0.f;
+    s_coef[512 + i] = KIN == 128 ? src_shift[i] * kLog2e : 0.f;
   }
   const int64_t nslab = M / LSLAB;
   const int rounds = (int)((nslab + gridDim.x - 1) / gridDim.x);
@@ -115,7 +121,7 @@ layer_bwd_spec_kernel(int64_t M, const float* __restrict__ g, const float* __res
   if (!consumer) {
     // ---- producer: lane (row group h, prow, pq) owns columns 8 pq .. + 7 of rows 8 pw + 4 h + (lane >> 4), h = 0, 1
     const int pw = wave - 4, pq = lane & 15;
-    struct Raw { f32x4 g0, g1, z0, z1, s0, s1; };
+    struct Raw { f32x4 g0, g1, z0, z1, s0, s1, o0, o1; };
     auto row_of = [&](int h) { return 8 * pw + 4 * h + (lane >> 4); };
     auto load_raw = [&](Raw& r, int64_t ps, int h) {
       const int64_t off = (ps * LSLAB + row_of(h)) * 128 + 8 * pq;
@@ -123,8 +129,19 @@ layer_bwd_spec_kernel(int64_t M, const float* __restrict__ g, const float* __res
       r.g1 = *reinterpret_cast<const f32x4*>(g + off + 4);
       r.z0 = *reinterpret_cast<const f32x4*>(gz + off);
       r.z1 = *reinterpret_cast<const f32x4*>(gz + off + 4);
-      r.s0 = *reinterpret_cast<const f32x4*>(src_z + off);
-      r.s1 = *reinterpret_cast<const f32x4*>(src_z + off + 4);
+      if (KIN == 128) {
+        r.s0 = *reinterpret_cast<const f32x4*>(src_z + off);
+        r.s1 = *reinterpret_cast<const f32x4*>(src_z + off + 4);
+      } else {      // raw input rows of 72 floats: chunks 0..8 (lanes beyond re-read chunk 8, masked in produce)
+        const int64_t xo = (ps * LSLAB + row_of(h)) * KIN + 8 * (pq < KIN / 8 ? pq : KIN / 8 - 1);
+        r.s0 = *reinterpret_cast<const f32x4*>(src_z + xo);
+        r.s1 = *reinterpret_cast<const f32x4*>(src_z + xo + 4);
+      }
+      if (ACCUM) {      // the rows of `out` this slab adds to: handed to the consumers through LDS
+        const int64_t oo = (ps * LSLAB + row_of(h)) * ldo + 8 * (KIN == 128 || pq < KIN / 8 ? pq : KIN / 8 - 1);
+        r.o0 = *reinterpret_cast<const f32x4*>(out + oo);
+        r.o1 = *reinterpret_cast<const f32x4*>(out + oo + 4);
+      }
     };
     // per-column coefficients of this lane's 8 columns: registers (a producer holds little else)
     __syncthreads();                                     // coefficients staged
@@ -136,7 +153,7 @@ layer_bwd_spec_kernel(int64_t M, const float* __restrict__ g, const float* __res
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias[e] = 0.f;
     auto produce = [&](const Raw& r, int buf, int h, bool live) {
-      char* const base = lds + buf * BUF;
+      char* const base = lds + buf * BUFB;
       const int prow = row_of(h);
       const int pswz = ((prow & 3) << 2) | ((prow >> 2) & 3);
       const int p_img = prow * 256 + ((pq ^ pswz) << 4);
@@ -154,10 +171,16 @@ layer_bwd_spec_kernel(int64_t M, const float* __restrict__ g, const float* __res
       *reinterpret_cast<u32x4*>(base + p_img) = p1;
       *reinterpret_cast<u32x4*>(base + PLANE + p_img) = p2;
       *reinterpret_cast<u32x4*>(base + 2 * PLANE + p_img) = p3;
-      v[0] = softplus_log2(fmaf(C0.x, r.s0.x, H0.x)); v[1] = softplus_log2(fmaf(C0.y, r.s0.y, H0.y));
-      v[2] = softplus_log2(fmaf(C0.z, r.s0.z, H0.z)); v[3] = softplus_log2(fmaf(C0.w, r.s0.w, H0.w));
-      v[4] = softplus_log2(fmaf(C1.x, r.s1.x, H1.x)); v[5] = softplus_log2(fmaf(C1.y, r.s1.y, H1.y));
-      v[6] = softplus_log2(fmaf(C1.z, r.s1.z, H1.z)); v[7] = softplus_log2(fmaf(C1.w, r.s1.w, H1.w));
+      if (KIN == 128) {
+        v[0] = softplus_log2(fmaf(C0.x, r.s0.x, H0.x)); v[1] = softplus_log2(fmaf(C0.y, r.s0.y, H0.y));
+        v[2] = softplus_log2(fmaf(C0.z, r.s0.z, H0.z)); v[3] = softplus_log2(fmaf(C0.w, r.s0.w, H0.w));
+        v[4] = softplus_log2(fmaf(C1.x, r.s1.x, H1.x)); v[5] = softplus_log2(fmaf(C1.y, r.s1.y, H1.y));
+        v[6] = softplus_log2(fmaf(C1.z, r.s1.z, H1.z)); v[7] = softplus_log2(fmaf(C1.w, r.s1.w, H1.w));
+      } else {      // raw input; columns beyond KIN are zero (their dW columns are never read)
+        const float on = pq < KIN / 8 ? 1.f : 0.f;
+        v[0] = r.s0.x * on; v[1] = r.s0.y * on; v[2] = r.s0.z * on; v[3] = r.s0.w * on;
+        v[4] = r.s1.x * on; v[5] = r.s1.y * on; v[6] = r.s1.z * on; v[7] = r.s1.w * on;
+      }
       split8(v, p1, p2, p3);
       *reinterpret_cast<u32x4*>(base + IMG + p_img) = p1;
       *reinterpret_cast<u32x4*>(base + IMG + PLANE + p_img) = p2;
@@ -165,6 +188,10 @@ layer_bwd_spec_kernel(int64_t M, const float* __restrict__ g, const float* __res
       if (SIG) {
         *reinterpret_cast<f32x4*>(base + 2 * IMG + p_zs) = r.s0;
         *reinterpret_cast<f32x4*>(base + 2 * IMG + p_zs + 16) = r.s1;
+      }
+      if (ACCUM) {
+        *reinterpret_cast<f32x4*>(base + BUF + p_zs) = r.o0;
+        *reinterpret_cast<f32x4*>(base + BUF + p_zs + 16) = r.o1;
       }
     };
     // two slabs of raw rows in flight: sets (a0, a1) and (b0, b1); the round loop is unrolled by two so that a set is
@@ -182,10 +209,11 @@ layer_bwd_spec_kernel(int64_t M, const float* __restrict__ g, const float* __res
     // at a full store queue stalls the matrix pipe (measured: 3-4 k cycles per round), a producer has slack.
     auto drain = [&](int r, int h) {                     // output tile of round r (buffer r & 1), row group h
       if (r < 0 || !(slab_of(r) < nslab && r < rounds)) return;
-      const char* const zs = lds + (r & 1) * BUF + 2 * IMG + row_of(h) * 512 + pq * 32;
+      const char* const zs = lds + (r & 1) * BUFB + 2 * IMG + row_of(h) * 512 + pq * 32;
       const float4 o0 = *reinterpret_cast<const float4*>(zs);
       const float4 o1 = *reinterpret_cast<const float4*>(zs + 16);
-      float* const op = out + (phys(slab_of(r)) * LSLAB + row_of(h)) * 128 + 8 * pq;
+      if (KIN != 128 && pq >= KIN / 8) return;
+      float* const op = out + (phys(slab_of(r)) * LSLAB + row_of(h)) * ldo + 8 * pq;
       *reinterpret_cast<float4*>(op) = o0;
       *reinterpret_cast<float4*>(op + 4) = o1;
     };
@@ -193,6 +221,7 @@ layer_bwd_spec_kernel(int64_t M, const float* __restrict__ g, const float* __res
     // prologue arithmetic of all four produce calls of the unrolled body to its top and waits for every load there
     auto pin = [&](Raw& s) {
       asm volatile("" : "+v"(s.g0), "+v"(s.g1), "+v"(s.z0), "+v"(s.z1), "+v"(s.s0), "+v"(s.s1) :: "memory");
+      if (ACCUM) asm volatile("" : "+v"(s.o0), "+v"(s.o1) :: "memory");
     };
     auto round = [&](Raw& s0, Raw& s1, int r) {          // slab r + 1 -> buffer (r + 1) & 1, then slab r + 3's loads
       const bool live = slab_of(r + 1) < nslab && r + 1 < rounds;
@@ -237,12 +266,13 @@ layer_bwd_spec_kernel(int64_t M, const float* __restrict__ g, const float* __res
     // ---- consumer
     u32x4 Bw[8][3];
     {
-      const float* wp = W + (size_t)(8 * kg) * ldw + 32 * wave + c;
+      const bool col_on = 32 * wave + c < O;
+      const float* wp = W + (size_t)(8 * kg) * ldw + (col_on ? 32 * wave + c : 0);
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = wp[(size_t)(16 * s + e) * ldw];
+        for (int e = 0; e < 8; ++e) v[e] = col_on ? wp[(size_t)(16 * s + e) * ldw] : 0.f;
         split8(v, Bw[s][0], Bw[s][1], Bw[s][2]);
       }
     }
@@ -274,19 +304,10 @@ layer_bwd_spec_kernel(int64_t M, const float* __restrict__ g, const float* __res
     const int rounds2 = (rounds + 1) & ~1;
     LBWD_STAMP(0, 63, 1);
     for (int r = 0; r < rounds2; ++r) {
-      const char* const base = lds + (r & 1) * BUF;
+      const char* const base = lds + (r & 1) * BUFB;
       const int64_t ps = phys(slab_of(r));
       const bool live = slab_of(r) < nslab && r < rounds;
       LBWD_STAMP(0, r, 0);
-      float old[16];
-      // uniform base (scalar registers) + a 32-bit lane offset: no 64-bit per-lane pointer to keep (or spill: a
-      // reload is a VMEM operation, and waiting for it waits for the previous round's stores as well)
-      float* const obase = out + ps * (LSLAB * 128) + 32 * wave;
-      const int olane = (4 * kg) * 128 + c;
-      if (ACCUM) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) old[q] = obase[olane + ((q & 3) + 8 * (q >> 2)) * 128];
-      }
       // data gradient of this wave's 32 output columns, then the weight-gradient quadrant: 12 groups of MFMAs, the
       // LDS reads of a group issued BEFORE the MFMAs of the previous one (fences: the compiler otherwise sinks every
       // read to its use and the consumer — alone on its SIMD's matrix pipe — waits out each LDS round trip)
@@ -340,13 +361,14 @@ layer_bwd_spec_kernel(int64_t M, const float* __restrict__ g, const float* __res
       }
       LBWD_STAMP(0, r, 2);
       // epilogue of the output tile: the result replaces z in the slab's Z_src image (the producers store it)
-      float* zs = reinterpret_cast<float*>(lds + (r & 1) * BUF + 2 * IMG) + (4 * kg) * 128 + 32 * wave + c;
+      float* zs = reinterpret_cast<float*>(lds + (r & 1) * BUFB + 2 * IMG) + (4 * kg) * 128 + 32 * wave + c;
+      const float* olds = reinterpret_cast<const float*>(lds + (r & 1) * BUFB + BUF) + (4 * kg) * 128 + 32 * wave + c;
       if (live) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int row = (q & 3) + 8 * (q >> 2);
           float val = acc[q];
-          if (ACCUM) val += old[q];
+          if (ACCUM) val += olds[row * 128];
           if (SIG) {
             const float zv = zs[row * 128];
             val *= sigmoid_log2(fmaf(ssc, zv, ssh));
@@ -376,7 +398,7 @@ layer_bwd_spec_kernel(int64_t M, const float* __restrict__ g, const float* __res
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int n = (2 * jn + a) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kg;
-          wout[n * 128 + (2 * ik + b) * 32 + c] = wacc[a][b][q] * kLn2;     // a was in log2 units
+          wout[n * 128 + (2 * ik + b) * 32 + c] = wacc[a][b][q] * (KIN == 128 ? kLn2 : 1.f);   // softplus in log2 units
         }
   }
   __syncthreads();
@@ -399,6 +421,50 @@ int32_t ganet_mlp_bwd_fused_parts(void) { return LBLOCKS; }
 
 size_t ganet_mlp_bwd_fused_workspace(void) { return (size_t)LBLOCKS * LTILE * sizeof(float); }
 
+static int layer_bwd_launch(int64_t M, int kin, const float* g, const float* gz, const float* gcoef, const float* W,
+                            int64_t ldw, int O, float* out, int accumulate, const float* src, const float* src_scale,
+                            const float* src_shift, int apply_act, float* col_part, void* wgrad_workspace,
+                            size_t workspace_bytes, int32_t row_order, hipStream_t stream) {
+  if (workspace_bytes < ganet_mlp_bwd_fused_workspace()) {
+    set_error("ganet_mlp_bwd_fused: workspace too small (%zu < %zu)", workspace_bytes,
+              ganet_mlp_bwd_fused_workspace());
+    return 2;
+  }
+  const int reverse = row_order == GANET_ROWS_DOWN ? 1 : 0;
+  const int64_t nslab = M / LSLAB;
+  const int blocks = (int)(nslab < LBLOCKS ? nslab : LBLOCKS);
+  float* wp = static_cast<float*>(wgrad_workspace);
+  if (blocks < LBLOCKS)        // the reduction adds up all LBLOCKS partial tiles
+    if (check_hip(hipMemsetAsync(wp + (size_t)blocks * LTILE, 0, (size_t)(LBLOCKS - blocks) * LTILE * sizeof(float),
+                                 stream), "hipMemsetAsync")) return 3;
+  if (apply_act && blocks < LBLOCKS)
+    if (check_hip(hipMemsetAsync(col_part + (size_t)blocks * 256, 0, (size_t)(LBLOCKS - blocks) * 256 * sizeof(float),
+                                 stream), "hipMemsetAsync")) return 3;
+#define LAUNCH(AC, SG, KI)                                                                                      \
+  do {                                                                                                          \
+    static bool attr_set = false;                                                                               \
+    if (!attr_set) {                                                                                            \
+      if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_bwd_spec_kernel<AC, SG, KI>),       \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * ((AC) ? BUF_ACC : BUF))), \
+                    "hipFuncSetAttribute")) return 3;                                                           \
+      attr_set = true;                                                                                          \
+    }                                                                                                           \
+    ProfScope prof_(K_LAYER_BWD, stream);                                                                       \
+    hipLaunchKernelGGL((layer_bwd_spec_kernel<AC, SG, KI>), dim3(blocks), dim3(LWG), 2 * ((AC) ? BUF_ACC : BUF), stream, M, g, gz, \
+                       gcoef, W, ldw, O, out, src, src_scale, src_shift, col_part, wp, reverse);                \
+    return check_hip(hipGetLastError(), "layer_bwd_kernel");                                                    \
+  } while (0)
+  if (kin == 72) {
+    if (accumulate) LAUNCH(true, false, 72);
+    LAUNCH(false, false, 72);
+  }
+  if (accumulate && apply_act) LAUNCH(true, true, 128);
+  if (accumulate) LAUNCH(true, false, 128);
+  if (apply_act) LAUNCH(false, true, 128);
+  LAUNCH(false, false, 128);
+#undef LAUNCH
+}
+
 int ganet_mlp_bwd_fused(int64_t M, const float* g, const float* gz, const float* gcoef, const float* W, int64_t ldw,
                         float* out, int32_t accumulate, const float* src_z, const float* src_scale,
                         const float* src_shift, int32_t apply_act, float* col_part, void* wgrad_workspace,
@@ -410,41 +476,21 @@ int ganet_mlp_bwd_fused(int64_t M, const float* g, const float* gz, const float*
               "and 16-byte aligned, W [128, >=128] with row stride ldw)", LSLAB);
     return 1;
   }
-  if (workspace_bytes < ganet_mlp_bwd_fused_workspace()) {
-    set_error("ganet_mlp_bwd_fused: workspace too small (%zu < %zu)", workspace_bytes,
-              ganet_mlp_bwd_fused_workspace());
-    return 2;
+  return layer_bwd_launch(M, 128, g, gz, gcoef, W, ldw, 128, out, accumulate, src_z, src_scale, src_shift, apply_act,
+                          col_part, wgrad_workspace, workspace_bytes, row_order, static_cast<hipStream_t>(stream_));
+}
+
+int ganet_mlp_bwd_fused_input(int64_t M, const float* g, const float* gz, const float* gcoef, const float* W,
+                              int64_t ldw, int32_t O, float* out, int64_t ldo, int32_t accumulate, const float* x,
+                              void* wgrad_workspace, size_t workspace_bytes, int32_t row_order, void* stream_) {
+  if (M <= 0 || (M % LSLAB) || !g || !gz || !gcoef || !W || O <= 0 || O > 72 || ldw < O || !out || ldo != 72 ||
+      !x || !wgrad_workspace || !aligned16(g) || !aligned16(gz) || !aligned16(x) || !aligned16(out)) {
+    set_error("ganet_mlp_bwd_fused_input: invalid arguments (M a multiple of %d; g, gz [M,128]; x and out [M,72] contiguous, "
+              "all 16-byte aligned; W [128, >= O], O <= 72)", LSLAB);
+    return 1;
   }
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const int reverse = row_order == GANET_ROWS_DOWN ? 1 : 0;
-  const int64_t nslab = M / LSLAB;
-  const int blocks = (int)(nslab < LBLOCKS ? nslab : LBLOCKS);
-  float* wp = static_cast<float*>(wgrad_workspace);
-  if (blocks < LBLOCKS)        // the reduction adds up all LBLOCKS partial tiles
-    if (check_hip(hipMemsetAsync(wp + (size_t)blocks * LTILE, 0, (size_t)(LBLOCKS - blocks) * LTILE * sizeof(float),
-                                 stream), "hipMemsetAsync")) return 3;
-  if (apply_act && blocks < LBLOCKS)
-    if (check_hip(hipMemsetAsync(col_part + (size_t)blocks * 256, 0, (size_t)(LBLOCKS - blocks) * 256 * sizeof(float),
-                                 stream), "hipMemsetAsync")) return 3;
-#define LAUNCH(AC, SG)                                                                                          \
-  do {                                                                                                          \
-    static bool attr_set = false;                                                                               \
-    if (!attr_set) {                                                                                            \
-      if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_bwd_spec_kernel<AC, SG>),                \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES),            \
-                    "hipFuncSetAttribute")) return 3;                                                           \
-      attr_set = true;                                                                                          \
-    }                                                                                                           \
-    ProfScope prof_(K_LAYER_BWD, stream);                                                                       \
-    hipLaunchKernelGGL((layer_bwd_spec_kernel<AC, SG>), dim3(blocks), dim3(LWG), LDS_BYTES, stream, M, g, gz, gcoef, \
-                       W, ldw, out, src_z, src_scale, src_shift, col_part, wp, reverse);                        \
-    return check_hip(hipGetLastError(), "layer_bwd_kernel");                                                    \
-  } while (0)
-  if (accumulate && apply_act) LAUNCH(true, true);
-  if (accumulate) LAUNCH(true, false);
-  if (apply_act) LAUNCH(false, true);
-  LAUNCH(false, false);
-#undef LAUNCH
+  return layer_bwd_launch(M, 72, g, gz, gcoef, W, ldw, O, out, accumulate, x, nullptr, nullptr, 0, nullptr,
+                          wgrad_workspace, workspace_bytes, row_order, static_cast<hipStream_t>(stream_));
 }
 
 }  // extern "C"

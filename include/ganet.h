@@ -162,6 +162,12 @@ int32_t ganet_mlp_head_bwd_parts(void);
  * accumulating into one source). wgrad_workspace (ganet_mlp_bwd_fused_workspace() bytes) receives
  * ganet_mlp_bwd_fused_parts() partial tiles [128*128 + 128] for ganet_wgrad_reduce_batch (job.nblocks =
  * ganet_mlp_bwd_fused_parts()). */
+/* ganet_mlp_bwd_fused_input: the same one-pass backward for a layer whose input is the RAW decoder input x [M,72] (conv1,
+ * and the input half of conv5): out [M,72] (+)= dz . W[128, 0:O] (columns >= O receive zeros), dW[n, 0:72] = sum_m
+ * dz[m,n] x[m,k] — delivered as the left 72 columns of a 128 x 128 partial tile (reduce with N = K = 128), db likewise. */
+int ganet_mlp_bwd_fused_input(int64_t M, const float* g, const float* gz, const float* gcoef, const float* W,
+                              int64_t ldw, int32_t O, float* out, int64_t ldo, int32_t accumulate, const float* x,
+                              void* wgrad_workspace, size_t workspace_bytes, int32_t row_order, void* stream);
 int32_t ganet_mlp_bwd_fused_parts(void);
 size_t ganet_mlp_bwd_fused_workspace(void);
 int ganet_mlp_bwd_fused(int64_t M, const float* g, const float* gz, const float* gcoef, const float* W, int64_t ldw,

@@ -656,6 +656,50 @@ def test_mlp_bwd_fused_matches_float64(M, accumulate, act, wslice, row_order):
     assert float((db.double() - dz.sum(0)).abs().max()) <= 2e-5 * float(dz.abs().sum(0).max()) + 1e-4
 
 
+@pytest.mark.parametrize("row_order", [0, 2])
+@pytest.mark.parametrize("M,accumulate,wide", [(262144, False, True), (32 * 1031, True, False), (64, True, True), (32, False, False)])
+def test_mlp_bwd_fused_input_matches_float64(M, accumulate, wide, row_order):
+    """ganet_mlp_bwd_fused_input: the one-pass backward of a layer fed by the raw decoder input x [M,72] (conv1, the
+    input half of conv5): input gradient [M,72] (columns >= 66 zero-filled) and weight / bias gradient, against
+    float64. wide: W is the left column slice of conv5's [128, 194] weight."""
+    from gaussianavatar_amd import _native, fused
+    lib = _native.ganet()
+    torch.manual_seed(M % 23 + 1)
+    dev = torch.device("cuda")
+    cin = 66
+    G = torch.randn(M, 128, device=dev)
+    z = torch.randn(M, 128, device=dev) * 2
+    coef = torch.randn(3, 128, device=dev)
+    Wfull = torch.randn(128, 194 if wide else cin, device=dev) * 0.1
+    W = Wfull[:, :cin]
+    x = torch.randn(M, 72, device=dev)
+    x[:, cin:] = 0
+    out = torch.randn(M, 72, device=dev) if accumulate else torch.full((M, 72), float("nan"), device=dev)
+    prev = out.clone()
+    parts = lib.ganet_mlp_bwd_fused_parts()
+    wsb = lib.ganet_mlp_bwd_fused_workspace()
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    ws.view(torch.float32).fill_(float("nan"))
+    _native.ganet_check(lib.ganet_mlp_bwd_fused_input(M, fused._ptr(G), fused._ptr(z), fused._ptr(coef), fused._ptr(W),
+                                                      W.stride(0), cin, fused._ptr(out), 72, int(accumulate), fused._ptr(x),
+                                                      ws.data_ptr(), wsb, row_order, fused._stream(dev)))
+    dW, db = torch.empty(128, 128, device=dev), torch.empty(128, device=dev)
+    jobs = (_native.GanetWgradJob * 1)()
+    jobs[0].workspace, jobs[0].M, jobs[0].N, jobs[0].K = ws.data_ptr(), M, 128, 128
+    jobs[0].dW, jobs[0].db, jobs[0].nblocks = dW.data_ptr(), db.data_ptr(), parts
+    _native.ganet_check(lib.ganet_wgrad_reduce_batch(1, jobs, fused._stream(dev)))
+    dz = coef[0].double() * G.double() + coef[1].double() * z.double() + coef[2].double()
+    ref = dz @ W.double()
+    if accumulate:
+        ref = ref + prev[:, :cin].double()
+    got = out[:, :cin].double()
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 2e-5
+    assert torch.isfinite(out).all()
+    refW = dz.t() @ x[:, :cin].double()
+    assert float((dW[:, :cin].double() - refW).abs().max()) <= 2e-5 * float(refW.abs().max()) + 1e-4
+    assert float((db.double() - dz.sum(0)).abs().max()) <= 2e-5 * float(dz.abs().sum(0).max()) + 1e-4
+
+
 def test_batchnorm_statistics_survive_a_large_mean():
     """Advisor finding r1: E[z^2] - mean^2 from raw fp32 sums cancels once |mean| >> std. The fused layer
     accumulates its statistics about the BatchNorm layer's running mean: with columns at mean ~1e3, std ~1
