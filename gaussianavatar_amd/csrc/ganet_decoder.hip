@@ -256,9 +256,12 @@ int ganet_decoder_bwd(int64_t M, const float* x, const GanetDecoderParams* p, co
     const int j = heads[pos], i6 = 5 + 2 * j, i7 = 6 + 2 * j, N8 = p->n8[j];
     float* G7 = Gbuf[0];
     float* G6 = Gbuf[1];
-    GA_TRY(wgrad(d_out[j], N8, -1, nullptr, i7, H, g->dW8[j], g->db8[j]));
+    // the head's own weight gradient rides on head_bwd (same g and z rows, the activation shares its exponential
+    // with softplus'): its per-workgroup partials join the batched reduction. (Round 1 measured this slower — head_bwd
+    // turned VALU-bound beside fp32-MFMA kernels; with the separate pass at 43-55 us per head it now wins: +3 % it/s.)
+    float* hw = static_cast<float*>(add_job(N8, H, g->dW8[j], g->db8[j], n_head));
     GA_TRY(ganet_mlp_head_bwd(M, N8, d_out[j], p->W8[j], sv.z[i7], H, sv.stat[i7] + 2 * H, sv.stat[i7] + 3 * H, G7, H,
-                              col_part, nullptr, stream));
+                              col_part, hw, stream));
     GA_TRY(finish(i7, n_head));
     GA_TRY(layer_bwd(i7, G7, i6, p->W[i7], H, G6, 0, 1, g->dW[i7], g->db[i7]));
     GA_TRY(finish(i6, n_fused));
