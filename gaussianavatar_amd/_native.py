@@ -142,7 +142,7 @@ def galbs() -> ctypes.CDLL:
 
 _ganet = None
 GANET_SYMBOLS = ["ganet_linear_wgrad_workspace", "ganet_linear_wgrad", "ganet_bn_workspace",
-                 "ganet_bn_act_fwd", "ganet_bn_act_bwd", "ganet_ssim_fwd", "ganet_ssim_bwd",
+                 "ganet_bn_act_fwd", "ganet_bn_act_bwd", "ganet_ssim_sums_floats", "ganet_ssim_fwd", "ganet_ssim_bwd",
                  "ganet_mlp_stats_floats", "ganet_mlp_fwd", "ganet_mlp_stats",
                  "ganet_wgrad_act_workspace", "ganet_wgrad_act", "ganet_wgrad_reduce_batch", "ganet_adam_step", "ganet_mlp_bwd_data_parts",
                  "ganet_mlp_head_bwd_parts", "ganet_mlp_bwd_data", "ganet_mlp_head_bwd", "ganet_mlp_bwd_stats",
@@ -202,6 +202,8 @@ def ganet() -> ctypes.CDLL:
                                          c_size_t, P]
         lib.ganet_bn_act_bwd.restype = c_int
         lib.ganet_bn_act_bwd.argtypes = [c_int64, c_int32, P, P, P, P, P, c_int32, P, P, P, P, P, c_size_t, P]
+        lib.ganet_ssim_sums_floats.restype = c_int64
+        lib.ganet_ssim_sums_floats.argtypes = []
         lib.ganet_ssim_fwd.restype = c_int
         lib.ganet_ssim_fwd.argtypes = [c_int32, c_int32, c_int32, P, P, c_float, P, P, P]
         lib.ganet_ssim_bwd.restype = c_int
@@ -281,7 +283,7 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_conv5_wgrad.argtypes = [c_int32, c_int32, c_int32, P, P, P, P, c_size_t, P]
         lib.ganet_last_error.restype = c_char_p
         lib.ganet_abi_version.restype = c_int
-        if lib.ganet_abi_version() != 4:
+        if lib.ganet_abi_version() != 5:
             raise RuntimeError("libganet_hip.so ABI version mismatch; rebuild")
         _ganet = lib
     return _ganet

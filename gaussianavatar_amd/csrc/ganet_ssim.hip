@@ -7,7 +7,8 @@
 // image plane and streams down its rows (no workgroup barriers): a row (+5 columns of halo each side)
 // goes through a per-wave LDS line, every lane takes the 11 horizontal taps of its column, and the
 // vertical pass is a ring of 11 partially accumulated output rows held in registers (each new input
-// row is scattered into the 11 output rows it contributes to; the oldest one is then complete).
+// row is scattered into the 11 output rows it contributes to; the oldest one is then complete). A
+// row's global loads are issued 11 rows before it is consumed (see the schedule note below).
 // The L1 loss between the same two images rides along (forward: |x1 - x2| of the strip's own pixels;
 // backward: its sign term is added to the SSIM gradient), so the loop's two image losses cost one pass.
 // Forward evaluates the SSIM map and — because the loss is always differentiated — the three partial
@@ -27,12 +28,45 @@ constexpr int R = 5, WIN = 11;
 #ifndef GANET_SSIM_STRIP
 #define GANET_SSIM_STRIP 34
 #endif
-constexpr int STRIP = GANET_SSIM_STRIP;   // output rows per wave (STRIP + 10 input rows = whole rounds of 11)
-constexpr int WAVES = 4;                  // strips stacked in a workgroup
-constexpr int LINE = 64 + 2 * R + 6;      // LDS line per input map (padded to 80 floats)
+#ifndef GANET_SSIM_WAVES
+#define GANET_SSIM_WAVES 4
+#endif
+constexpr int STRIP = GANET_SSIM_STRIP;   // output rows per wave; STRIP + 10 input rows are streamed
+constexpr int WAVES = GANET_SSIM_WAVES;   // strips stacked in a workgroup
+#ifndef GANET_SSIM_AHEAD
+#define GANET_SSIM_AHEAD 3
+#endif
+constexpr int AHEAD = GANET_SSIM_AHEAD;   // rows between a row's global loads and its filtering (1..11)
+constexpr int ROUNDS = (STRIP + 2 * R + WIN - 1) / WIN;
+constexpr int LINE = 64 + 2 * R + 6;      // LDS line (padded to 80 entries)
 constexpr float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+// The two sums: 3,000 waves adding into one cache line would serialise at the memory-side atomic unit
+// (~15 ns each, 45 us — more than the kernel's arithmetic), so every wave adds into one of SUM_SLOTS
+// partial sums on cache lines of their own and bumps that slot's arrival counter; the wave that completes
+// a slot folds it into sums[0..1] (SUM_SLOTS additions on the result's line in total).
+constexpr int SUM_SLOTS = 64, SUM_LINE = 64;             // floats per line (256 B)
+constexpr int SUM_FLOATS = SUM_LINE * (1 + SUM_SLOTS);   // what `sums` must hold; zeroed by the host call
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Window { float w[WIN]; };
+
+// The SIMD's arbiter issues oldest-wave-first. A wave alone can issue one instruction every ~6 cycles, so the
+// three resident waves of a SIMD finished as a staircase (22 / 30 / 38 us, tools/ssim_trace.py): the oldest ran
+// at its solo speed, the others in its gaps, and the last one finished alone. A wave therefore lowers its own
+// priority as it advances (3 in the first quarter of its rounds ... 0 in the last): whoever is behind issues
+// first, the waves stay within a round of each other and the VALU stays busy until they all end together.
+__device__ __forceinline__ void progress_priority(int round) {
+  if (round == 0) __builtin_amdgcn_s_setprio(3);
+  else if (round == (ROUNDS + 3) / 4) __builtin_amdgcn_s_setprio(2);
+  else if (round == (2 * ROUNDS + 3) / 4) __builtin_amdgcn_s_setprio(1);
+  else if (round == (3 * ROUNDS + 3) / 4) __builtin_amdgcn_s_setprio(0);
+}
+
+#ifdef GANET_SSIM_TRACE   // dev build: per-wave residency (tools/ssim_trace.py)
+__device__ unsigned long long g_ssim_trace[8192][4];
+#endif
 
 Window make_window() {
   Window k;
@@ -42,118 +76,166 @@ Window make_window() {
   return k;
 }
 
-// Streams the rows ys-5 .. ys+STRIP+4 of NIN input maps through the wave. `horiz(taps, h, own)` turns
-// the 11 taps of every input map at this lane's column into NQ horizontally filtered values (`own`: the
-// input row belongs to this wave's strip, i.e. taps[.][5] is a pixel no other wave visits as a centre);
-// `emit(y, v)` receives the NQ fully filtered values of output row y (only rows of the strip that exist).
-template <int NIN, int NQ, class Horiz, class Emit>
-__device__ __forceinline__ void stream_strip(const float* const* src, int H, int W, int x0, int ys,
-                                             float* line, const Window& k, Horiz horiz, Emit emit) {
-  const int lane = threadIdx.x & 63;
-  float acc[WIN][NQ];
-#pragma unroll
-  for (int j = 0; j < WIN; ++j)
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[j][q] = 0.f;
-  const int gx0 = x0 - R + lane;                 // first column this lane stages
-  const int gx1 = x0 + 64 - R + lane;            // lanes 0..9: the right halo
-  const bool c0 = gx0 >= 0 && gx0 < W, c1 = lane < 2 * R && gx1 < W;
-  // the next row's values are fetched into registers while the current row is being filtered
-  float nv0[NIN], nv1[NIN];
-  auto fetch = [&](int y) {
-    const bool rowok = y >= 0 && y < H;
-#pragma unroll
-    for (int q = 0; q < NIN; ++q) {
-      const float* row = src[q] + (size_t)(rowok ? y : 0) * W;
-      nv0[q] = (rowok && c0) ? row[gx0] : 0.f;
-      nv1[q] = (rowok && c1) ? row[gx1] : 0.f;
-    }
-  };
-  fetch(ys - R);
-  for (int base = -R; base < STRIP + R; base += WIN) {
-#pragma unroll
-    for (int j = 0; j < WIN; ++j) {              // row r = base + j sits in ring slot j
-      const int r = base + j;
-      const int y = ys + r;
-      __builtin_amdgcn_wave_barrier();           // previous row's LDS reads are done (in-order LDS)
-#pragma unroll
-      for (int q = 0; q < NIN; ++q) {
-        line[q * LINE + lane] = nv0[q];
-        if (lane < 2 * R) line[q * LINE + 64 + lane] = nv1[q];
-      }
-      __builtin_amdgcn_wave_barrier();
-      fetch(y + 1);
-      float taps[NIN][WIN];
-#pragma unroll
-      for (int q = 0; q < NIN; ++q)
-#pragma unroll
-        for (int t = 0; t < WIN; ++t) taps[q][t] = line[q * LINE + lane + t];
-      float h[NQ];
-      horiz(taps, h, r >= 0 && r < STRIP && y < H);
-      // scatter into the output rows r-5 .. r+5 (ring slots (j + d) mod 11), weight w[5 - d]
-#pragma unroll
-      for (int d = -R; d <= R; ++d) {
-        const int slot = (j + d + WIN) % WIN;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[slot][q] = fmaf(k.w[R - d], h[q], acc[slot][q]);
-      }
-      // output row r-5 is complete
-      const int done = (j + WIN - R) % WIN;
-      const int yo = y - R;
-      if (r - R >= 0 && r - R < STRIP && yo < H) emit(yo, acc[done]);
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) acc[done][q] = 0.f;
-    }
-  }
+// Buffer loads and stores: an element outside the plane (or a row this wave does not need) is addressed at
+// offset ~0u, which the hardware answers with 0 (drops, for a store) without touching memory — the
+// convolution's zero padding and every "skip this access" case cost no branch, so the prefetched values
+// have no control dependence that would make the compiler wait for them early.
+constexpr uint32_t kSkip = 0xffffffffu;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float* p, int H, int W) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, H * W * 4, 0x00020000);
 }
+// `col` is the lane's byte offset inside a row (kSkip: the column does not exist), `row` the row's byte
+// offset (wave-uniform, travels in an SGPR), `rowok` whether this wave wants the row at all.
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, uint32_t col, uint32_t row, bool rowok) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, rowok ? col : kSkip, rowok ? row : 0u, 0));
+}
+__device__ __forceinline__ void buf_store(float v, __amdgpu_buffer_rsrc_t r, uint32_t col, uint32_t row) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, col, row, 0);
+}
+
+// Both kernels share one schedule. Input row r = base + j (relative to the strip's first output row)
+// lives in ring slot j of three rings that are all indexed statically (the j loop is fully unrolled):
+//   * the PREFETCH ring: the row's global loads are issued one whole round (11 rows) before the row is
+//     staged through LDS, so a wave has up to 11 rows in flight and never waits a memory round trip per row;
+//   * the ACCUMULATOR ring: 11 partially summed output rows (each filtered input row is scattered into
+//     the 11 output rows it contributes to; the oldest one is then complete);
+//   * (backward) the SIDE ring: the image pixels the finished output row needs, fetched a round ahead too.
+// The maps of a row travel through LDS interleaved (one 8- or 16-byte entry per column), so a tap is one
+// ds_read and the filters run on packed pairs (v_pk_fma_f32).
 
 __global__ void __launch_bounds__(64 * WAVES)
 ssim_fwd_kernel(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
                 float norm, float* __restrict__ sums, float* __restrict__ partials, size_t map_stride,
-                Window k) {
-  __shared__ float s_line[WAVES][2 * LINE];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+                int strips, Window k) {
+  __shared__ f32x2 s_line[WAVES][LINE];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int plane = blockIdx.z;
   const int x0 = blockIdx.x * 64, ys = (blockIdx.y * WAVES + wave) * STRIP;
   if (ys >= H) return;
+#ifdef GANET_SSIM_TRACE
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#endif
+  f32x2* line = s_line[wave];
   const size_t poff = (size_t)plane * H * W;
-  const float* src[2] = {img1 + poff, img2 + poff};
+  const __amdgpu_buffer_rsrc_t a_img = plane_rsrc(img1 + poff, H, W), b_img = plane_rsrc(img2 + poff, H, W);
+  const __amdgpu_buffer_rsrc_t o_mu = plane_rsrc(partials + poff, H, W),
+                               o_11 = plane_rsrc(partials + map_stride + poff, H, W),
+                               o_12 = plane_rsrc(partials + 2 * map_stride + poff, H, W);
   const int gx = x0 + lane;
-  float S = 0.f, L = 0.f;
-  auto horiz = [&](const float (*taps)[WIN], float* h, bool own) {
-    L += (own && gx < W) ? fabsf(taps[0][R] - taps[1][R]) : 0.f;      // L1 rides along
-    float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+  const int gx0 = x0 - R + lane;                 // first column this lane stages
+  const int gx1 = x0 + 64 - R + lane;            // lanes 0..9: the right halo
+  const uint32_t col0 = (gx0 >= 0 && gx0 < W) ? (uint32_t)gx0 * 4u : kSkip;
+  const uint32_t col1 = (lane < 2 * R && gx1 < W) ? (uint32_t)gx1 * 4u : kSkip;
+  const uint32_t colx = gx < W ? (uint32_t)gx * 4u : kSkip;
+  const float inside = gx < W ? 1.f : 0.f;
+
+  f32x2 p0[WIN], p1[WIN];                        // prefetch ring: (x1, x2) at gx0 / gx1
+  auto fetch = [&](f32x2& v0, f32x2& v1, int r) {   // input row ys + r
+    const int y = ys + r;
+    const bool rowok = y >= 0 && y < H && r < STRIP + R;
+    const uint32_t row = (uint32_t)(y * W) * 4u;
+    v0 = f32x2{buf_load(a_img, col0, row, rowok), buf_load(b_img, col0, row, rowok)};
+    v1 = f32x2{buf_load(a_img, col1, row, rowok), buf_load(b_img, col1, row, rowok)};
+  };
+  f32x2 acc_m[WIN], acc_e[WIN];                  // (mu1, mu2), (E11, E22)
+  float acc_x[WIN];                              // E12
 #pragma unroll
-    for (int t = 0; t < WIN; ++t) {
-      const float a = taps[0][t], b = taps[1][t];
-      const float wa = k.w[t] * a, wb = k.w[t] * b;
-      m1 += wa; m2 += wb;
-      e11 = fmaf(wa, a, e11); e22 = fmaf(wb, b, e22); e12 = fmaf(wa, b, e12);
+  for (int j = 0; j < WIN; ++j) {
+    acc_m[j] = f32x2{0.f, 0.f};
+    acc_e[j] = f32x2{0.f, 0.f};
+    acc_x[j] = 0.f;
+    if (j < AHEAD) fetch(p0[j], p1[j], j - R);
+  }
+  float S = 0.f, L = 0.f;
+#pragma unroll 1
+  for (int round = 0; round < ROUNDS; ++round) {
+    const int base = -R + round * WIN;
+    progress_priority(round);
+#pragma unroll
+    for (int j = 0; j < WIN; ++j) {
+      const int r = base + j;
+      if (r >= STRIP + R) break;                 // uniform; only in the last round
+      const int y = ys + r;
+      __builtin_amdgcn_wave_barrier();           // the previous row's reads were issued before (in-order LDS)
+      line[lane] = p0[j];
+      if (lane < 2 * R) line[64 + lane] = p1[j];
+      __builtin_amdgcn_wave_barrier();
+      fetch(p0[(j + AHEAD) % WIN], p1[(j + AHEAD) % WIN], r + AHEAD);
+      f32x2 t[WIN];
+#pragma unroll
+      for (int i = 0; i < WIN; ++i) t[i] = line[lane + i];
+      if (r >= 0 && r < STRIP) L += fabsf(t[R].x - t[R].y);   // L1 rides along (rows/columns outside are 0 - 0)
+      f32x2 m = f32x2{0.f, 0.f}, e = f32x2{0.f, 0.f};
+      float x = 0.f;
+#pragma unroll
+      for (int i = 0; i < WIN; ++i) {
+        const f32x2 wt = t[i] * k.w[i];
+        m += wt;
+        e = wt * t[i] + e;
+        x = fmaf(wt.x, t[i].y, x);
+      }
+      // scatter into the output rows r-5 .. r+5 (ring slots (j + d) mod 11), weight w[5 - d]
+#pragma unroll
+      for (int d = -R; d <= R; ++d) {
+        const int slot = (j + d + WIN) % WIN;
+        const float wv = k.w[R - d];
+        acc_m[slot] = m * wv + acc_m[slot];
+        acc_e[slot] = e * wv + acc_e[slot];
+        acc_x[slot] = fmaf(wv, x, acc_x[slot]);
+      }
+      const int done = (j + WIN - R) % WIN;      // output row r-5 is complete
+      const int yo = y - R;
+      if (r - R >= 0 && r - R < STRIP && yo < H) {          // uniform
+        const float m1 = acc_m[done].x, m2 = acc_m[done].y, e11 = acc_e[done].x, e22 = acc_e[done].y;
+        const float e12 = acc_x[done];
+        const float n1 = 2.f * m1 * m2 + C1;
+        const float n2 = 2.f * (e12 - m1 * m2) + C2;
+        const float d1 = m1 * m1 + m2 * m2 + C1;
+        const float d2 = (e11 - m1 * m1) + (e22 - m2 * m2) + C2;
+        const float i1 = __builtin_amdgcn_rcpf(d1), i2 = __builtin_amdgcn_rcpf(d2);
+        const float inv = i1 * i2;
+        const float Sv = n1 * n2 * inv;
+        S = fmaf(inside, Sv, S);
+        const uint32_t row = (uint32_t)(yo * W) * 4u;
+        buf_store(2.f * m2 * (n2 - n1) * inv - 2.f * m1 * Sv * (i1 - i2), o_mu, colx, row);   // dS/dmu1
+        buf_store(-Sv * i2, o_11, colx, row);                                                 // dS/dE[x1^2]
+        buf_store(2.f * n1 * inv, o_12, colx, row);                                           // dS/dE[x1 x2]
+      }
+      acc_m[done] = f32x2{0.f, 0.f};
+      acc_e[done] = f32x2{0.f, 0.f};
+      acc_x[done] = 0.f;
     }
-    h[0] = m1; h[1] = m2; h[2] = e11; h[3] = e22; h[4] = e12;
-  };
-  auto emit = [&](int y, const float* v) {
-    if (gx >= W) return;
-    const float m1 = v[0], m2 = v[1], e11 = v[2], e22 = v[3], e12 = v[4];
-    const float n1 = 2.f * m1 * m2 + C1;
-    const float n2 = 2.f * (e12 - m1 * m2) + C2;
-    const float d1 = m1 * m1 + m2 * m2 + C1;
-    const float d2 = (e11 - m1 * m1) + (e22 - m2 * m2) + C2;
-    const float inv = 1.0f / (d1 * d2);
-    const float Sv = n1 * n2 * inv;
-    S += Sv;
-    const size_t o = poff + (size_t)y * W + gx;
-    partials[o] = 2.f * m2 * (n2 - n1) * inv - 2.f * m1 * Sv * (1.0f / d1 - 1.0f / d2);   // dS/dmu1
-    partials[map_stride + o] = -Sv / d2;                                                   // dS/dE[x1^2]
-    partials[2 * map_stride + o] = 2.f * n1 * inv;                                         // dS/dE[x1 x2]
-  };
-  stream_strip<2, 5>(src, H, W, x0, ys, s_line[wave], k, horiz, emit);
+  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     S += __shfl_xor(S, off);
     L += __shfl_xor(L, off);
   }
-  if (lane < 2) atomicAdd(sums + lane, (lane ? L : S) * norm);
+  // the waves that exist (ys < H) are numbered densely: that is what the per-slot arrival counts assume
+  const uint32_t wid = ((uint32_t)plane * gridDim.x + blockIdx.x) * strips + (blockIdx.y * WAVES + wave);
+  const uint32_t total = gridDim.z * gridDim.x * strips;
+  const uint32_t slot = wid % SUM_SLOTS, expected = (total - slot + SUM_SLOTS - 1) / SUM_SLOTS;
+  float* sl = sums + SUM_LINE * (1 + slot);
+  // Device-scope atomics are performed at the memory side, so "the addition's old value has come back"
+  // means it is visible to every later atomic: order the arrival count behind it through a data dependence
+  // (no fence — a fence would also write this XCD's L2 back, once per wave).
+  float seen = 0.f;
+  if (lane < 2) seen = atomicAdd(sl + lane, (lane ? L : S) * norm);
+  uint32_t one = 1u;
+  asm volatile("" : "+v"(one) : "v"(seen));
+  uint32_t prev = 0;
+  if (lane == 0) prev = atomicAdd(reinterpret_cast<uint32_t*>(sl + 2), one);
+  if (__builtin_amdgcn_readfirstlane(prev) + 1 == expected) {
+    if (lane < 2) atomicAdd(sums + lane, atomicAdd(sl + lane, 0.f));
+  }
+#ifdef GANET_SSIM_TRACE
+  if (lane == 0 && wid < 8192) {
+    g_ssim_trace[wid][0] = t_start;
+    g_ssim_trace[wid][1] = __builtin_amdgcn_s_memrealtime();
+    g_ssim_trace[wid][2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_ID
+    g_ssim_trace[wid][3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // XCC_ID
+  }
+#endif
 }
 
 __global__ void __launch_bounds__(64 * WAVES)
@@ -161,34 +243,94 @@ ssim_bwd_kernel(int H, int W, const float* __restrict__ img1, const float* __res
                 const float* __restrict__ partials, size_t map_stride, float norm,
                 const float* __restrict__ d_ssim, const float* __restrict__ d_l1,
                 float* __restrict__ dimg1, Window k) {
-  __shared__ float s_line[WAVES][3 * LINE];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __shared__ f32x4 s_line[WAVES][LINE];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int plane = blockIdx.z;
   const int x0 = blockIdx.x * 64, ys = (blockIdx.y * WAVES + wave) * STRIP;
   if (ys >= H) return;
+  f32x4* line = s_line[wave];
   const size_t poff = (size_t)plane * H * W;
-  const float* src[3] = {partials + poff, partials + map_stride + poff, partials + 2 * map_stride + poff};
+  const __amdgpu_buffer_rsrc_t pa = plane_rsrc(partials + poff, H, W),
+                               pb = plane_rsrc(partials + map_stride + poff, H, W),
+                               pc = plane_rsrc(partials + 2 * map_stride + poff, H, W),
+                               xa = plane_rsrc(img1 + poff, H, W), xb = plane_rsrc(img2 + poff, H, W),
+                               od = plane_rsrc(dimg1 + poff, H, W);
   const int gx = x0 + lane;
+  const int gx0 = x0 - R + lane, gx1 = x0 + 64 - R + lane;
+  const uint32_t col0 = (gx0 >= 0 && gx0 < W) ? (uint32_t)gx0 * 4u : kSkip;
+  const uint32_t col1 = (lane < 2 * R && gx1 < W) ? (uint32_t)gx1 * 4u : kSkip;
+  const uint32_t colx = gx < W ? (uint32_t)gx * 4u : kSkip;
   const float scale = d_ssim ? norm * d_ssim[0] : 0.f;
   const float l1s = d_l1 ? norm * d_l1[0] : 0.f;
-  auto horiz = [&](const float (*taps)[WIN], float* h, bool) {
-    float a = 0.f, b = 0.f, c = 0.f;
+
+  f32x4 p0[WIN], p1[WIN];                        // prefetch ring: the three derivative maps at gx0 / gx1
+  f32x2 side[WIN];                               // side ring: (x1, x2) of the output row the slot completes
+  auto fetch = [&](f32x4& v0, f32x4& v1, int r) {   // input row ys + r
+    const int y = ys + r;
+    const bool rowok = y >= 0 && y < H && r < STRIP + R;
+    const uint32_t row = (uint32_t)(y * W) * 4u;
+    v0 = f32x4{buf_load(pa, col0, row, rowok), buf_load(pb, col0, row, rowok), buf_load(pc, col0, row, rowok), 0.f};
+    v1 = f32x4{buf_load(pa, col1, row, rowok), buf_load(pb, col1, row, rowok), buf_load(pc, col1, row, rowok), 0.f};
+  };
+  auto fetch_side = [&](f32x2& v, int ro) {      // output row ys + ro
+    const int yo = ys + ro;
+    const bool rowok = ro >= 0 && ro < STRIP && yo < H;
+    const uint32_t row = (uint32_t)(yo * W) * 4u;
+    v = f32x2{buf_load(xa, colx, row, rowok), buf_load(xb, colx, row, rowok)};
+  };
+  f32x2 acc_ab[WIN];
+  float acc_c[WIN];
 #pragma unroll
-    for (int t = 0; t < WIN; ++t) {
-      a = fmaf(k.w[t], taps[0][t], a);
-      b = fmaf(k.w[t], taps[1][t], b);
-      c = fmaf(k.w[t], taps[2][t], c);
+  for (int j = 0; j < WIN; ++j) {
+    acc_ab[j] = f32x2{0.f, 0.f};
+    acc_c[j] = 0.f;
+    if (j < AHEAD) {
+      fetch(p0[j], p1[j], j - R);
+      fetch_side(side[j], j - 2 * R);
     }
-    h[0] = a; h[1] = b; h[2] = c;
-  };
-  auto emit = [&](int y, const float* v) {
-    if (gx >= W) return;
-    const size_t o = poff + (size_t)y * W + gx;
-    const float a = img1[o], b = img2[o];
-    const float sg = (a > b) ? l1s : ((a < b) ? -l1s : 0.f);
-    dimg1[o] = fmaf(scale, v[0] + 2.f * a * v[1] + b * v[2], sg);
-  };
-  stream_strip<3, 3>(src, H, W, x0, ys, s_line[wave], k, horiz, emit);
+  }
+#pragma unroll 1
+  for (int round = 0; round < ROUNDS; ++round) {
+    const int base = -R + round * WIN;
+    progress_priority(round);
+#pragma unroll
+    for (int j = 0; j < WIN; ++j) {
+      const int r = base + j;
+      if (r >= STRIP + R) break;
+      const int y = ys + r;
+      __builtin_amdgcn_wave_barrier();
+      line[lane] = p0[j];
+      if (lane < 2 * R) line[64 + lane] = p1[j];
+      __builtin_amdgcn_wave_barrier();
+      fetch(p0[(j + AHEAD) % WIN], p1[(j + AHEAD) % WIN], r + AHEAD);
+      f32x2 ab = f32x2{0.f, 0.f};
+      float c = 0.f;
+#pragma unroll
+      for (int i = 0; i < WIN; ++i) {
+        const f32x4 t = line[lane + i];
+        ab = f32x2{t.x, t.y} * k.w[i] + ab;
+        c = fmaf(k.w[i], t.z, c);
+      }
+#pragma unroll
+      for (int d = -R; d <= R; ++d) {
+        const int slot = (j + d + WIN) % WIN;
+        const float wv = k.w[R - d];
+        acc_ab[slot] = ab * wv + acc_ab[slot];
+        acc_c[slot] = fmaf(wv, c, acc_c[slot]);
+      }
+      const int done = (j + WIN - R) % WIN;
+      const int yo = y - R;
+      if (r - R >= 0 && r - R < STRIP && yo < H) {          // uniform
+        const float a = side[j].x, b = side[j].y;
+        const float sg = (a > b) ? l1s : ((a < b) ? -l1s : 0.f);
+        buf_store(fmaf(scale, acc_ab[done].x + 2.f * a * acc_ab[done].y + b * acc_c[done], sg), od, colx,
+                  (uint32_t)(yo * W) * 4u);
+      }
+      fetch_side(side[(j + AHEAD) % WIN], r - R + AHEAD);
+      acc_ab[done] = f32x2{0.f, 0.f};
+      acc_c[done] = 0.f;
+    }
+  }
 }
 
 }  // namespace
@@ -199,6 +341,12 @@ using namespace ganet;
 
 extern "C" {
 
+#ifdef GANET_SSIM_TRACE
+int ganet_dev_ssim_trace(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ssim_trace), sizeof(g_ssim_trace)); }
+#endif
+
+int64_t ganet_ssim_sums_floats(void) { return SUM_FLOATS; }
+
 int ganet_ssim_fwd(int32_t planes, int32_t H, int32_t W, const float* img1, const float* img2, float norm,
                    float* sums, float* partials, void* stream_) {
   if (planes <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !sums || !partials) {
@@ -206,12 +354,13 @@ int ganet_ssim_fwd(int32_t planes, int32_t H, int32_t W, const float* img1, cons
     return 1;
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  int rc = check_hip(hipMemsetAsync(sums, 0, 2 * sizeof(float), stream), "memset ssim sums");
+  int rc = check_hip(hipMemsetAsync(sums, 0, SUM_FLOATS * sizeof(float), stream), "memset ssim sums");
   if (rc) return rc;
-  const dim3 grid((W + 63) / 64, (H + STRIP * WAVES - 1) / (STRIP * WAVES), planes);
+  const int strips = (H + STRIP - 1) / STRIP;
+  const dim3 grid((W + 63) / 64, (strips + WAVES - 1) / WAVES, planes);
   ProfScope prof_(K_SSIM_FWD, stream);
   hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(64 * WAVES), 0, stream, H, W, img1, img2, norm, sums,
-                     partials, (size_t)planes * H * W, make_window());
+                     partials, (size_t)planes * H * W, strips, make_window());
   return check_hip(hipGetLastError(), "ssim_fwd_kernel");
 }
 

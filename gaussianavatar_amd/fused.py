@@ -177,7 +177,7 @@ class _SsimL1Fn(torch.autograd.Function):
         planes = img1.numel() // (H * W)
         a = img1.contiguous().float()
         b = img2.contiguous().float()
-        sums = torch.empty(2, dtype=torch.float32, device=a.device)
+        sums = torch.empty(lib.ganet_ssim_sums_floats(), dtype=torch.float32, device=a.device)
         partials = torch.empty((3, planes, H, W), dtype=torch.float32, device=a.device)
         _native.ganet_check(lib.ganet_ssim_fwd(planes, H, W, _ptr(a), _ptr(b), 1.0 / float(a.numel()), _ptr(sums),
                                                _ptr(partials), _stream(a.device)))

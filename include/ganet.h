@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GANET_ABI_VERSION 4
+#define GANET_ABI_VERSION 5
 #define GANET_MAX_TERMS 8
 
 /* ---- dW[N,K] = sum_m g[m,n] x[m,k] ; db[N] = sum_m g[m,n] (db may be NULL).
@@ -65,7 +65,9 @@ int ganet_bn_act_bwd(int64_t M, int32_t C, const float* x, const float* gamma, c
  * gives utils/loss_utils.py's ssim(...) and l1_loss_w(...)), and three partial-derivative maps
  * [3, planes, H, W] into `partials` for the backward pass. Backward:
  * dimg1 = norm * (d_ssim[0] * d(sum SSIM)/dimg1 + d_l1[0] * sign(img1 - img2)); d_ssim / d_l1 are device
- * scalars, either may be NULL (= 0). */
+ * scalars, either may be NULL (= 0). `sums` holds ganet_ssim_sums_floats() floats (the two results first,
+ * then the partial sums the waves spread their additions over); the call zeroes all of it. */
+int64_t ganet_ssim_sums_floats(void);
 int ganet_ssim_fwd(int32_t planes, int32_t H, int32_t W, const float* img1, const float* img2, float norm,
                    float* sums, float* partials, void* stream);
 int ganet_ssim_bwd(int32_t planes, int32_t H, int32_t W, const float* img1, const float* img2,
