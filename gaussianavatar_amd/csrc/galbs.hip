@@ -380,14 +380,23 @@ skin_kernel(int B, int N, int J, const float* __restrict__ points, int64_t pts_s
 }
 
 // dL/dM_j = sum_n w_nj [g_n (x) (x_n, 1)] as a skinny GEMM on the matrix cores:  D[j][e] += W^T[j][n] O[n][e]
-// with O[n][4r+c] = g_n[r] * (x_n, 1)[c] (12 columns). v_mfma_f32_32x32x2_f32 takes two texels per
-// step: lane (col, half) supplies w[n0+half][col] as the A operand and builds its own B element from
-// g and x of texel n0+half. A wave walks a contiguous chunk of texels, the four waves of a workgroup
-// combine in LDS, one global atomic per (joint, entry) and workgroup. Replaces a per-joint wave
-// reduction (12 x 6 shuffles per active joint and texel group).
+// with O[n][4r+c] = g_n[r] * (x_n, 1)[c] (12 columns). v_mfma_f32_32x32x2_f32 takes two texels per step:
+// lane (col, half) supplies w[n0+half][col] as the A operand and builds its own B element from g and x of
+// texel n0+half. The operands of a chunk of 32 texels are contiguous in memory (32 J weights, 96 + 96 (+ 96)
+// floats of dout / points / res): a wave fetches them with a handful of 16-byte buffer loads (rows past N read
+// as 0), one chunk ahead, parks them in its own slice of LDS and picks the MFMA operands out of it with
+// 4-byte LDS reads — the first version loaded every operand element straight from global memory, 64 load
+// instructions per chunk instead of 6, and was bound by the address unit (52 us for 53 MB). The 16 waves of a
+// workgroup add their tiles in LDS; one global atomic per (joint, entry) and workgroup.
 typedef float skin_f32x16 __attribute__((ext_vector_type(16)));
+typedef float skin_f32x4 __attribute__((ext_vector_type(4)));
 constexpr int DM_BLOCKS = 128;
-constexpr int DM_THREADS = 1024;        // 16 waves combine in LDS before the global atomics
+constexpr int DM_THREADS = 1024;        // 16 waves
+constexpr int DM_CHUNK = 32;            // texels per chunk
+
+__device__ __forceinline__ skin_f32x4 dm_load4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  return __builtin_bit_cast(skin_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
 
 template <int JT>     // joint tiles of 32 (1: SMPL, 2: SMPL-X)
 __global__ void __launch_bounds__(DM_THREADS)
@@ -395,20 +404,41 @@ skin_dmats_kernel(int N, int J, const float* __restrict__ points, int64_t pts_st
                   const float* __restrict__ res, int64_t res_stride,
                   const float* __restrict__ weights, int64_t w_stride,
                   const float* __restrict__ dout, float* __restrict__ dmats) {
-  __shared__ float s_acc[DM_THREADS / 64][JT * 32][12];     // one tile per wave, summed afterwards
-  const int b = blockIdx.y;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int half = lane >> 5, col = lane & 31;
-  points += (size_t)b * pts_stride;
-  if (res) res += (size_t)b * res_stride;
-  weights += (size_t)b * w_stride;
-  dout += (size_t)b * N * 3;
-  // this wave's texels: [n0, n1)
   constexpr int WPB = DM_THREADS / 64;
-  const int per = (N + gridDim.x * WPB - 1) / (gridDim.x * WPB);
-  const int per2 = (per + 1) & ~1;
-  const int n0 = (blockIdx.x * WPB + wave) * per2;
-  const int n1 = min(n0 + per2, N);
+  constexpr int NW = JT * DM_CHUNK * 32 / 256;           // 16-byte loads per lane that cover a chunk's weights
+  constexpr int SLICE = JT * DM_CHUNK * 32 + 2 * 128;    // floats per wave: weights, dout, points (+ res)
+  static_assert(SLICE >= JT * 32 * 12, "the wave's result tile reuses its slice");
+  __shared__ __attribute__((aligned(16))) float s_all[WPB][SLICE];
+  const int b = blockIdx.y;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int half = lane >> 5, col = lane & 31;
+  const uint32_t kSkip = 0xffffffffu;
+  const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(weights + (size_t)b * w_stride), 0, N * J * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_g = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(dout + (size_t)b * N * 3), 0, N * 12, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_p = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(points + (size_t)b * pts_stride), 0, N * 12, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_r = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(res ? res + (size_t)b * res_stride : points), 0, res ? N * 12 : 0, 0x00020000);
+  float* s_w = s_all[wave];
+  float* s_g = s_w + JT * DM_CHUNK * 32;
+  float* s_x = s_g + 128;
+  const int chunks = (N + DM_CHUNK - 1) / DM_CHUNK, stride = gridDim.x * WPB;
+  const int wlen = DM_CHUNK * J;                         // floats of weights per chunk
+
+  skin_f32x4 wv[NW], gv, pv;
+  auto fetch = [&](int c) {
+    const bool live = c < chunks;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int f = 4 * lane + 256 * i;
+      wv[i] = dm_load4(r_w, (live && f < wlen) ? (uint32_t)(c * wlen + f) * 4u : kSkip);
+    }
+    const uint32_t o = (live && lane < 24) ? (uint32_t)(c * 96 + 4 * lane) * 4u : kSkip;
+    gv = dm_load4(r_g, o);
+    pv = dm_load4(r_p, o) + dm_load4(r_r, o);
+  };
   skin_f32x16 acc[JT];
 #pragma unroll
   for (int t = 0; t < JT; ++t)
@@ -416,49 +446,47 @@ skin_dmats_kernel(int N, int J, const float* __restrict__ points, int64_t pts_st
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   const int er = col >> 2, ec = col & 3;       // B element (row of g, column of (x,1)) of this lane
   const bool eok = col < 12;
-  constexpr int U = 8;                          // steps whose loads are issued together
-  for (int nb = n0; nb < n1; nb += 2 * U) {
-    float av[U][JT], gv[U], xv[U];
+  int c = blockIdx.x * WPB + wave;
+  fetch(c);
+  for (; c < chunks; c += stride) {
+    __builtin_amdgcn_wave_barrier();            // the previous chunk's LDS reads were issued before (in-order LDS)
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int n = nb + 2 * u + half;
-      const bool ok = n < n1;
-      const int nn = ok ? n : n0;
-      gv[u] = (ok && eok) ? dout[(size_t)nn * 3 + er] : 0.f;
-      float xc = 1.f;
-      if (ec < 3) {
-        xc = points[(size_t)nn * 3 + ec];
-        if (res) xc += res[(size_t)nn * 3 + ec];
-      }
-      xv[u] = xc;
+    for (int i = 0; i < NW; ++i)
+      if (4 * lane + 256 * i < wlen) *reinterpret_cast<skin_f32x4*>(s_w + 4 * lane + 256 * i) = wv[i];
+    if (lane < 24) {
+      *reinterpret_cast<skin_f32x4*>(s_g + 4 * lane) = gv;
+      *reinterpret_cast<skin_f32x4*>(s_x + 4 * lane) = pv;
+    }
+    __builtin_amdgcn_wave_barrier();
+    fetch(c + stride);
+#pragma unroll
+    for (int st = 0; st < DM_CHUNK / 2; ++st) {
+      const int n = 2 * st + half;
+      const float g = s_g[n * 3 + (eok ? er : 0)];
+      const float x = ec < 3 ? s_x[n * 3 + ec] : 1.f;
+      const float bval = eok ? g * x : 0.f;
 #pragma unroll
       for (int t = 0; t < JT; ++t) {
-        const int j = min(t * 32 + col, J - 1);
-        const float w = weights[(size_t)nn * J + j];
-        av[u][t] = (ok && t * 32 + col < J) ? w : 0.f;
+        const int j = t * 32 + col;
+        const float a = s_w[n * J + (j < J ? j : 0)];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(j < J ? a : 0.f, bval, acc[t], 0, 0, 0);
       }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const float bval = gv[u] * xv[u];
-#pragma unroll
-      for (int t = 0; t < JT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][t], bval, acc[t], 0, 0, 0);
     }
   }
   // D layout: column e = lane & 31, row j = (reg & 3) + 8 * (reg >> 2) + 4 * half
+  __builtin_amdgcn_wave_barrier();
   if (eok) {
 #pragma unroll
     for (int t = 0; t < JT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s_acc[wave][t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half][col] = acc[t][r];
+      for (int r = 0; r < 16; ++r) s_w[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 12 + col] = acc[t][r];
   }
   __syncthreads();
   for (int q = threadIdx.x; q < J * 12; q += DM_THREADS) {
-    const int j = q / 12, e = q - j * 12;
     float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < DM_THREADS / 64; ++w) v += s_acc[w][j][e];
-    if (v != 0.f) unsafeAtomicAdd(&dmats[((size_t)b * J + j) * 16 + e], v);
+    for (int w = 0; w < WPB; ++w) v += s_all[w][q];
+    if (v != 0.f) unsafeAtomicAdd(&dmats[((size_t)b * J + q / 12) * 16 + q % 12], v);
   }
 }
 

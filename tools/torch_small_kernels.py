@@ -1,0 +1,35 @@
+#!/usr/bin/env python
+"""Which aten ops launch the small torch / runtime kernels of the headline iteration (fills, copies, element-wise, reduce):
+torch.profiler over 5 iterations, ops that ran a device kernel, sorted by device time, with input shapes."""
+import os, sys, types
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch.profiler import profile, ProfilerActivity
+import bench
+from gaussianavatar_amd.avatar_model import AvatarModel, collate_frames, default_params
+from gaussianavatar_amd.losses import l1_loss_w, ssim, weighted_sum
+dev = torch.device("cuda")
+torch.manual_seed(0)
+B, N, S = 2, 200_000, 1024
+mp, npar, op = default_params(batch_size=B, num_points=N, image_width=S, image_height=S, num_frames=16, train_stage=1,
+                              smpl_type="smpl", query_posmap_size=512)
+model = AvatarModel(mp, npar, op, train=True, device=dev); model.training_setup(); model.net.train()
+ds = model.train_dataset
+gt = torch.ones(B, 3, S, S, device=dev)
+batches = [collate_frames([ds[(s * B + k) % len(ds)] for k in range(B)], dev) for s in range(2)]
+l = op.lambda_dssim
+def step(i):
+    image, points, offset_loss, geo_loss, scale_loss = model.train_stage1(batches[i % 2], 1)
+    loss = weighted_sum([scale_loss, offset_loss, l1_loss_w(image, gt), ssim(image, gt), geo_loss],
+                        [op.lambda_scale, op.lambda_rgl, 1.0 - l, -l, 1.0], bias=l)
+    model.zero_grad(1); loss.backward(); model.step(1)
+for i in range(5): step(i)
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
+    for i in range(5): step(i)
+    torch.cuda.synchronize()
+rows = [e for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=6) if e.self_device_time_total > 0 and e.key.startswith("aten::")]
+for e in sorted(rows, key=lambda e: -e.self_device_time_total)[:45]:
+    st = [s_ for s_ in (e.stack or []) if "gaussianavatar_amd" in s_ or "bench" in s_ or "tools/" in s_][:2]
+    print("%6.1f us/iter %4.1f calls/iter  %-26s %-56s %s" % (e.self_device_time_total / 5, e.count / 5, e.key, str(e.input_shapes)[:56],
+                                                          " <- ".join(x.split("/")[-1][:50] for x in st)))
