@@ -45,6 +45,7 @@ LIBS = {
         ("ganet_mlp_split.hip", []),
         ("ganet_wgrad_split.hip", []),
         ("ganet_layer_bwd.hip", []),
+        ("ganet_layer_fwd.hip", []),
         ("ganet_decoder.hip", []),
         ("ganet_pack.hip", []),
         ("ganet_upsample.hip", []),

@@ -20,6 +20,9 @@ struct ProfScope {
 };
 
 // ganet_mlp_split.hip / ganet_wgrad_split.hip: return -1 when the shape has no split kernel
+int layer_fwd_spec(int64_t M, const float* x, int64_t ldx, const float* in_scale, const float* in_shift, const float* W,
+                   const float* bias, float* z, int64_t ldz, float* col_part, const float* stat_shift, int reverse,
+                   hipStream_t stream);
 int mlp_fwd_split(int64_t M, int N, int K1, int K2, const float* x1, int64_t ld1, const float* x2, int64_t ld2,
                   const float* in_scale, const float* in_shift, const float* W, const float* bias, float* z,
                   int64_t ldz, float* col_part, const float* stat_shift, int reverse, hipStream_t stream);

@@ -440,6 +440,12 @@ int mlp_fwd_split(int64_t M, int N, int K1, int K2, const float* x1, int64_t ld1
                        in_scale, in_shift, W, bias, z, ldz, col_part, stat_shift, reverse);                    \
     return check_hip(hipGetLastError(), "mlp_fwd_split_kernel");                                               \
   } while (0)
+#ifndef GANET_NO_LAYER_FWD
+  if (K1 == 0 && K2 == 128 && N == 128) {     // hidden layer: producer / consumer kernel (ganet_layer_fwd.hip)
+    const int rc = layer_fwd_spec(M, x2, ld2, in_scale, in_shift, W, bias, z, ldz, col_part, stat_shift, reverse, stream);
+    if (rc >= 0) return rc;
+  }
+#endif
   if (K1 == 0 && K2 == 128 && nt == 4) LAUNCH(0, 8, 4);
   if (K1 == 72 && K2 == 0 && nt == 4) LAUNCH(72, 0, 4);
   if (K1 == 72 && K2 == 128 && nt == 4) LAUNCH(72, 8, 4);

@@ -9,7 +9,7 @@ mkdir -p $out/obj
 cp gaussianavatar_amd/_lib/libgalbs_hip.so $out/
 common="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Igaussianavatar_amd/csrc -fhip-fp32-correctly-rounded-divide-sqrt"
 objs=""
-for f in ganet_bn ganet_wgrad ganet_ssim ganet_mlp ganet_mlp_bwd ganet_mlp_split ganet_wgrad_split ganet_layer_bwd ganet_decoder ganet_pack ganet_upsample ganet_optim ganet_conv; do
+for f in ganet_bn ganet_wgrad ganet_ssim ganet_mlp ganet_mlp_bwd ganet_mlp_split ganet_wgrad_split ganet_layer_bwd ganet_layer_fwd ganet_decoder ganet_pack ganet_upsample ganet_optim ganet_conv; do
   [ -f gaussianavatar_amd/csrc/$f.hip ] || continue
   hipcc $common "$@" -c gaussianavatar_amd/csrc/$f.hip -o $out/obj/$f.o
   objs="$objs $out/obj/$f.o"
