@@ -29,46 +29,40 @@ namespace {
 
 constexpr int FWD_BLOCKS = 256;       // workgroups of the forward GEMM = rows of its column-sum partials
 
-// One workgroup per column: sum the per-workgroup partials in double, then mean / rstd, the folded
+// One wave per column: sum the per-workgroup partials in double, then mean / rstd, the folded
 // scale = gamma * rstd and shift = beta - mean * scale the next layer's prologue applies, and the
 // running statistics exactly as F.batch_norm(training=True) updates them.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 mlp_stats_kernel(int nparts, int NP, int64_t M, const float* __restrict__ col_part,
                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                  float* __restrict__ mean_out, float* __restrict__ rstd_out,
                  float* __restrict__ scale_out, float* __restrict__ shift_out,
                  float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
                  long long* __restrict__ num_batches_tracked, const float* __restrict__ stat_shift) {
-  __shared__ double s_s[256], s_q[256];
   const int n = blockIdx.x;
-  double s = 0.0, q = 0.0;
-  for (int p = threadIdx.x; p < nparts; p += 256) {
-    s += (double)col_part[(size_t)p * 2 * NP + n];
-    q += (double)col_part[(size_t)p * 2 * NP + NP + n];
-  }
-  s_s[threadIdx.x] = s; s_q[threadIdx.x] = q;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) { s_s[threadIdx.x] += s_s[threadIdx.x + o]; s_q[threadIdx.x] += s_q[threadIdx.x + o]; }
-    __syncthreads();
-  }
+  // the per-column scalars are requested before the partials: one memory round trip instead of two in a kernel that
+  // is nothing but latency
+  const float g_n = gamma[n], b_n = beta[n];
+  const float sh_n = stat_shift ? stat_shift[n] : 0.f;      // may alias running_mean: read before the update below
+  const float rm_n = running_mean ? running_mean[n] : 0.f, rv_n = running_mean ? running_var[n] : 0.f;
+  double sum1, sum2;
+  column_sums_wave(col_part, nparts, 2 * NP, NP, n, sum1, sum2);
   if (threadIdx.x == 0) {
-    // sums about the shift s: mean = s + S1 / M, var = S2 / M - (S1 / M)^2 (stat_shift may alias running_mean:
-    // it is read here, before the update below)
-    const double dm = s_s[0] / (double)M;
-    const double mean = (stat_shift ? (double)stat_shift[n] : 0.0) + dm;
-    double var = s_q[0] / (double)M - dm * dm;
+    // sums about the shift s: mean = s + S1 / M, var = S2 / M - (S1 / M)^2
+    const double dm = sum1 / (double)M;
+    const double mean = (double)sh_n + dm;
+    double var = sum2 / (double)M - dm * dm;
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float sc = gamma[n] * rstd;
+    const float sc = g_n * rstd;
     mean_out[n] = (float)mean;
     rstd_out[n] = rstd;
     scale_out[n] = sc;
-    shift_out[n] = beta[n] - (float)mean * sc;
+    shift_out[n] = b_n - (float)mean * sc;
     if (running_mean) {
       const double unbiased = var * ((double)M / (double)(M > 1 ? M - 1 : 1));
-      running_mean[n] = (1.0f - momentum) * running_mean[n] + momentum * (float)mean;
-      running_var[n] = (1.0f - momentum) * running_var[n] + momentum * (float)unbiased;
+      running_mean[n] = (1.0f - momentum) * rm_n + momentum * (float)mean;
+      running_var[n] = (1.0f - momentum) * rv_n + momentum * (float)unbiased;
     }
     if (n == 0 && num_batches_tracked) *num_batches_tracked += 1;
   }
@@ -446,7 +440,7 @@ int ganet_mlp_stats(int64_t M, int32_t N, const float* col_part, const float* ga
   }
   const int np = ((N + 31) / 32) * 32;
   ProfScope prof_(K_MLP_STATS, static_cast<hipStream_t>(stream_));
-  hipLaunchKernelGGL(mlp_stats_kernel, dim3(N), dim3(256), 0, static_cast<hipStream_t>(stream_),
+  hipLaunchKernelGGL(mlp_stats_kernel, dim3(N), dim3(64), 0, static_cast<hipStream_t>(stream_),
                      FWD_BLOCKS, np, M, col_part, gamma, beta, eps, mean, rstd, scale, shift,
                      running_mean, running_var, momentum,
                      reinterpret_cast<long long*>(num_batches_tracked), stat_shift);

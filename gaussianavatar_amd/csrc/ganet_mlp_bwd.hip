@@ -157,29 +157,18 @@ head_bwd_kernel(int64_t M, int N8, const float* __restrict__ g, const float* __r
   }
 }
 
-// One workgroup per column: sum the partials in double, then the BatchNorm-backward coefficients
+// One wave per column: sum the partials in double, then the BatchNorm-backward coefficients
 // (A, q, p) the consumers apply, and d gamma / d beta.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 bwd_stats_kernel(int nparts, int64_t M, const float* __restrict__ col_part,
                  const float* __restrict__ mean, const float* __restrict__ rstd,
                  const float* __restrict__ scale, float* __restrict__ coef,
                  float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ double s_s[256], s_q[256];
   const int n = blockIdx.x;
-  double s = 0.0, q = 0.0;
-  for (int p = threadIdx.x; p < nparts; p += 256) {
-    s += (double)col_part[(size_t)p * 256 + n];
-    q += (double)col_part[(size_t)p * 256 + 128 + n];
-  }
-  s_s[threadIdx.x] = s; s_q[threadIdx.x] = q;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) { s_s[threadIdx.x] += s_s[threadIdx.x + o]; s_q[threadIdx.x] += s_q[threadIdx.x + o]; }
-    __syncthreads();
-  }
+  const double mu = mean[n], rs = rstd[n], sc = scale[n];   // requested before the partials: one round trip, not two
+  double sumG, sumGz;
+  column_sums_wave(col_part, nparts, 256, 128, n, sumG, sumGz);
   if (threadIdx.x == 0) {
-    const double sumG = s_s[0], sumGz = s_q[0];
-    const double mu = mean[n], rs = rstd[n], sc = scale[n];
     const double dg = rs * (sumGz - mu * sumG);          // sum_m G xhat
     const double c1 = sumG / (double)M, c2 = dg / (double)M;
     coef[n] = (float)sc;
@@ -251,7 +240,7 @@ int ganet_mlp_bwd_stats(int64_t M, int32_t nparts, const float* col_part, const 
     return 1;
   }
   ProfScope prof_(K_BWD_STATS, static_cast<hipStream_t>(stream_));
-  hipLaunchKernelGGL(bwd_stats_kernel, dim3(128), dim3(256), 0, static_cast<hipStream_t>(stream_),
+  hipLaunchKernelGGL(bwd_stats_kernel, dim3(128), dim3(64), 0, static_cast<hipStream_t>(stream_),
                      nparts, M, col_part, mean, rstd, scale, coef, dgamma, dbeta);
   return check_hip(hipGetLastError(), "bwd_stats_kernel");
 }
