@@ -20,6 +20,19 @@ struct ProfScope {
 };
 
 // ganet_mlp_split.hip / ganet_wgrad_split.hip: return -1 when the shape has no split kernel
+// BatchNorm statistics of up to three layers in ONE launch (the decoder's three heads run level by level:
+// ganet_decoder.hip). Jobs are independent; a launch costs ~5 us whatever it does.
+constexpr int kMaxStatsJobs = 3;
+struct FwdStatsJob {
+  const float* col_part; const float* gamma; const float* beta; float eps;
+  float *mean, *rstd, *scale, *shift, *running_mean, *running_var;
+  float momentum; long long* num_batches_tracked; const float* stat_shift;
+};
+struct BwdStatsJob {
+  const float* col_part; int nparts; const float *mean, *rstd, *scale; float *coef, *dgamma, *dbeta;
+};
+int mlp_stats_launch(int njobs, const FwdStatsJob* jobs, int64_t M, int N, hipStream_t stream);
+int bwd_stats_launch(int njobs, const BwdStatsJob* jobs, int64_t M, hipStream_t stream);
 int layer_fwd_spec(int64_t M, const float* x, int64_t ldx, const float* in_scale, const float* in_shift, const float* W,
                    const float* bias, float* z, int64_t ldz, float* col_part, const float* stat_shift, int reverse,
                    hipStream_t stream);

@@ -32,39 +32,36 @@ constexpr int FWD_BLOCKS = 256;       // workgroups of the forward GEMM = rows o
 // One wave per column: sum the per-workgroup partials in double, then mean / rstd, the folded
 // scale = gamma * rstd and shift = beta - mean * scale the next layer's prologue applies, and the
 // running statistics exactly as F.batch_norm(training=True) updates them.
+struct FwdStatsJobs { FwdStatsJob j[kMaxStatsJobs]; };
 __global__ void __launch_bounds__(64)
-mlp_stats_kernel(int nparts, int NP, int64_t M, const float* __restrict__ col_part,
-                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                 float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                 float* __restrict__ scale_out, float* __restrict__ shift_out,
-                 float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
-                 long long* __restrict__ num_batches_tracked, const float* __restrict__ stat_shift) {
+mlp_stats_kernel(int nparts, int NP, int64_t M, FwdStatsJobs jobs) {
+  const FwdStatsJob& J = jobs.j[blockIdx.y];
   const int n = blockIdx.x;
   // the per-column scalars are requested before the partials: one memory round trip instead of two in a kernel that
   // is nothing but latency
-  const float g_n = gamma[n], b_n = beta[n];
-  const float sh_n = stat_shift ? stat_shift[n] : 0.f;      // may alias running_mean: read before the update below
-  const float rm_n = running_mean ? running_mean[n] : 0.f, rv_n = running_mean ? running_var[n] : 0.f;
+  const float g_n = J.gamma[n], b_n = J.beta[n];
+  const float sh_n = J.stat_shift ? J.stat_shift[n] : 0.f;      // may alias running_mean: read before the update below
+  const float rm_n = J.running_mean ? J.running_mean[n] : 0.f, rv_n = J.running_mean ? J.running_var[n] : 0.f;
   double sum1, sum2;
-  column_sums_wave(col_part, nparts, 2 * NP, NP, n, sum1, sum2);
+  column_sums_wave(J.col_part, nparts, 2 * NP, NP, n, sum1, sum2);
   if (threadIdx.x == 0) {
     // sums about the shift s: mean = s + S1 / M, var = S2 / M - (S1 / M)^2
     const double dm = sum1 / (double)M;
     const double mean = (double)sh_n + dm;
     double var = sum2 / (double)M - dm * dm;
     if (var < 0.0) var = 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float rstd = (float)(1.0 / sqrt(var + (double)J.eps));
     const float sc = g_n * rstd;
-    mean_out[n] = (float)mean;
-    rstd_out[n] = rstd;
-    scale_out[n] = sc;
-    shift_out[n] = b_n - (float)mean * sc;
-    if (running_mean) {
+    J.mean[n] = (float)mean;
+    J.rstd[n] = rstd;
+    J.scale[n] = sc;
+    J.shift[n] = b_n - (float)mean * sc;
+    if (J.running_mean) {
       const double unbiased = var * ((double)M / (double)(M > 1 ? M - 1 : 1));
-      running_mean[n] = (1.0f - momentum) * rm_n + momentum * (float)mean;
-      running_var[n] = (1.0f - momentum) * rv_n + momentum * (float)unbiased;
+      J.running_mean[n] = (1.0f - J.momentum) * rm_n + J.momentum * (float)mean;
+      J.running_var[n] = (1.0f - J.momentum) * rv_n + J.momentum * (float)unbiased;
     }
-    if (n == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    if (n == 0 && J.num_batches_tracked) *J.num_batches_tracked += 1;
   }
 }
 
@@ -395,6 +392,16 @@ int plan_wgrad(int64_t M, int64_t* rows_per_wave) {
 
 }  // namespace
 
+int mlp_stats_launch(int njobs, const FwdStatsJob* jobs, int64_t M, int N, hipStream_t stream) {
+  if (njobs <= 0 || njobs > kMaxStatsJobs) { set_error("mlp_stats_launch: 1..%d jobs", kMaxStatsJobs); return 1; }
+  FwdStatsJobs js;
+  for (int i = 0; i < kMaxStatsJobs; ++i) js.j[i] = jobs[i < njobs ? i : 0];
+  const int np = ((N + 31) / 32) * 32;
+  ProfScope prof_(K_MLP_STATS, stream);
+  hipLaunchKernelGGL(mlp_stats_kernel, dim3(N, njobs), dim3(64), 0, stream, FWD_BLOCKS, np, M, js);
+  return check_hip(hipGetLastError(), "mlp_stats_kernel");
+}
+
 }  // namespace ganet
 
 using namespace ganet;
@@ -438,13 +445,9 @@ int ganet_mlp_stats(int64_t M, int32_t N, const float* col_part, const float* ga
     set_error("ganet_mlp_stats: invalid arguments");
     return 1;
   }
-  const int np = ((N + 31) / 32) * 32;
-  ProfScope prof_(K_MLP_STATS, static_cast<hipStream_t>(stream_));
-  hipLaunchKernelGGL(mlp_stats_kernel, dim3(N), dim3(64), 0, static_cast<hipStream_t>(stream_),
-                     FWD_BLOCKS, np, M, col_part, gamma, beta, eps, mean, rstd, scale, shift,
-                     running_mean, running_var, momentum,
-                     reinterpret_cast<long long*>(num_batches_tracked), stat_shift);
-  return check_hip(hipGetLastError(), "mlp_stats_kernel");
+  const FwdStatsJob job{col_part, gamma, beta, eps, mean, rstd, scale, shift, running_mean, running_var, momentum,
+                        reinterpret_cast<long long*>(num_batches_tracked), stat_shift};
+  return mlp_stats_launch(1, &job, M, N, static_cast<hipStream_t>(stream_));
 }
 
 size_t ganet_wgrad_act_workspace(int64_t M, int32_t N, int32_t K) {

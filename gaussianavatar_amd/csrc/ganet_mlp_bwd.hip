@@ -159,27 +159,35 @@ head_bwd_kernel(int64_t M, int N8, const float* __restrict__ g, const float* __r
 
 // One wave per column: sum the partials in double, then the BatchNorm-backward coefficients
 // (A, q, p) the consumers apply, and d gamma / d beta.
+struct BwdStatsJobs { BwdStatsJob j[kMaxStatsJobs]; };
 __global__ void __launch_bounds__(64)
-bwd_stats_kernel(int nparts, int64_t M, const float* __restrict__ col_part,
-                 const float* __restrict__ mean, const float* __restrict__ rstd,
-                 const float* __restrict__ scale, float* __restrict__ coef,
-                 float* __restrict__ dgamma, float* __restrict__ dbeta) {
+bwd_stats_kernel(int64_t M, BwdStatsJobs jobs) {
+  const BwdStatsJob& J = jobs.j[blockIdx.y];
   const int n = blockIdx.x;
-  const double mu = mean[n], rs = rstd[n], sc = scale[n];   // requested before the partials: one round trip, not two
+  const double mu = J.mean[n], rs = J.rstd[n], sc = J.scale[n];   // requested before the partials: one round trip, not two
   double sumG, sumGz;
-  column_sums_wave(col_part, nparts, 256, 128, n, sumG, sumGz);
+  column_sums_wave(J.col_part, J.nparts, 256, 128, n, sumG, sumGz);
   if (threadIdx.x == 0) {
     const double dg = rs * (sumGz - mu * sumG);          // sum_m G xhat
     const double c1 = sumG / (double)M, c2 = dg / (double)M;
-    coef[n] = (float)sc;
-    coef[128 + n] = (float)(-sc * c2 * rs);
-    coef[256 + n] = (float)(-sc * c1 + sc * c2 * rs * mu);
-    dgamma[n] = (float)dg;
-    dbeta[n] = (float)sumG;
+    J.coef[n] = (float)sc;
+    J.coef[128 + n] = (float)(-sc * c2 * rs);
+    J.coef[256 + n] = (float)(-sc * c1 + sc * c2 * rs * mu);
+    J.dgamma[n] = (float)dg;
+    J.dbeta[n] = (float)sumG;
   }
 }
 
 }  // namespace
+
+int bwd_stats_launch(int njobs, const BwdStatsJob* jobs, int64_t M, hipStream_t stream) {
+  if (njobs <= 0 || njobs > kMaxStatsJobs) { set_error("bwd_stats_launch: 1..%d jobs", kMaxStatsJobs); return 1; }
+  BwdStatsJobs js;
+  for (int i = 0; i < kMaxStatsJobs; ++i) js.j[i] = jobs[i < njobs ? i : 0];
+  ProfScope prof_(K_BWD_STATS, stream);
+  hipLaunchKernelGGL(bwd_stats_kernel, dim3(128, njobs), dim3(64), 0, stream, M, js);
+  return check_hip(hipGetLastError(), "bwd_stats_kernel");
+}
 
 }  // namespace ganet
 
@@ -239,10 +247,8 @@ int ganet_mlp_bwd_stats(int64_t M, int32_t nparts, const float* col_part, const 
     set_error("ganet_mlp_bwd_stats: invalid arguments");
     return 1;
   }
-  ProfScope prof_(K_BWD_STATS, static_cast<hipStream_t>(stream_));
-  hipLaunchKernelGGL(bwd_stats_kernel, dim3(128), dim3(64), 0, static_cast<hipStream_t>(stream_),
-                     nparts, M, col_part, mean, rstd, scale, coef, dgamma, dbeta);
-  return check_hip(hipGetLastError(), "bwd_stats_kernel");
+  const BwdStatsJob job{col_part, nparts, mean, rstd, scale, coef, dgamma, dbeta};
+  return bwd_stats_launch(1, &job, M, static_cast<hipStream_t>(stream_));
 }
 
 }  // extern "C"
