@@ -42,9 +42,9 @@ constexpr int HEAD_BLOCKS = 512;
 // WG: the head's own weight gradient rides along (it needs the same g and z rows): per-workgroup
 // partial sums of dW8[n,k] = sum_m g[m,n] softplus(u[m,k]) and db8[n] = sum_m g[m,n], in the layout of
 // ganet_wgrad_act's workspace ([block][N8*128 + N8]) for ganet_wgrad_reduce_batch.
-template <bool WG>
+template <bool WG, int N8>      // N8: the head's width, a compile-time count (no branch around a load)
 __global__ void __launch_bounds__(256)
-head_bwd_kernel(int64_t M, int N8, const float* __restrict__ g, const float* __restrict__ W8,
+head_bwd_kernel(int64_t M, const float* __restrict__ g, const float* __restrict__ W8,
                 const float* __restrict__ z, int64_t ldz, const float* __restrict__ scale,
                 const float* __restrict__ shift, float* __restrict__ G, int64_t ldG,
                 float* __restrict__ col_part, float* __restrict__ wgrad_part) {
@@ -63,11 +63,40 @@ head_bwd_kernel(int64_t M, int N8, const float* __restrict__ g, const float* __r
   float dbv[WG ? 4 : 1];
 #pragma unroll
   for (int n = 0; n < (WG ? 4 : 1); ++n) { dw[n] = make_float4(0.f, 0.f, 0.f, 0.f); dbv[n] = 0.f; }
-  for (int64_t row = (int64_t)blockIdx.x * 8 + rsub; row < M; row += (int64_t)gridDim.x * 8) {
-    float gv[4];
+  // U rows per thread and step with all their loads issued first: 512 workgroups x 8 rows x one 16-byte load were
+  // 2 MB in flight chip-wide — a fraction of what the HBM latency needs (61 us per head; 268 MB = 43 us at 6.3 TB/s)
+  constexpr int U = 4;
+  // a workgroup's step = 8 U consecutive rows (16 KB of z), row group rsub taking U consecutive ones
+  const int64_t rstep = 1;
+  for (int64_t row0 = ((int64_t)blockIdx.x * 8 + rsub) * U; row0 < M; row0 += (int64_t)gridDim.x * 8 * U) {
+    float gvs[U][4];
+    float4 zvs[U];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) gv[n] = n < N8 ? g[row * N8 + n] : 0.f;
-    const float4 zv = *reinterpret_cast<const float4*>(z + row * ldz + 4 * cg);
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = row0 + u * rstep;
+      const int64_t rr = row < M ? row : row0;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) gvs[u][n] = n < N8 ? g[rr * N8 + n] : 0.f;     // a clamped row: no branch
+      zvs[u] = *reinterpret_cast<const float4*>(z + rr * ldz + 4 * cg);
+    }
+    // every load above is issued before the first value is touched, and "touched" whatever `row < M` says below
+    // (otherwise the compiler sinks the loads of a row into that row's branch, one round trip per row)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int n = 0; n < N8; ++n) asm volatile("" : "+v"(gvs[u][n]));
+      asm volatile("" : "+v"(zvs[u].x), "+v"(zvs[u].y), "+v"(zvs[u].z), "+v"(zvs[u].w));
+      if (row0 + u * rstep >= M) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) gvs[u][n] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+    const int64_t row = row0 + u * rstep;
+    if (row >= M) break;
+    const float (&gv)[4] = gvs[u];
+    const float4 zv = zvs[u];
     float4 d;
     d.x = gv[0] * w[0].x + gv[1] * w[1].x + gv[2] * w[2].x + gv[3] * w[3].x;
     d.y = gv[0] * w[0].y + gv[1] * w[1].y + gv[2] * w[2].y + gv[3] * w[3].y;
@@ -102,6 +131,7 @@ head_bwd_kernel(int64_t M, int N8, const float* __restrict__ g, const float* __r
     sg.x += d.x; sg.y += d.y; sg.z += d.z; sg.w += d.w;
     sgz.x = fmaf(d.x, zv.x, sgz.x); sgz.y = fmaf(d.y, zv.y, sgz.y);
     sgz.z = fmaf(d.z, zv.z, sgz.z); sgz.w = fmaf(d.w, zv.w, sgz.w);
+    }
   }
   s_red[0][rsub][cg] = sg;
   s_red[1][rsub][cg] = sgz;
@@ -229,14 +259,15 @@ int ganet_mlp_head_bwd(int64_t M, int32_t N8, const float* g, const float* W8, c
     return 1;
   }
   ProfScope prof_(K_HEAD_BWD, static_cast<hipStream_t>(stream_));
-  if (wgrad_part)
-    hipLaunchKernelGGL(head_bwd_kernel<true>, dim3(HEAD_BLOCKS), dim3(256), 0,
-                       static_cast<hipStream_t>(stream_), M, N8, g, W8, z, ldz, scale, shift, G, ldG,
-                       col_part, wgrad_part);
-  else
-    hipLaunchKernelGGL(head_bwd_kernel<false>, dim3(HEAD_BLOCKS), dim3(256), 0,
-                       static_cast<hipStream_t>(stream_), M, N8, g, W8, z, ldz, scale, shift, G, ldG,
-                       col_part, nullptr);
+#define LAUNCH(WG_, N_)                                                                                     \
+  hipLaunchKernelGGL((head_bwd_kernel<WG_, N_>), dim3(HEAD_BLOCKS), dim3(256), 0, static_cast<hipStream_t>(stream_), \
+                     M, g, W8, z, ldz, scale, shift, G, ldG, col_part, wgrad_part)
+  if (wgrad_part) {
+    if (N8 == 1) LAUNCH(true, 1); else if (N8 == 2) LAUNCH(true, 2); else if (N8 == 3) LAUNCH(true, 3); else LAUNCH(true, 4);
+  } else {
+    if (N8 == 1) LAUNCH(false, 1); else if (N8 == 2) LAUNCH(false, 2); else if (N8 == 3) LAUNCH(false, 3); else LAUNCH(false, 4);
+  }
+#undef LAUNCH
   return check_hip(hipGetLastError(), "head_bwd_kernel");
 }
 
