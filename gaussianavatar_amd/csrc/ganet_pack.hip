@@ -40,24 +40,40 @@ decode_pack_fwd_kernel(int64_t HW, int64_t N, const float* __restrict__ res,
   float* o_col = out + F * N * 4 + f * N * 3;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // Few workgroups — each ends in two atomics on the same line, ~15 ns apiece: 768 of them were most of this kernel's
+  // 15 us — and in exchange four texels per thread and step, their gathers issued together.
   float sc = 0.f;
-  for (int64_t n = t0; n < N; n += stride) {
-    const int64_t m = valid_index[n];
-    o_res[3 * n] = res[3 * m] * res_scale;
-    o_res[3 * n + 1] = res[3 * m + 1] * res_scale;
-    o_res[3 * n + 2] = res[3 * m + 2] * res_scale;
-    const float sv = sigmoid_f(scale_logit[m]) * scale_mult;
-    o_scale[n] = sv;
-    sc += sv;
-    o_col[3 * n] = sigmoid_f(colour_logit[3 * m]);
-    o_col[3 * n + 1] = sigmoid_f(colour_logit[3 * m + 1]);
-    o_col[3 * n + 2] = sigmoid_f(colour_logit[3 * m + 2]);
+  for (int64_t n0 = t0; n0 < N; n0 += 4 * stride) {
+    int64_t m[4];
+    float r[4][3], sl[4], cl[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) m[u] = valid_index[min(n0 + u * stride, N - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { r[u][c] = res[3 * m[u] + c]; cl[u][c] = colour_logit[3 * m[u] + c]; }
+      sl[u] = scale_logit[m[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t n = n0 + u * stride;
+      if (n >= N) break;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { o_res[3 * n + c] = r[u][c] * res_scale; o_col[3 * n + c] = sigmoid_f(cl[u][c]); }
+      const float sv = sigmoid_f(sl[u]) * scale_mult;
+      o_scale[n] = sv;
+      sc += sv;
+    }
   }
   // sum over ALL texels of (res_scale * res)^2
   float s = 0.f;
-  for (int64_t i = t0; i < HW * 3; i += stride) {
-    const float v = res[i] * res_scale;
-    s = fmaf(v, v, s);
+  for (int64_t i = t0; i < HW * 3; i += 4 * stride) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = res[min(i + u * stride, HW * 3 - 1)] * res_scale;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i + u * stride < HW * 3) s = fmaf(v[u], v[u], s);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -119,9 +135,16 @@ mean_sq_fwd_kernel(int64_t n, const float* __restrict__ x, float norm, float* __
   float s = 0.f;
   const int64_t n4 = n >> 2;
   const float4* x4 = reinterpret_cast<const float4*>(x);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    const float4 v = x4[i];
-    s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  // few workgroups (every one ends in an atomic on the same address: ~15 ns each, 1024 of them were the kernel's
+  // 15 us), four independent 16-byte loads per thread and step
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += 4 * stride) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = x4[min(i + u * stride, n4 - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i + u * stride < n4) s += (v[u].x * v[u].x + v[u].y * v[u].y) + (v[u].z * v[u].z + v[u].w * v[u].w);
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = x[4 * n4 + threadIdx.x]; s = fmaf(v, v, s); }
 #pragma unroll
@@ -180,7 +203,7 @@ int ganet_decode_pack_fwd(int32_t frames, int64_t HW, int64_t N, const float* re
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   int rc = check_hip(hipMemsetAsync(sums, 0, 2 * sizeof(float), stream), "memset sums");
   if (rc) return rc;
-  const int blocks = (int)((HW * 3 / 4 + 255) / 256 < 2048 ? (HW * 3 / 4 + 255) / 256 : 2048);
+  const int blocks = (int)((HW * 3 / 16 + 255) / 256 < 192 ? (HW * 3 / 16 + 255) / 256 : 192);
   hipLaunchKernelGGL(decode_pack_fwd_kernel, dim3(blocks > 0 ? blocks : 1, frames), dim3(256), 0, stream, HW, N,
                      res, scale_logit, colour_logit, valid_index, res_scale, scale_mult, sq_norm, scale_norm,
                      out, sums);
@@ -214,7 +237,7 @@ int ganet_mean_sq_fwd(int64_t n, const float* x, float norm, float* out, void* s
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   int rc = check_hip(hipMemsetAsync(out, 0, sizeof(float), stream), "memset mean_sq");
   if (rc) return rc;
-  const int blocks = (int)((n / 4 + 255) / 256 < 1024 ? (n / 4 + 255) / 256 : 1024);
+  const int blocks = (int)((n / 16 + 255) / 256 < 64 ? (n / 16 + 255) / 256 : 64);
   hipLaunchKernelGGL(mean_sq_fwd_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, stream, n, x, norm, out);
   return check_hip(hipGetLastError(), "mean_sq_fwd_kernel");
 }
