@@ -571,14 +571,15 @@ def main():
         if dom_family in dflops:
             # HBM bytes of one 128->128 launch of this family (PMC passes committed under profiles/)
             traffic, traffic_note = None, None
-            tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
             if os.path.exists(tpath):
                 t = json.load(open(tpath)).get(dom_family)
                 if t:
                     traffic = (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0
                     traffic_note = ("HBM bytes of one 128->128 launch (M = 262,144) of this family: rocprofv3 --pmc "
-                                    "FETCH_SIZE / WRITE_SIZE, separate passes of this command, profiles/r02_final_pmc_traffic.txt; "
-                                    "2*FETCH+WRITE (gfx950 wide-read correction); equals the algorithmic traffic")
+                                    "FETCH_SIZE / WRITE_SIZE, separate passes of this command, profiles/r03_pmc_traffic.txt; "
+                                    "2*FETCH+WRITE (gfx950 wide-read correction); equals the algorithmic traffic of that "
+                                    "launch (4 x 134 MB of activations + 17 MB of partial weight-gradient tiles)")
             mfma = {"bound": "mfma", "achieved": d["TFLOPs"], "peak": mfma_peak, "unit": "TFLOP/s",
                     "frac": d["frac_of_mfma_peak"], "algorithmic_flops_per_iter": d["flops_per_iter"]}
             hbm = {"bound": "hbm", "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -611,13 +612,13 @@ def main():
         if "render_bwd" in kern:
             rb = kern["render_bwd"]
             traffic, traffic_note = None, None
-            tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
             if os.path.exists(tpath) and (N, H, B) == (200_000, 1024, 2):
                 t = json.load(open(tpath)).get("render_bwd")
                 if t:
                     traffic = (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0
                     traffic_note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of this command, "
-                                    "profiles/r02_final_pmc_traffic.txt; 2*FETCH+WRITE (gfx950 wide-read correction)")
+                                    "profiles/r03_pmc_traffic.txt; 2*FETCH+WRITE (gfx950 wide-read correction)")
             out["roofline_raster_bwd"] = {
                 "kernel": "render_bwd", "bound": "hbm", "achieved": rb["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": rb["frac_of_peak"], "traffic": traffic, "traffic_note": traffic_note, "avg_us": rb["avg_us"],
