@@ -409,10 +409,8 @@ class AvatarModel:
             # one flat tensor (residual | scale | colour segments) is the DP exchange point
             # (parallel.exchange_output_grads is the identity on one rank)
             flat = parallel.exchange_output_grads(flat)
-        point_res, scale1, pshs = fused.split_records(flat, b, N)
-        if shared:
-            point_res, scale1, pshs = (t.expand(B, -1, -1) for t in (point_res, scale1, pshs))
-        return offset_loss, scale_loss, point_res, scale1.expand(-1, -1, 3), pshs
+        point_res, scale3, pshs = fused.expand_records(flat, b, N, B if shared else b)
+        return offset_loss, scale_loss, point_res, scale3, pshs
 
     def _decode_texel_sharded(self, B, uv, scale_mult):
         """Stage 1 with parallel.set_mode("texels"): this rank evaluates the decoder on its slice of the
@@ -439,9 +437,8 @@ class AvatarModel:
         offset_loss = parallel.sum_over_ranks(off_l * ((r1 - r0) / float(HW)))
         scale_loss = parallel.sum_over_ranks(scale_l * (sh["n_local"] / float(N)))
         flat = parallel.gather_segments(flat_l, sh["n0"], sh["n_local"], N)
-        point_res, scale1, pshs = fused.split_records(flat, 1, N)
-        point_res, scale1, pshs = (t.expand(B, -1, -1) for t in (point_res, scale1, pshs))
-        return offset_loss, scale_loss, point_res, scale1.expand(-1, -1, 3), pshs
+        point_res, scale3, pshs = fused.expand_records(flat, 1, N, B)
+        return offset_loss, scale_loss, point_res, scale3, pshs
 
     def _render_frames(self, batch_data, full_pred, colors, scales):
         """The reference renders the frames one by one (avatar_model.py:332-365); here the whole

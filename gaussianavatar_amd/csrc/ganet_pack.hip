@@ -129,6 +129,34 @@ decode_pack_bwd_kernel(int64_t HW, int64_t N, const float* __restrict__ res,
   }
 }
 
+// Gradient of the packed record buffer from the gradients of its expanded views (avatar_model._decode: the stage-1
+// decoder is evaluated once, its residual / scale / colour records are broadcast over the B frames and the scalar scale
+// over three axes): d_flat[(f, n)] = sum over the frames that share record f (all B when b = 1) — and, for the scale,
+// over its three copies. One launch instead of autograd's four expand-backward sums, a cat and its fills.
+__global__ void __launch_bounds__(256)
+records_bwd_kernel(int b, int B, int64_t N, const float* __restrict__ g_res, const float* __restrict__ g_scale3,
+                   const float* __restrict__ g_col, float* __restrict__ d_flat) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (record frame f, n)
+  if (i >= (int64_t)b * N) return;
+  const int64_t f = i / N, n = i - f * N;
+  const int f0 = b == 1 ? 0 : (int)f, f1 = b == 1 ? B : (int)f + 1;
+  float r[3] = {0.f, 0.f, 0.f}, c[3] = {0.f, 0.f, 0.f}, sc = 0.f;
+  for (int q = f0; q < f1; ++q) {
+    const int64_t o = ((int64_t)q * N + n) * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (g_res) r[k] += g_res[o + k];
+      if (g_col) c[k] += g_col[o + k];
+      if (g_scale3) sc += g_scale3[o + k];
+    }
+  }
+  float* o_res = d_flat + i * 3;
+  float* o_col = d_flat + (int64_t)b * N * 4 + i * 3;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { o_res[k] = r[k]; o_col[k] = c[k]; }
+  d_flat[(int64_t)b * N * 3 + i] = sc;
+}
+
 // out[0] += norm * sum x^2   (geometry-feature regulariser, /root/reference/model/avatar_model.py:367)
 __global__ void __launch_bounds__(256)
 mean_sq_fwd_kernel(int64_t n, const float* __restrict__ x, float norm, float* __restrict__ out) {
@@ -227,6 +255,18 @@ int ganet_decode_pack_bwd(int32_t frames, int64_t HW, int64_t N, const float* re
                      res_scale, scale_mult, sq_norm, scale_norm, d_out, d_sq, d_scale_sum, d_res,
                      d_scale_logit, d_colour_logit);
   return check_hip(hipGetLastError(), "decode_pack_bwd_kernel");
+}
+
+int ganet_records_bwd(int32_t b, int32_t B, int64_t N, const float* g_res, const float* g_scale3, const float* g_col,
+                      float* d_flat, void* stream_) {
+  if (b <= 0 || B < b || (b != 1 && b != B) || N <= 0 || !d_flat) {
+    set_error("ganet_records_bwd: invalid arguments (b = 1 or b = B)");
+    return 1;
+  }
+  const int64_t n = (int64_t)b * N;
+  hipLaunchKernelGGL(records_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                     b, B, N, g_res, g_scale3, g_col, d_flat);
+  return check_hip(hipGetLastError(), "records_bwd_kernel");
 }
 
 int ganet_mean_sq_fwd(int64_t n, const float* x, float norm, float* out, void* stream_) {

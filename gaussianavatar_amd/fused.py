@@ -443,6 +443,43 @@ def split_records(flat, b, N):
     return _SplitRecords.apply(flat, b, N)
 
 
+class _ExpandRecords(torch.autograd.Function):
+    """flat [b*N*7] -> (residual [B,N,3], scale [B,N,3], colour [B,N,3]): the record views of split_records broadcast
+    over the B frames (b = 1) and the scalar scale over three axes — what avatar_model hands to skinning and to the
+    rasterizer. The backward is ONE kernel (sum over frames / over the scale's copies, written straight into the flat
+    gradient) instead of autograd's four expand-backward reductions, a cat and its fills."""
+
+    @staticmethod
+    def forward(ctx, flat, b, N, B):
+        ctx.dims = (b, N, B)
+        res = flat[:b * N * 3].view(b, N, 3).expand(B, -1, -1)
+        scale = flat[b * N * 3:b * N * 4].view(b, N, 1).expand(B, -1, 3)
+        col = flat[b * N * 4:].view(b, N, 3).expand(B, -1, -1)
+        return res, scale, col
+
+    @staticmethod
+    def backward(ctx, g_res, g_scale, g_col):
+        b, N, B = ctx.dims
+        ref = next(g for g in (g_res, g_scale, g_col) if g is not None)
+        c = lambda g: None if g is None else g.contiguous().float()
+        g_res, g_scale, g_col = c(g_res), c(g_scale), c(g_col)
+        d = torch.empty(b * N * 7, dtype=torch.float32, device=ref.device)
+        _native.ganet_check(_native.ganet().ganet_records_bwd(b, B, N, _ptr(g_res), _ptr(g_scale), _ptr(g_col), _ptr(d),
+                                                            _stream(ref.device)))
+        return d, None, None, None
+
+
+def expand_records(flat, b, N, B):
+    """(residual, scale x3, colour) [B,N,3] views of the packed records; see _ExpandRecords. b is 1 (records shared by
+    the frames) or B."""
+    if flat.is_cuda:
+        return _ExpandRecords.apply(flat, b, N, B)
+    res, s1, col = split_records(flat, b, N)
+    if b != B:
+        res, s1, col = (t.expand(B, -1, -1) for t in (res, s1, col))
+    return res, s1.expand(-1, -1, 3), col
+
+
 # ------------------------------------------------------------------------------------------------
 # Whole-decoder autograd function on the fused layer kernels (ganet_mlp.hip): no normalised
 # activation is ever stored, BatchNorm statistics come out of the producing GEMM's epilogue.

@@ -258,6 +258,11 @@ int ganet_decode_pack_bwd(int32_t frames, int64_t HW, int64_t N, const float* re
                           float scale_norm, const float* d_out, const float* d_sq,
                           const float* d_scale_sum, float* d_res, float* d_scale_logit,
                           float* d_colour_logit, void* stream);
+/* Gradient of decode_pack's record buffer [residual b*N*3 | scale b*N | colour b*N*3] from the gradients of its views
+ * broadcast over B frames (b = 1: summed over the frames; b = B: per frame) with the scale broadcast over three axes:
+ * g_res, g_scale3, g_col are [B, N, 3] (any may be NULL = zero). One launch instead of the expand-backward sums. */
+int ganet_records_bwd(int32_t b, int32_t B, int64_t N, const float* g_res, const float* g_scale3, const float* g_col,
+                      float* d_flat, void* stream);
 
 /* out[0] = norm * sum_i x[i]^2 (x 16-byte aligned; geometry-feature regulariser,
  * /root/reference/model/avatar_model.py:367); backward dx = 2 * norm * d_out[0] * x. */
