@@ -192,7 +192,7 @@ class AvatarModel:
         self.fix_rotation = rots
         lbs = assets["lbs_map"].reshape(S * S, joint_num)
         self.query_lbs = lbs[valid].to(dev).contiguous()[None].expand(self.batch_size, -1, -1)
-        self.inv_mats = torch.linalg.inv(assets["cano_joint_mat"]).to(dev).expand(self.batch_size, -1, -1, -1)
+        self.inv_mats = torch.linalg.inv(assets["cano_joint_mat"]).to(dev).contiguous().expand(self.batch_size, -1, -1, -1)
         self.betas = assets["betas"][0][None].expand(self.batch_size, -1).to(dev)
         self.pose = nn.Embedding(len(self.train_dataset), frames["pose"].shape[1],
                                  _weight=frames["pose"].clone(), sparse=True).to(dev)

@@ -35,6 +35,7 @@ class _JointTransforms(torch.autograd.Function):
         lib = _native.galbs()
         B = pose.shape[0]
         J = joints_rest.shape[0]
+        ctx.set_materialize_grads(False)      # the loop uses only M: no zero-filled dA per iteration
         pose_c = pose.contiguous().float()
         transl_c = transl.contiguous().float() if transl is not None else None
         jr = joints_rest.contiguous().float()

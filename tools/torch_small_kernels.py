@@ -25,11 +25,12 @@ def step(i):
     model.zero_grad(1); loss.backward(); model.step(1)
 for i in range(5): step(i)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True,
+             experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     for i in range(5): step(i)
     torch.cuda.synchronize()
-rows = [e for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=6) if e.self_device_time_total > 0 and e.key.startswith("aten::")]
-for e in sorted(rows, key=lambda e: -e.self_device_time_total)[:45]:
-    st = [s_ for s_ in (e.stack or []) if "gaussianavatar_amd" in s_ or "bench" in s_ or "tools/" in s_][:2]
-    print("%6.1f us/iter %4.1f calls/iter  %-26s %-56s %s" % (e.self_device_time_total / 5, e.count / 5, e.key, str(e.input_shapes)[:56],
-                                                          " <- ".join(x.split("/")[-1][:50] for x in st)))
+rows = [e for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=12) if e.self_device_time_total > 0 and e.key.startswith("aten::")]
+for e in sorted(rows, key=lambda e: -e.self_device_time_total)[:30]:
+    st = [s_ for s_ in (e.stack or []) if ("gaussianavatar_amd" in s_ or "bench" in s_ or "tools/" in s_ or "autograd" in s_)][:3]
+    print("%6.1f us/iter %4.1f calls/iter  %-22s %-40s %s" % (e.self_device_time_total / 5, e.count / 5, e.key, str(e.input_shapes)[:40],
+                                                          " <- ".join(x.split("/")[-1][:60] for x in st)))
