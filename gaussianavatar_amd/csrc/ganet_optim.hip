@@ -42,14 +42,42 @@ adam_kernel(int nt, AdamTable t, float beta1, float beta2, float eps) {
   float* __restrict__ m = t.m[k];
   float* __restrict__ v = t.v[k];
   const float ss = t.step_size[k], isb = t.inv_sqrt_bc2[k];
+  const int end = min(base + CHUNK, n);
+  auto update = [&](float gi, float& mi, float& vi, float& pi) {
+    mi = fmaf(beta1, mi, (1.0f - beta1) * gi);
+    vi = fmaf(beta2, vi, (1.0f - beta2) * gi * gi);
+    pi -= ss * (mi / (sqrtf(vi) * isb + eps));
+  };
+  const bool wide = end - base == CHUNK && ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) |
+                                              reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+  if (wide) {      // a whole chunk of 16-byte aligned tensors: four 16-byte loads per array and thread, all issued first
+    float4 G[4], Mv[4], V[4], P[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + 4 * (threadIdx.x + 256 * u);
+      G[u] = *reinterpret_cast<const float4*>(g + i);
+      Mv[u] = *reinterpret_cast<const float4*>(m + i);
+      V[u] = *reinterpret_cast<const float4*>(v + i);
+      P[u] = *reinterpret_cast<const float4*>(p + i);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + 4 * (threadIdx.x + 256 * u);
+      update(G[u].x, Mv[u].x, V[u].x, P[u].x); update(G[u].y, Mv[u].y, V[u].y, P[u].y);
+      update(G[u].z, Mv[u].z, V[u].z, P[u].z); update(G[u].w, Mv[u].w, V[u].w, P[u].w);
+      *reinterpret_cast<float4*>(m + i) = Mv[u];
+      *reinterpret_cast<float4*>(v + i) = V[u];
+      *reinterpret_cast<float4*>(p + i) = P[u];
+    }
+    return;
+  }
 #pragma unroll 4
-  for (int i = base + threadIdx.x; i < min(base + CHUNK, n); i += 256) {
-    const float gi = g[i];
-    const float mi = fmaf(beta1, m[i], (1.0f - beta1) * gi);
-    const float vi = fmaf(beta2, v[i], (1.0f - beta2) * gi * gi);
+  for (int i = base + threadIdx.x; i < end; i += 256) {
+    float mi = m[i], vi = v[i], pi = p[i];
+    update(g[i], mi, vi, pi);
     m[i] = mi;
     v[i] = vi;
-    p[i] -= ss * (mi / (sqrtf(vi) * isb + eps));
+    p[i] = pi;
   }
 }
 
