@@ -167,7 +167,10 @@ def _softplus_bn(z, sc, sh):
 
 @pytest.mark.parametrize("row_order", [0, 2])          # GANET_ROWS_DEFAULT / GANET_ROWS_DOWN
 @pytest.mark.parametrize("M,K1,K2,N", [(262144, 0, 128, 128), (40000, 72, 0, 128), (33333, 72, 128, 128),
-                                       (70001, 0, 128, 3), (4100, 0, 128, 1), (31, 0, 128, 128)])
+                                       (70001, 0, 128, 3), (4100, 0, 128, 1), (31, 0, 128, 128),
+                                       # the producer / consumer kernel of the hidden layers (M a multiple of 32): fewer
+                                       # slabs than workgroups, a ragged last round, one slab
+                                       (32 * 100, 0, 128, 128), (32 * 1031, 0, 128, 128), (32, 0, 128, 128)])
 def test_mlp_fwd_layer_matches_torch(M, K1, K2, N, row_order):
     """ganet_mlp_fwd: activation-on-load GEMM + column statistics, incl. ragged M (tail slab),
     the skip layer's two operands and the narrow output heads."""
@@ -815,3 +818,29 @@ def test_geom_convs_match_torch_float64(b, H, W):
     assert rel(x.grad, xr.grad) < 2e-6, rel(x.grad, xr.grad)
     for w, r in zip(ws, wr):
         assert rel(w.grad, r.grad) < 2e-6, rel(w.grad, r.grad)
+
+
+@pytest.mark.parametrize("b,B,N,missing", [(1, 3, 5000, None), (2, 2, 777, None), (1, 2, 200_000, None), (1, 2, 100, "scale")])
+def test_expand_records_backward_is_the_expand_backward(b, B, N, missing):
+    """fused.expand_records: the packed record buffer's views broadcast over the frames (and the scale over three
+    axes); its one-kernel backward (ganet_records_bwd) against autograd's own expand / slice backward."""
+    from gaussianavatar_amd import fused
+    torch.manual_seed(N)
+    flat = torch.randn(b * N * 7, device="cuda")
+    fa = flat.clone().requires_grad_()
+    fb = flat.clone().requires_grad_()
+    res, sc3, col = fused.expand_records(fa, b, N, B)
+    r0, s1, c0 = fb[:b * N * 3].view(b, N, 3), fb[b * N * 3:b * N * 4].view(b, N, 1), fb[b * N * 4:].view(b, N, 3)
+    if b != B:
+        r0, s1, c0 = (t.expand(B, -1, -1) for t in (r0, s1, c0))
+    s3 = s1.expand(-1, -1, 3)
+    assert res.shape == r0.shape == (B, N, 3) and sc3.shape == s3.shape and col.shape == c0.shape
+    assert torch.equal(res, r0) and torch.equal(sc3, s3) and torch.equal(col, c0)
+    w = [torch.randn(B, N, 3, device="cuda") for _ in range(3)]
+    terms_a = [(res * w[0]).sum(), (sc3 * w[1]).sum(), (col * w[2]).sum()]
+    terms_b = [(r0 * w[0]).sum(), (s3 * w[1]).sum(), (c0 * w[2]).sum()]
+    if missing == "scale":                      # a view nobody differentiates: its gradient arrives as None
+        terms_a.pop(1); terms_b.pop(1)
+    sum(terms_a).backward()
+    sum(terms_b).backward()
+    torch.testing.assert_close(fa.grad, fb.grad, rtol=1e-6, atol=1e-6)
