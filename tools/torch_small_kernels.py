@@ -34,3 +34,11 @@ for e in sorted(rows, key=lambda e: -e.self_device_time_total)[:30]:
     st = [s_ for s_ in (e.stack or []) if ("gaussianavatar_amd" in s_ or "bench" in s_ or "tools/" in s_ or "autograd" in s_)][:3]
     print("%6.1f us/iter %4.1f calls/iter  %-22s %-40s %s" % (e.self_device_time_total / 5, e.count / 5, e.key, str(e.input_shapes)[:40],
                                                           " <- ".join(x.split("/")[-1][:60] for x in st)))
+# runtime copies / fills (hipMemcpyAsync / hipMemsetAsync), with the op that issued them
+mem = [e for e in prof.events() if ("emcpy" in e.name or "emset" in e.name) and e.device_time_total > 0]
+agg = {}
+for e in mem:
+    par = e.cpu_parent.name if getattr(e, "cpu_parent", None) is not None else "?"
+    a = agg.setdefault((e.name[:40], par[:60]), [0, 0.0]); a[0] += 1; a[1] += e.device_time_total
+for (n, par), (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:20]:
+    print("MEM %6.1f us/iter %4.1f calls/iter  %-40s <- %s" % (t / 5, c / 5, n, par))
