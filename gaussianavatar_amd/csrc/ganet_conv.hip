@@ -103,16 +103,29 @@ conv5_kernel(int H, int W, const float* __restrict__ x, const u32x4* __restrict_
 
   // stage the 5 x 68 pixel halo once: coalesced loads (a pixel = 8 lanes x 32 bytes), zeros outside the image, split
   // into the three bf16 planes here — every element is converted once, not once per tap and consumer wave
-  for (int i = threadIdx.x; i < 5 * HALO_W * 8; i += WGC) {
+  // (all loads of a thread's items are issued first, from clamped addresses, and masked afterwards: with the loads
+  // inside the bounds branch every item was its own memory round trip, six in a row before the first MFMA)
+  constexpr int HALO_ITEMS = 5 * HALO_W * 8, HALO_IT = (HALO_ITEMS + WGC - 1) / WGC;
+  float4 lo[HALO_IT], hi[HALO_IT];
+#pragma unroll
+  for (int k = 0; k < HALO_IT; ++k) {
+    const int i = min((int)threadIdx.x + k * WGC, HALO_ITEMS - 1);
+    const int u = i & 7, p = i >> 3;
+    const int hy = p / HALO_W, hx = p - hy * HALO_W;
+    const int yy = min(max(py + hy - 2, 0), H - 1), xx = min(max(px0 + hx - 2, 0), W - 1);
+    const float* src = img + ((size_t)yy * W + xx) * C + 8 * u;
+    lo[k] = *reinterpret_cast<const float4*>(src);
+    hi[k] = *reinterpret_cast<const float4*>(src + 4);
+  }
+#pragma unroll
+  for (int k = 0; k < HALO_IT; ++k) {
+    const int i = threadIdx.x + k * WGC;
+    if (i >= HALO_ITEMS) break;
     const int u = i & 7, p = i >> 3;
     const int hy = p / HALO_W, hx = p - hy * HALO_W;
     const int yy = py + hy - 2, xx = px0 + hx - 2;
-    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-      const float4 lo = *reinterpret_cast<const float4*>(img + ((size_t)yy * W + xx) * C + 8 * u);
-      const float4 hi = *reinterpret_cast<const float4*>(img + ((size_t)yy * W + xx) * C + 8 * u + 4);
-      v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-    }
+    const float on = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? 1.f : 0.f;
+    const float v[8] = {lo[k].x * on, lo[k].y * on, lo[k].z * on, lo[k].w * on, hi[k].x * on, hi[k].y * on, hi[k].z * on, hi[k].w * on};
     u32x4 p1, p2, p3;
     split8(v, p1, p2, p3);
     s_halo[p * PIX_UNITS + u] = p1;
