@@ -243,7 +243,9 @@ __device__ __forceinline__ int merge_split(const uint64_t* A, int na, const uint
 // bitonic network this replaces (62 -> 46 us for the bench scene's lists, 2 frames): n log2(n / 8) key moves instead of
 // n log2^2(n) / 2, log2(n / 8) workgroup barriers instead of ~22 for 2048 keys, no padding to a power of two.
 // (Measured and rejected: rank-scatter merging — a thread keeps 8 keys and binary-searches each one's rank in the
-// sibling run, eight independent searches interleaved: 105 us, the random 8-byte LDS reads conflict on the banks.)
+// sibling run, eight independent searches interleaved: 105 us, the random 8-byte LDS reads conflict on the banks; and
+// the 8 outputs of a thread taken from two 8-key register windows with a bitonic half-cleaner + 12 compare-exchanges
+// instead of 8 dependent LDS round trips: 50 us against 46 — the u64 network costs more than the round trips.)
 __device__ __forceinline__ void cex(uint64_t& x, uint64_t& y) {
   const uint64_t lo = x < y ? x : y, hi = x < y ? y : x;
   x = lo; y = hi;
