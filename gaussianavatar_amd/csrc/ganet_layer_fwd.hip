@@ -142,10 +142,8 @@ layer_fwd_spec_kernel(int64_t M, const float* __restrict__ x, const float* __res
       load_raw(s0, phys(slab_of(r + 5)));
       __builtin_amdgcn_sched_barrier(0);
       LFWD_STAMP(1, r, 3);
-      LFWD_STAMP(1, r, 4);
-      LFWD_STAMP(1, r, 5);
       __syncthreads();
-      LFWD_STAMP(1, r, 6);
+      LFWD_STAMP(1, r, 4);
     };
     for (int r = 0; r < roundsN; r += 4) {
       round(q[1], r);

@@ -22,9 +22,9 @@ t = buf.astype(np.int64); c, p = t[0], t[1]
 R = slice(4, 28)
 print("consumer (cycles): mfma %.0f  epilogue %.0f  barrier wait %.0f | round %.0f" % (
     (c[R, 1] - c[R, 0]).mean(), (c[R, 2] - c[R, 1]).mean(), (c[R, 3] - c[R, 2]).mean(), (c[5:29, 0] - c[4:28, 0]).mean()))
-print("producer (cycles): drain0 %.0f  wait loads %.0f  produce0+loads %.0f  drain1+wait %.0f  produce1+loads %.0f  barrier wait %.0f | round %.0f" % (
+print("producer (cycles): drain %.0f  wait loads %.0f  produce + loads %.0f  barrier wait %.0f | round %.0f" % (
     (p[R, 1] - p[R, 0]).mean(), (p[R, 2] - p[R, 1]).mean(), (p[R, 3] - p[R, 2]).mean(), (p[R, 4] - p[R, 3]).mean(),
-    (p[R, 5] - p[R, 4]).mean(), (p[R, 6] - p[R, 5]).mean(), (p[5:29, 0] - p[4:28, 0]).mean()))
+    (p[5:29, 0] - p[4:28, 0]).mean()))
 print("rounds (consumer, start to start):", (c[1:32, 0] - c[0:31, 0]).tolist())
 print("producer wait-loads per round:", (p[0:32, 2] - p[0:32, 1]).tolist())
 bl = np.zeros((256, 4), dtype=np.uint64)
