@@ -186,6 +186,8 @@ def test_mlp_fwd_layer_matches_torch(M, K1, K2, N, row_order):
     b = torch.randn(N, device=dev)
     part = torch.zeros(lib.ganet_mlp_stats_floats(N), device=dev)
     z = fused._mlp_fwd(lib, M, N, x1, x2, sc, sh, W, b, part, dev, row_order)
+    if N <= 4:       # the output heads run without column statistics
+        z_head = fused._mlp_fwd(lib, M, N, x1, x2, sc, sh, W, b, None, dev, row_order)
     cols = []
     if K1:
         cols.append(x1.double())
@@ -194,6 +196,8 @@ def test_mlp_fwd_layer_matches_torch(M, K1, K2, N, row_order):
     ref = torch.cat(cols, 1) @ W.double().t() + b.double()
     tol = 2e-5 * float(ref.abs().max()) + 1e-5
     assert float((z.double() - ref).abs().max()) <= tol
+    if N <= 4:
+        assert float((z_head.double() - ref).abs().max()) <= tol
     NP = ((N + 31) // 32) * 32
     p = part.reshape(-1, 2, NP).double().sum(0)
     assert float((p[0, :N] - ref.sum(0)).abs().max()) <= 1e-4 * float(ref.abs().sum(0).max()) + 1e-3
