@@ -44,7 +44,10 @@ class GsrBatch(ctypes.Structure):
 _LAYOUT_FIELDS = ["total_bytes", "depth", "xy", "conic_opacity", "rgb", "cov3d", "rect",
                   "tiles_touched", "clamped", "tile_count", "tile_offset", "tile_cursor",
                   "pair_key", "point_list", "pair_tmp", "final_T", "n_contrib", "grad_acc", "status", "seg_heads",
-                  "seg_count", "xyext", "seg_entries", "seg_ckpt", "seg_info", "pix_accum", "pair_grad", "seg_list"]
+                  "seg_count", "xyext", "seg_entries", "seg_ckpt", "seg_info", "pix_accum", "pair_grad", "seg_list",
+                  "eval_bytes", "train_bytes"]
+
+GSR_WS_EVAL, GSR_WS_TRAIN, GSR_WS_DEBUG = 0, 1, 2
 
 
 class GsrLayout(ctypes.Structure):
@@ -65,9 +68,11 @@ def _load(name: str) -> ctypes.CDLL:
 _gsr = None
 _galbs = None
 
-GSR_SYMBOLS = ["gsr_workspace_bytes", "gsr_workspace_layout", "gsr_forward", "gsr_backward",
+GSR_SYMBOLS = ["gsr_workspace_bytes", "gsr_workspace_bytes_for", "gsr_workspace_layout", "gsr_forward", "gsr_backward",
+               "gsr_forward_eval", "gsr_forward_eval_batch",
                "gsr_mark_visible", "gsr_batch_status", "gsr_read_status", "gsr_last_error", "gsr_abi_version",
-               "gsr_profile_enable", "gsr_profile_read", "gsr_profile_kernel_name",
+               "gsr_profile_create", "gsr_profile_destroy", "gsr_profile_bind", "gsr_profile_read",
+               "gsr_profile_kernel_name", "gsr_render_block_edge",
                "gsr_forward_batch", "gsr_backward_batch"]
 GALBS_SYMBOLS = ["galbs_joint_saved_floats", "galbs_joint_transforms_fwd",
                  "galbs_joint_transforms_bwd", "galbs_skin_fwd", "galbs_skin_bwd",
@@ -81,36 +86,47 @@ def gsr() -> ctypes.CDLL:
         P = c_void_p
         lib.gsr_workspace_bytes.restype = c_size_t
         lib.gsr_workspace_bytes.argtypes = [c_int32, c_int32, c_int32, c_int64]
+        lib.gsr_workspace_bytes_for.restype = c_size_t
+        lib.gsr_workspace_bytes_for.argtypes = [c_int32, c_int32, c_int32, c_int64, c_int32]
         lib.gsr_workspace_layout.restype = c_int
         lib.gsr_workspace_layout.argtypes = [c_int32, c_int32, c_int32, c_int64, ctypes.POINTER(GsrLayout)]
         lib.gsr_forward.restype = c_int
         lib.gsr_forward.argtypes = [ctypes.POINTER(GsrSettings), c_int32, P, P, P, c_int32, P, P, P, P,
                                     P, c_size_t, c_int64, P, P, P]
+        lib.gsr_forward_eval.restype = c_int
+        lib.gsr_forward_eval.argtypes = lib.gsr_forward.argtypes
         lib.gsr_backward.restype = c_int
         lib.gsr_backward.argtypes = [ctypes.POINTER(GsrSettings), c_int32, P, P, P, c_int32, P, P, P, P,
-                                     P, P, c_size_t, c_int64, P, P, P, P, P, P, P, P, P, P]
+                                     P, P, c_size_t, c_int64, P, P, P, P, P, P, P, P, P, P, P]
         B_ = ctypes.POINTER(GsrBatch)
         lib.gsr_forward_batch.restype = c_int
         lib.gsr_forward_batch.argtypes = [ctypes.POINTER(GsrSettings), B_, c_int32, P, P, P, c_int32, P, P, P, P,
                                           P, c_size_t, c_int64, P, P, P]
+        lib.gsr_forward_eval_batch.restype = c_int
+        lib.gsr_forward_eval_batch.argtypes = lib.gsr_forward_batch.argtypes
         lib.gsr_backward_batch.restype = c_int
         lib.gsr_backward_batch.argtypes = [ctypes.POINTER(GsrSettings), B_, c_int32, P, P, P, c_int32, P, P, P, P,
-                                           P, P, c_size_t, c_int64, P, P, P, P, P, P, P, P, P, P]
+                                           P, P, c_size_t, c_int64, P, P, P, P, P, P, P, P, P, P, P]
         lib.gsr_mark_visible.restype = c_int
         lib.gsr_mark_visible.argtypes = [c_int32, P, P, P, P, P]
         lib.gsr_batch_status.restype = c_int
-        lib.gsr_batch_status.argtypes = [P, c_int32, c_int32, c_int32, c_int32, c_int64, P, P]
+        lib.gsr_batch_status.argtypes = [P, c_int32, c_int32, c_int32, c_int32, c_int64, c_int32, P, P]
         lib.gsr_read_status.restype = c_int
         lib.gsr_read_status.argtypes = [P, c_int32, c_int32, c_int32, c_int64, P, P]
         lib.gsr_last_error.restype = c_char_p
         lib.gsr_abi_version.restype = c_int
-        lib.gsr_profile_enable.restype = c_int
-        lib.gsr_profile_enable.argtypes = [c_int]
+        lib.gsr_profile_create.restype = c_void_p
+        lib.gsr_profile_create.argtypes = []
+        lib.gsr_profile_destroy.restype = None
+        lib.gsr_profile_destroy.argtypes = [P]
+        lib.gsr_profile_bind.restype = c_int
+        lib.gsr_profile_bind.argtypes = [P, c_int]
         lib.gsr_profile_read.restype = c_int
-        lib.gsr_profile_read.argtypes = [P, P, c_int]
+        lib.gsr_profile_read.argtypes = [P, P, P, c_int]
+        lib.gsr_render_block_edge.restype = c_int
         lib.gsr_profile_kernel_name.restype = c_char_p
         lib.gsr_profile_kernel_name.argtypes = [c_int]
-        if lib.gsr_abi_version() != 4:
+        if lib.gsr_abi_version() != 5:
             raise RuntimeError("libgsr_hip.so ABI version mismatch; rebuild")
         _gsr = lib
     return _gsr
@@ -255,7 +271,7 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_wgrad_reduce_batch.restype = c_int
         lib.ganet_wgrad_reduce_batch.argtypes = [c_int32, P, P]
         lib.ganet_adam_step.restype = c_int
-        lib.ganet_adam_step.argtypes = [c_int32, P, c_float, c_float, c_float, P]
+        lib.ganet_adam_step.argtypes = [c_int32, P, c_float, c_float, c_float, P, P]
         lib.ganet_mean_sq_fwd.restype = c_int
         lib.ganet_mean_sq_fwd.argtypes = [c_int64, P, c_float, P, P]
         lib.ganet_mean_sq_bwd.restype = c_int
@@ -285,7 +301,7 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_conv5_wgrad.argtypes = [c_int32, c_int32, c_int32, P, P, P, P, c_size_t, P]
         lib.ganet_last_error.restype = c_char_p
         lib.ganet_abi_version.restype = c_int
-        if lib.ganet_abi_version() != 5:
+        if lib.ganet_abi_version() != 6:
             raise RuntimeError("libganet_hip.so ABI version mismatch; rebuild")
         _ganet = lib
     return _ganet

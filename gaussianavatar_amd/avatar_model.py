@@ -336,7 +336,7 @@ class AvatarModel:
         return self.model_parms.train_stage == 1 and epoch > self.opt_parms.pose_op_start_iter
 
     def zero_grad(self, epoch):
-        self.optimizer.zero_grad()
+        self.optimizer.zero_grad()        # (optim.Adam: also lowers the rasterizer's overflow flag for the new step)
         if self._pose_opt_active(epoch):
             self.optimizer_pose.zero_grad()
         elif self.model_parms.train_stage == 1:
@@ -353,6 +353,7 @@ class AvatarModel:
         elif parallel.texel_sharding():
             # every rank back-propagated its slice of the UV map: the parameter gradients are partial sums
             parallel.allreduce_param_grads(list(self.net.parameters()) + [self.geo_feature], average=False)
+        parallel.wait_overflow_flag()     # every rank skips the step if any rank dropped a frame's gradient
         self.optimizer.step()
         self.scheduler.step()
         if self._pose_opt_active(epoch):

@@ -1,10 +1,20 @@
 // ganet_common.h — shared helpers of the ganet_* translation units (internal).
 #pragma once
+#include <atomic>
 #include <cstdint>
 
 #include <hip/hip_runtime.h>
 
 namespace ganet {
+
+// "done once per device" flag for per-function attributes (hipFuncSetAttribute is a per-device setting; a process may
+// drive several GPUs): bit d = done on device d. Used as `static PerDeviceFlag f; if (!f) { ...; f = true; }`.
+struct PerDeviceFlag {
+  std::atomic<uint64_t> mask{0};
+  static uint64_t bit() { int d = 0; (void)hipGetDevice(&d); return 1ull << (d & 63); }
+  bool operator!() const { return !(mask.load(std::memory_order_acquire) & bit()); }
+  PerDeviceFlag& operator=(bool v) { if (v) mask.fetch_or(bit(), std::memory_order_release); return *this; }
+};
 void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
 

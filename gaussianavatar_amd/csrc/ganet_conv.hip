@@ -340,7 +340,7 @@ int ganet_conv5_apply(int32_t b, int32_t H, int32_t W, const float* x, const voi
   const u32x4* p = static_cast<const u32x4*>(packed) + (size_t)conv * PACKED_UNITS +
                    (size_t)(input_gradient ? 1 : 0) * TAPS * TAP_UNITS;
   const size_t lds = CONV_LDS;
-  static bool attr_set = false;
+  static PerDeviceFlag attr_set;       
   if (!attr_set) {
     if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute")) return 3;
@@ -371,7 +371,7 @@ int ganet_conv5_wgrad(int32_t b, int32_t H, int32_t W, const float* x, const flo
   const int runs = b * H * (W / 16), nchunks = chunks_of(runs);
   float* partial = static_cast<float*>(workspace);
   const size_t lds = (size_t)4 * 5 * 16 * 64 * sizeof(float);
-  static bool attr_set = false;
+  static PerDeviceFlag attr_set;       
   if (!attr_set) {
     if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_wgrad_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute")) return 3;

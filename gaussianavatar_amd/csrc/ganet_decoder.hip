@@ -211,7 +211,12 @@ int ganet_decoder_bwd(int64_t M, const float* x, const GanetDecoderParams* p, co
   int njobs = 0;
   Sweep sweep;
   // the weight-gradient launches that remain separate are off the dependency chain: side stream, ordered by events
-  static thread_local hipEvent_t ev_main = nullptr, ev_side = nullptr;
+  // (one pair per host thread and device: an event belongs to the device that was current when it was created)
+  static thread_local hipEvent_t ev_main_dev[64] = {}, ev_side_dev[64] = {};
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  hipEvent_t& ev_main = ev_main_dev[dev_ & 63];
+  hipEvent_t& ev_side = ev_side_dev[dev_ & 63];
   if (side && !ev_main) {
     GA_TRY(check_hip(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming), "hipEventCreate"));
     GA_TRY(check_hip(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming), "hipEventCreate"));

@@ -442,7 +442,7 @@ static int layer_bwd_launch(int64_t M, int kin, const float* g, const float* gz,
                                  stream), "hipMemsetAsync")) return 3;
 #define LAUNCH(AC, SG, KI)                                                                                      \
   do {                                                                                                          \
-    static bool attr_set = false;                                                                               \
+    static PerDeviceFlag attr_set;                                                                                      \
     if (!attr_set) {                                                                                            \
       if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_bwd_spec_kernel<AC, SG, KI>),       \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * ((AC) ? BUF_ACC : BUF))), \

@@ -247,7 +247,7 @@ int layer_fwd_spec(int64_t M, const float* x, int64_t ldx, const float* in_scale
                    hipStream_t stream) {
   if (M < FSLAB || (M % FSLAB) != 0 || ldx != 128 || ldz != 128 || !aligned16(z)) return -1;
   const size_t lds = (size_t)2 * BUF;
-  static bool attr_set = false;
+  static PerDeviceFlag attr_set;       
   if (!attr_set) {
     if (int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_fwd_spec_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "layer_fwd lds"))

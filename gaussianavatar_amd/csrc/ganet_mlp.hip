@@ -488,7 +488,7 @@ int ganet_wgrad_act(int64_t M, int32_t N, int32_t K, const float* g, int64_t ldg
 #define LAUNCH(T, KT_, A, G)                                                                       \
   do {                                                                                             \
     const size_t lds = 2 * ((size_t)(T) * 32 * (KT_) * 32 + (T) * 32) * sizeof(float);             \
-    static bool attr_set = false;                                                                  \
+    static PerDeviceFlag attr_set;                                                                         \
     if (!attr_set) {                                                                               \
       if (check_hip(hipFuncSetAttribute(                                                           \
                         reinterpret_cast<const void*>(wgrad_act_kernel<T, KT_, A, G>),             \

@@ -413,8 +413,8 @@ mlp_bwd_split_kernel(int64_t M, int O, const float* __restrict__ g, int64_t ldg,
 }
 
 template <typename Kern>
-int set_lds(Kern kern, size_t lds, bool& done) {
-  if (done) return 0;
+int set_lds(Kern kern, size_t lds, PerDeviceFlag& done) {
+  if (!!done) return 0;
   if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds), "hipFuncSetAttribute")) return 3;
   done = true;
@@ -433,7 +433,7 @@ int mlp_fwd_split(int64_t M, int N, int K1, int K2, const float* x1, int64_t ld1
   do {                                                                                                         \
     constexpr int RU_ = 2 * (((K1_) + 15) / 16 + (K2S_));                                                      \
     const size_t lds = (size_t)3 * (T) * 32 * RU_ * 16 + (size_t)2 * 16 * (K2S_) * 4;                          \
-    static bool attr_set = false;                                                                              \
+    static PerDeviceFlag attr_set;                                                                                     \
     if (int rc = set_lds(mlp_fwd_split_kernel<K1_, K2S_, T>, lds, attr_set)) return rc;                        \
     ProfScope prof_(K_MLP_FWD, stream);                                                                        \
     hipLaunchKernelGGL((mlp_fwd_split_kernel<K1_, K2S_, T>), grid, block, lds, stream, M, N, x1, ld1, x2, ld2, \
@@ -465,7 +465,7 @@ int mlp_bwd_split(int64_t M, int O, const float* g, int64_t ldg, const float* gz
 #define LAUNCH(T, AC, SG)                                                                                      \
   do {                                                                                                         \
     const size_t lds = (size_t)3 * (T) * 32 * 16 * 16 + 96 * 16;                                               \
-    static bool attr_set = false;                                                                              \
+    static PerDeviceFlag attr_set;                                                                                     \
     if (int rc = set_lds(mlp_bwd_split_kernel<T, AC, SG>, lds, attr_set)) return rc;                           \
     ProfScope prof_(K_BWD_DATA, stream);                                                                       \
     hipLaunchKernelGGL((mlp_bwd_split_kernel<T, AC, SG>), grid, block, lds, stream, M, O, g, ldg, gz, ldgz,    \

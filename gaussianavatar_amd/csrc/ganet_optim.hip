@@ -30,7 +30,8 @@ struct AdamTable {
 };
 
 __global__ void __launch_bounds__(256)
-adam_kernel(int nt, AdamTable t, float beta1, float beta2, float eps) {
+adam_kernel(int nt, AdamTable t, float beta1, float beta2, float eps, const int32_t* __restrict__ skip_flag) {
+  if (skip_flag && *skip_flag != 0) return;                // uniform: one scalar load per workgroup
   const int c = blockIdx.x;
   int k = 0;
   while (k < nt - 1 && c >= t.chunk_end[k]) ++k;          // uniform: scalar loads and branches
@@ -90,7 +91,7 @@ using namespace ganet;
 extern "C" {
 
 int ganet_adam_step(int32_t n_tensors, const GanetAdamTensor* tensors, float beta1, float beta2, float eps,
-                    void* stream_) {
+                    const int32_t* skip_flag, void* stream_) {
   if (n_tensors <= 0 || n_tensors > GANET_MAX_ADAM_TENSORS || !tensors) {
     set_error("ganet_adam_step: invalid arguments (1 <= n_tensors <= %d)", GANET_MAX_ADAM_TENSORS);
     return 1;
@@ -112,7 +113,7 @@ int ganet_adam_step(int32_t n_tensors, const GanetAdamTensor* tensors, float bet
     t.inv_sqrt_bc2[k] = 1.0f / sqrtf(q.bias_correction2);
   }
   hipLaunchKernelGGL(adam_kernel, dim3(chunks), dim3(256), 0, static_cast<hipStream_t>(stream_), n_tensors, t,
-                     beta1, beta2, eps);
+                     beta1, beta2, eps, skip_flag);
   return check_hip(hipGetLastError(), "adam_kernel");
 }
 

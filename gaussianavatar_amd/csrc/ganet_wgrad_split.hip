@@ -274,7 +274,7 @@ int wgrad_split(int64_t M, int N, int K, const float* g, int64_t ldg, const floa
     constexpr size_t step_bytes = (size_t)4 * (3 * 2 * 128 + 3 * 2 * 32 * (KT_)) * 16;                         \
     constexpr size_t tile_bytes = ((size_t)128 * 32 * (KT_) + 128) * 4;                                        \
     const size_t lds = step_bytes > tile_bytes ? step_bytes : tile_bytes;                                      \
-    static bool attr_set = false;                                                                              \
+    static PerDeviceFlag attr_set;                                                                                     \
     if (!attr_set) {                                                                                           \
       if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_kernel<KT_, LDX_, A, G, E>), \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),                 \

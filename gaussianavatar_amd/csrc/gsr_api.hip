@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <vector>
 
 #include "gsr_common.h"
@@ -25,32 +26,43 @@ void set_error(const char* fmt, ...) {
 }
 
 // ---------------------------------------------------------------- opt-in profiler
+// A caller-owned object (include/gsr.h: GsrProfile) bound to the calling thread; nothing process-global.
+}  // namespace gsr
+
+struct GsrProfile {
+  struct Rec { hipEvent_t start, stop; int id; };
+  std::mutex mu;                      // read may come from another thread than the one that launches
+  std::vector<Rec> recs;              // recorded, not yet read
+  std::vector<Rec> free_;             // recycled event pairs
+  double ms[gsr::K_COUNT] = {0};
+  int64_t n[gsr::K_COUNT] = {0};
+};
+
+namespace gsr {
+
 namespace {
-struct ProfRec { hipEvent_t start, stop; int id; };
-std::mutex g_prof_mu;
-unsigned g_prof_mask = 0;     // bit k: time kernel id k
-std::vector<ProfRec> g_prof_recs;     // recorded, not yet read
-std::vector<ProfRec> g_prof_free;     // recycled event pairs
-double g_prof_ms[K_COUNT] = {0};
-int64_t g_prof_n[K_COUNT] = {0};
+thread_local GsrProfile* t_prof = nullptr;
+thread_local unsigned t_prof_mask = 0;     // bit k: time kernel id k
 }  // namespace
 
 ProfScope::ProfScope(KernelId id, hipStream_t s) : slot(-1), stream(s) {
-  if (!((g_prof_mask >> id) & 1u)) return;
-  std::lock_guard<std::mutex> lk(g_prof_mu);
-  ProfRec r;
-  if (!g_prof_free.empty()) { r = g_prof_free.back(); g_prof_free.pop_back(); }
+  GsrProfile* p = t_prof;
+  if (!p || !((t_prof_mask >> id) & 1u)) return;
+  std::lock_guard<std::mutex> lk(p->mu);
+  GsrProfile::Rec r;
+  if (!p->free_.empty()) { r = p->free_.back(); p->free_.pop_back(); }
   else { if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return; }
   r.id = id;
   hipEventRecord(r.start, s);
-  g_prof_recs.push_back(r);
-  slot = (int)g_prof_recs.size() - 1;
+  p->recs.push_back(r);
+  slot = (int)p->recs.size() - 1;
 }
 
 ProfScope::~ProfScope() {
-  if (slot < 0) return;
-  std::lock_guard<std::mutex> lk(g_prof_mu);
-  if (slot < (int)g_prof_recs.size()) hipEventRecord(g_prof_recs[slot].stop, stream);
+  GsrProfile* p = t_prof;
+  if (slot < 0 || !p) return;
+  std::lock_guard<std::mutex> lk(p->mu);
+  if (slot < (int)p->recs.size()) hipEventRecord(p->recs[slot].stop, stream);
 }
 
 static inline uint64_t align_up(uint64_t v) { return (v + 255u) & ~(uint64_t)255u; }
@@ -63,6 +75,7 @@ int compute_layout(int P, int W, int H, int64_t max_pairs, GsrLayout* out) {
   const uint64_t npix = (uint64_t)W * H;
   uint64_t off = 0;
   auto take = [&](uint64_t bytes) { uint64_t o = off; off = align_up(off + bytes); return o; };
+  // ---- what every forward pass touches (GSR_WS_EVAL)
   out->depth = take(Pn * 4);
   out->xy = take(Pn * 8);
   out->conic_opacity = take(Pn * 16);
@@ -79,19 +92,27 @@ int compute_layout(int P, int W, int H, int64_t max_pairs, GsrLayout* out) {
   out->pair_tmp = take(cap * 8);
   out->final_T = take(npix * 4);
   out->n_contrib = take(npix * 4);
-  out->grad_acc = take(Pn * GSR_GRAD_STRIDE * 4);
   out->status = take(8 * 4);
   out->seg_heads = take(8 * 64 * 4);            // directly behind status: one clear
   out->seg_count = take((uint64_t)d.T * GSR_SEG_BLOCKS * 4);
   out->xyext = take(Pn * 16);
+  out->eval_bytes = off;
+  // ---- what the forward pass leaves for the backward pass (GSR_WS_TRAIN)
+  out->grad_acc = take(Pn * GSR_GRAD_STRIDE * 4);
   out->seg_entries = take((uint64_t)d.seg_cap * GSR_WAVE * 8);
   out->seg_ckpt = take((uint64_t)d.seg_cap * GSR_SEG_PIX * 16);
   out->seg_info = take((uint64_t)d.seg_cap * 8);
   out->pix_accum = take(npix * 16);
-  out->pair_grad = take(cap * GSR_PAIR_GRAD * 4);
   out->seg_list = take(8 * (uint64_t)d.seg_cap * 4);
+  out->train_bytes = off;
+  // ---- per-pair records of the deterministic backward (GSR_WS_DEBUG)
+  out->pair_grad = take(cap * GSR_PAIR_GRAD * 4);
   out->total_bytes = off;
   return 0;
+}
+
+uint64_t mode_bytes(const GsrLayout& L, int mode) {
+  return mode == GSR_WS_EVAL ? L.eval_bytes : (mode == GSR_WS_TRAIN ? L.train_bytes : L.total_bytes);
 }
 
 Workspace resolve(void* base, const GsrLayout& L) {
@@ -142,7 +163,7 @@ static int validate(const GsrSettings* s, int32_t P, const float* means3D,
                     const float* colors_precomp, const float* shs, int32_t sh_coeffs,
                     const float* opacities, const float* scales, const float* rotations,
                     const float* cov3D_precomp, void* workspace, size_t workspace_bytes,
-                    int64_t max_pairs, GsrLayout* L) {
+                    int64_t max_pairs, int mode, GsrLayout* L) {
   if (!s) { set_error("settings is NULL"); return GSR_ERR_INVALID_ARGUMENT; }
   if (P < 0 || s->image_width <= 0 || s->image_height <= 0) {
     set_error("bad sizes: P=%d W=%d H=%d", P, s->image_width, s->image_height);
@@ -157,9 +178,9 @@ static int validate(const GsrSettings* s, int32_t P, const float* means3D,
       set_error("bad workspace arguments (max_pairs=%lld)", (long long)max_pairs);
       return GSR_ERR_INVALID_ARGUMENT;
     }
-    if (!workspace || workspace_bytes < L->total_bytes) {
+    if (!workspace || workspace_bytes < mode_bytes(*L, mode)) {
       set_error("workspace too small: have %zu bytes, need %llu", workspace_bytes,
-                (unsigned long long)L->total_bytes);
+                (unsigned long long)mode_bytes(*L, mode));
       return GSR_ERR_WORKSPACE_TOO_SMALL;
     }
     return GSR_OK;
@@ -193,9 +214,9 @@ static int validate(const GsrSettings* s, int32_t P, const float* means3D,
     set_error("bad workspace arguments (max_pairs=%lld)", (long long)max_pairs);
     return GSR_ERR_INVALID_ARGUMENT;
   }
-  if (!workspace || workspace_bytes < L->total_bytes) {
-    set_error("workspace too small: have %zu bytes, need %llu", workspace_bytes,
-              (unsigned long long)L->total_bytes);
+  if (!workspace || workspace_bytes < mode_bytes(*L, mode)) {
+    set_error("workspace too small: have %zu bytes, need %llu (gsr_workspace_bytes_for, mode %d)", workspace_bytes,
+              (unsigned long long)mode_bytes(*L, mode), mode);
     return GSR_ERR_WORKSPACE_TOO_SMALL;
   }
   return GSR_OK;
@@ -211,6 +232,12 @@ size_t gsr_workspace_bytes(int32_t P, int32_t W, int32_t H, int64_t max_pairs) {
   GsrLayout L;
   if (compute_layout(P, W, H, max_pairs, &L)) return 0;
   return (size_t)L.total_bytes;
+}
+
+size_t gsr_workspace_bytes_for(int32_t P, int32_t W, int32_t H, int64_t max_pairs, int32_t mode) {
+  GsrLayout L;
+  if (mode < GSR_WS_EVAL || mode > GSR_WS_DEBUG || compute_layout(P, W, H, max_pairs, &L)) return 0;
+  return (size_t)mode_bytes(L, mode);
 }
 
 int gsr_workspace_layout(int32_t P, int32_t W, int32_t H, int64_t max_pairs, GsrLayout* out) {
@@ -249,7 +276,7 @@ static hipError_t clear_frames(void* base, size_t stride, int frames, hipStream_
   return hipGetLastError();
 }
 
-static int make_batch(const GsrBatch* b, int32_t P, const GsrLayout& L, size_t workspace_bytes,
+static int make_batch(const GsrBatch* b, int32_t P, const GsrLayout& L, int mode, size_t workspace_bytes,
                       Batch* out) {
   if (!b || b->frames < 1 || b->frames > 65535) {
     set_error("batch descriptor: frames must be in [1, 65535]");
@@ -265,13 +292,13 @@ static int make_batch(const GsrBatch* b, int32_t P, const GsrLayout& L, size_t w
     set_error("batch descriptor: means3D_stride must be >= 3*P (frames do not share positions)");
     return GSR_ERR_INVALID_ARGUMENT;
   }
-  if (workspace_bytes < (size_t)b->frames * L.total_bytes) {
+  if (workspace_bytes < (size_t)b->frames * mode_bytes(L, mode)) {
     set_error("workspace too small: have %zu bytes, need %d x %llu", workspace_bytes, b->frames,
-              (unsigned long long)L.total_bytes);
+              (unsigned long long)mode_bytes(L, mode));
     return GSR_ERR_WORKSPACE_TOO_SMALL;
   }
   out->frames = b->frames;
-  out->ws_stride = (size_t)L.total_bytes;
+  out->ws_stride = (size_t)mode_bytes(L, mode);
   out->means = b->means3D_stride; out->colors = b->colors_stride; out->opacities = b->opacities_stride;
   out->scales = b->scales_stride; out->rotations = b->rotations_stride; out->cov3d = b->cov3D_stride;
   out->view = b->viewmatrix_stride; out->proj = b->projmatrix_stride;
@@ -279,21 +306,25 @@ static int make_batch(const GsrBatch* b, int32_t P, const GsrLayout& L, size_t w
   return GSR_OK;
 }
 
-int gsr_forward_batch(const GsrSettings* s, const GsrBatch* batch, int32_t P, const float* means3D,
-                      const float* colors_precomp, const float* shs, int32_t sh_coeffs,
-                      const float* opacities, const float* scales, const float* rotations,
-                      const float* cov3D_precomp, void* workspace, size_t workspace_bytes,
-                      int64_t max_pairs, float* out_color, int32_t* out_radii, void* stream_) {
+// the workspace mode of a differentiable render: forward and backward derive it from settings.debug
+static int train_mode(const GsrSettings* s) { return s && s->debug ? GSR_WS_DEBUG : GSR_WS_TRAIN; }
+
+static int forward_impl(bool record, const GsrSettings* s, const GsrBatch* batch, int32_t P, const float* means3D,
+                        const float* colors_precomp, const float* shs, int32_t sh_coeffs,
+                        const float* opacities, const float* scales, const float* rotations,
+                        const float* cov3D_precomp, void* workspace, size_t workspace_bytes,
+                        int64_t max_pairs, float* out_color, int32_t* out_radii, void* stream_) {
   GsrLayout L;
+  const int mode = record ? train_mode(s) : GSR_WS_EVAL;
   int rc = validate(s, P, means3D, colors_precomp, shs, sh_coeffs, opacities, scales, rotations,
-                    cov3D_precomp, workspace, workspace_bytes, max_pairs, &L);
+                    cov3D_precomp, workspace, workspace_bytes, max_pairs, mode, &L);
   if (rc) return rc;
   if (!out_color || (P > 0 && !out_radii)) {
     set_error("out_color / out_radii are NULL");
     return GSR_ERR_INVALID_ARGUMENT;
   }
   Batch bt;
-  if ((rc = make_batch(batch, P, L, workspace_bytes, &bt))) return rc;
+  if ((rc = make_batch(batch, P, L, mode, workspace_bytes, &bt))) return rc;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const Dims d = make_dims(P, s->image_width, s->image_height, max_pairs);
   const Workspace ws = resolve(workspace, L);
@@ -313,9 +344,27 @@ int gsr_forward_batch(const GsrSettings* s, const GsrBatch* batch, int32_t P, co
   if ((rc = debug_sync(s, stream, "preprocess (sync)"))) return rc;
   if ((rc = check_hip(launch_binning(d, ws, bt, stream), "binning"))) return rc;
   if ((rc = debug_sync(s, stream, "binning (sync)"))) return rc;
-  if ((rc = check_hip(launch_render_fwd(*s, d, ws, out_color, bt, stream), "render_fwd"))) return rc;
+  if ((rc = check_hip(launch_render_fwd(*s, d, ws, out_color, record, bt, stream), "render_fwd"))) return rc;
   if ((rc = debug_sync(s, stream, "render_fwd (sync)"))) return rc;
   return GSR_OK;
+}
+
+int gsr_forward_batch(const GsrSettings* s, const GsrBatch* batch, int32_t P, const float* means3D,
+                      const float* colors_precomp, const float* shs, int32_t sh_coeffs,
+                      const float* opacities, const float* scales, const float* rotations,
+                      const float* cov3D_precomp, void* workspace, size_t workspace_bytes,
+                      int64_t max_pairs, float* out_color, int32_t* out_radii, void* stream_) {
+  return forward_impl(true, s, batch, P, means3D, colors_precomp, shs, sh_coeffs, opacities, scales, rotations,
+                      cov3D_precomp, workspace, workspace_bytes, max_pairs, out_color, out_radii, stream_);
+}
+
+int gsr_forward_eval_batch(const GsrSettings* s, const GsrBatch* batch, int32_t P, const float* means3D,
+                           const float* colors_precomp, const float* shs, int32_t sh_coeffs,
+                           const float* opacities, const float* scales, const float* rotations,
+                           const float* cov3D_precomp, void* workspace, size_t workspace_bytes,
+                           int64_t max_pairs, float* out_color, int32_t* out_radii, void* stream_) {
+  return forward_impl(false, s, batch, P, means3D, colors_precomp, shs, sh_coeffs, opacities, scales, rotations,
+                      cov3D_precomp, workspace, workspace_bytes, max_pairs, out_color, out_radii, stream_);
 }
 
 int gsr_backward_batch(const GsrSettings* s, const GsrBatch* batch, int32_t P, const float* means3D,
@@ -325,17 +374,18 @@ int gsr_backward_batch(const GsrSettings* s, const GsrBatch* batch, int32_t P, c
                        size_t workspace_bytes, int64_t max_pairs, const float* dL_dout_color,
                        float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors, float* dL_dsh,
                        float* dL_dopacity, float* dL_dscales, float* dL_drotations,
-                       float* dL_dcov3D, void* stream_) {
+                       float* dL_dcov3D, int32_t* overflow_flag, void* stream_) {
   GsrLayout L;
+  const int mode = train_mode(s);
   int rc = validate(s, P, means3D, colors_precomp, shs, sh_coeffs, opacities, scales, rotations,
-                    cov3D_precomp, workspace, workspace_bytes, max_pairs, &L);
+                    cov3D_precomp, workspace, workspace_bytes, max_pairs, mode, &L);
   if (rc) return rc;
   if (!dL_dout_color || (P > 0 && !radii)) {
     set_error("dL_dout_color / radii are NULL");
     return GSR_ERR_INVALID_ARGUMENT;
   }
   Batch bt;
-  if ((rc = make_batch(batch, P, L, workspace_bytes, &bt))) return rc;
+  if ((rc = make_batch(batch, P, L, mode, workspace_bytes, &bt))) return rc;
   if (P == 0) return GSR_OK;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const Dims d = make_dims(P, s->image_width, s->image_height, max_pairs);
@@ -349,7 +399,7 @@ int gsr_backward_batch(const GsrSettings* s, const GsrBatch* batch, int32_t P, c
   if ((rc = debug_sync(s, stream, "render_bwd (sync)"))) return rc;
   if ((rc = check_hip(launch_preprocess_bwd(*s, d, means3D, scales, rotations, radii, ws,
                                             dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity,
-                                            dL_dscales, dL_drotations, dL_dcov3D, bt, stream),
+                                            dL_dscales, dL_drotations, dL_dcov3D, overflow_flag, bt, stream),
                       "preprocess_bwd")))
     return rc;
   if (shs && (dL_dsh || dL_dmeans3D) &&
@@ -379,11 +429,21 @@ int gsr_backward(const GsrSettings* s, int32_t P, const float* means3D,
                  size_t workspace_bytes, int64_t max_pairs, const float* dL_dout_color,
                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors, float* dL_dsh,
                  float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
-                 void* stream_) {
+                 int32_t* overflow_flag, void* stream_) {
   return gsr_backward_batch(s, &kSingleFrame, P, means3D, colors_precomp, shs, sh_coeffs, opacities,
                             scales, rotations, cov3D_precomp, radii, workspace, workspace_bytes,
                             max_pairs, dL_dout_color, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dsh,
-                            dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D, stream_);
+                            dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D, overflow_flag, stream_);
+}
+
+int gsr_forward_eval(const GsrSettings* s, int32_t P, const float* means3D,
+                     const float* colors_precomp, const float* shs, int32_t sh_coeffs,
+                     const float* opacities, const float* scales, const float* rotations,
+                     const float* cov3D_precomp, void* workspace, size_t workspace_bytes,
+                     int64_t max_pairs, float* out_color, int32_t* out_radii, void* stream_) {
+  return gsr_forward_eval_batch(s, &kSingleFrame, P, means3D, colors_precomp, shs, sh_coeffs, opacities,
+                                scales, rotations, cov3D_precomp, workspace, workspace_bytes, max_pairs,
+                                out_color, out_radii, stream_);
 }
 
 int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,
@@ -415,14 +475,15 @@ __global__ void batch_status_kernel(const char* ws, size_t status_off, size_t ws
 }  // namespace
 
 int gsr_batch_status(const void* workspace, int32_t frames, int32_t P, int32_t W, int32_t H,
-                     int64_t max_pairs, int32_t* status_dev, void* stream_) {
+                     int64_t max_pairs, int32_t mode, int32_t* status_dev, void* stream_) {
   GsrLayout L;
-  if (!workspace || !status_dev || frames < 1 || compute_layout(P, W, H, max_pairs, &L)) {
+  if (!workspace || !status_dev || frames < 1 || mode < GSR_WS_EVAL || mode > GSR_WS_DEBUG ||
+      compute_layout(P, W, H, max_pairs, &L)) {
     set_error("gsr_batch_status: invalid arguments");
     return GSR_ERR_INVALID_ARGUMENT;
   }
   hipLaunchKernelGGL(batch_status_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream_),
-                     static_cast<const char*>(workspace), (size_t)L.status, (size_t)L.total_bytes, frames,
+                     static_cast<const char*>(workspace), (size_t)L.status, (size_t)mode_bytes(L, mode), frames,
                      status_dev);
   return check_hip(hipGetLastError(), "batch_status_kernel");
 }
@@ -442,28 +503,39 @@ int gsr_read_status(const void* workspace, int32_t P, int32_t W, int32_t H, int6
   return check_hip(hipStreamSynchronize(stream), "status sync");
 }
 
-int gsr_profile_enable(int on) {
-  std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_prof_mask = (unsigned)on;
+GsrProfile* gsr_profile_create(void) { return new (std::nothrow) GsrProfile(); }
+
+void gsr_profile_destroy(GsrProfile* p) {
+  if (!p) return;
+  if (t_prof == p) { t_prof = nullptr; t_prof_mask = 0; }
+  for (auto* v : {&p->recs, &p->free_})
+    for (auto& r : *v) { hipEventDestroy(r.start); hipEventDestroy(r.stop); }
+  delete p;
+}
+
+int gsr_profile_bind(GsrProfile* p, int mask) {
+  t_prof = (p && mask) ? p : nullptr;
+  t_prof_mask = p ? (unsigned)mask : 0u;
   return GSR_OK;
 }
 
-int gsr_profile_read(double* ms_sum, int64_t* launches, int reset) {
-  std::lock_guard<std::mutex> lk(g_prof_mu);
-  for (auto& r : g_prof_recs) {
+int gsr_profile_read(GsrProfile* p, double* ms_sum, int64_t* launches, int reset) {
+  if (!p) { set_error("gsr_profile_read: profile is NULL"); return GSR_ERR_INVALID_ARGUMENT; }
+  std::lock_guard<std::mutex> lk(p->mu);
+  for (auto& r : p->recs) {
     float ms = 0.f;
     if (hipEventSynchronize(r.stop) == hipSuccess &&
         hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
-      g_prof_ms[r.id] += ms;
-      g_prof_n[r.id] += 1;
+      p->ms[r.id] += ms;
+      p->n[r.id] += 1;
     }
-    g_prof_free.push_back(r);
+    p->free_.push_back(r);
   }
-  g_prof_recs.clear();
+  p->recs.clear();
   for (int k = 0; k < K_COUNT; ++k) {
-    if (ms_sum) ms_sum[k] = g_prof_ms[k];
-    if (launches) launches[k] = g_prof_n[k];
-    if (reset) { g_prof_ms[k] = 0; g_prof_n[k] = 0; }
+    if (ms_sum) ms_sum[k] = p->ms[k];
+    if (launches) launches[k] = p->n[k];
+    if (reset) { p->ms[k] = 0; p->n[k] = 0; }
   }
   return GSR_OK;
 }
@@ -473,6 +545,8 @@ const char* gsr_profile_kernel_name(int id) {
                                        "render_fwd", "render_bwd", "preprocess_bwd"};
   return (id >= 0 && id < K_COUNT) ? names[id] : "";
 }
+
+int gsr_render_block_edge(void) { return GSR_SUB; }
 
 const char* gsr_last_error(void) { return g_err; }
 

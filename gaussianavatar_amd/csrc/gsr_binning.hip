@@ -78,7 +78,7 @@ tile_scan_kernel(int T, int64_t max_pairs, uint32_t* __restrict__ tile_count,
   // LDS, so only two of its workgroups fit on a CU and the launch is a list-scheduling problem: with
   // the long lists of the avatar's interior tiles dispatched first, the short ones fill the gaps instead
   // of a few long ones forming the tail. Order within a class is arbitrary (it only affects scheduling).
-  constexpr int MAXPER = 8, NCLS = 34;
+  constexpr int MAXPER = 8, NCLS = 34;              // MAXPER x SCAN_THREADS = 8192: gsr_common.h tile_order_is_sorted
   __shared__ uint32_t s_cls[NCLS];
   uint32_t pos[MAXPER];
   const bool ordered = per <= MAXPER;
@@ -506,7 +506,7 @@ hipError_t launch_binning(const Dims& d, const Workspace& ws, const Batch& bt, h
     {
       ProfScope prof_(K_SORT, stream);
       const int gx = min(d.T, SORT_GRID);
-      const int ordered = (d.T + SCAN_THREADS - 1) / SCAN_THREADS <= 8;       // tile_scan_kernel: MAXPER
+      const int ordered = tile_order_is_sorted(d.T);                          // tile_scan_kernel: MAXPER
       hipLaunchKernelGGL(tile_sort_chunk_kernel, dim3(gx, bt.frames, SORT_MAX_CHUNKS), dim3(CHUNK_WG), 0, stream, d.T,
                          ordered, d.max_pairs, ws.tile_count, ws.tile_offset, ws.pair_key, ws.pair_tmp, ws.point_list,
                          bt.ws_stride);

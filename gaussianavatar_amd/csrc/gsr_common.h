@@ -10,8 +10,8 @@
 //                                     through HBM for lists that do not fit) -> point_list
 //   K5 render_fwd      per 4x4 block: cull the tile list, blend 64 survivors at a time (entry-parallel,
 //                                     DPP wave scans); records the consumed segments
-//   K6 render_bwd      per tile     : the tile's recorded segments, forward-order gradients summed per list entry in
-//                                     LDS, one atomic record per (tile, Gaussian) pair
+//   K6 render_bwd      per segment  : forward-order gradients of the segment's 64 entries summed over the block's
+//                                     pixels in registers, one atomic record per (block, Gaussian) survivor
 //   K7 preprocess_bwd  per Gaussian : screen-space grads -> means3D / scales / rotations
 //
 // Behavioural spec: SURVEY.md Appendix A (the reference's rasterizer is the un-vendored
@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include <type_traits>
 
 #include "gsr.h"
@@ -29,14 +31,26 @@
 #define GSR_WAVE 64
 #define GSR_GRAD_STRIDE 16                   // floats per Gaussian in grad_acc: one 64-byte line per record, so a
                                              // wave's 9 atomics on a Gaussian touch exactly one line
-#define GSR_SEG_PIX 16                       // pixels of a render block (4x4) = checkpoints per segment
+#ifndef GSR_SUB
+#define GSR_SUB 4                            // edge of a wave's pixel block in the render kernels: 4, or 8 (lane = pixel);
+#endif                                       // 8 was built and measured in round 4: see gsr_render.hip
+#define GSR_SEG_PIX (GSR_SUB * GSR_SUB)      // pixels of a render block = checkpoints per segment
 #ifndef GSR_BWD_BLOCKS
 #define GSR_BWD_BLOCKS 2048                  // persistent workgroups of render_bwd (256 CUs x 8)
 #endif
-#define GSR_SEG_BLOCKS 16                    // 4x4 pixel blocks of a tile
+#define GSR_SEG_BLOCKS ((GSR_TILE / GSR_SUB) * (GSR_TILE / GSR_SUB))   // render blocks of a tile: 16 (or 4)
 #define GSR_PAIR_GRAD 9                      // floats of a per-pair gradient record (dxy2, dconic3, dopac1, drgb3)
 
 namespace gsr {
+
+// "done once per device" flag for per-function attributes (hipFuncSetAttribute is a per-device setting; a process may
+// drive several GPUs): bit d = done on device d. Used as `static PerDeviceFlag f; if (!f) { ...; f = true; }`.
+struct PerDeviceFlag {
+  std::atomic<uint64_t> mask{0};
+  static uint64_t bit() { int d = 0; (void)hipGetDevice(&d); return 1ull << (d & 63); }
+  bool operator!() const { return !(mask.load(std::memory_order_acquire) & bit()); }
+  PerDeviceFlag& operator=(bool v) { if (v) mask.fetch_or(bit(), std::memory_order_release); return *this; }
+};
 
 struct Dims {
   int P, W, H, gx, gy, T;
@@ -44,16 +58,21 @@ struct Dims {
   int seg_cap;        // capacity of the forward pass's segment records (see seg_capacity)
 };
 
-// Segment slots (64 survivors of one 4x4 block each) the forward pass may record. A block of a tile with n list
-// entries records at most ceil(n / 64) segments; the 16 blocks of tile t (list [o, o + n)) own the slots
-//   16 (o / 64 + t) + b c + s,   c = (o + n) / 64 - o / 64 + 1 >= ceil(n / 64)     (integer divisions)
-// — disjoint between tiles, no counters, no overflow: sum over tiles <= 16 (D / 64 + T).
+// Segment slots (64 survivors of one render block each) the forward pass may record. A block of a tile with n list
+// entries records at most ceil(n / 64) segments; the B = GSR_SEG_BLOCKS blocks of tile t (list [o, o + n)) own the slots
+//   B (o / 64 + t) + b c + s,   c = (o + n) / 64 - o / 64 + 1 >= ceil(n / 64)     (integer divisions)
+// — disjoint between tiles, no counters, no overflow: sum over tiles <= B (D / 64 + T).
 inline int seg_capacity(int T, int64_t max_pairs) {
-  const int64_t c = max_pairs / 4 + 16 * (int64_t)T + 16;
+  const int64_t c = max_pairs * GSR_SEG_BLOCKS / 64 + GSR_SEG_BLOCKS * (int64_t)T + GSR_SEG_BLOCKS;
   return (int)(c > 0x3fffffff ? 0x3fffffff : c);
 }
 __host__ __device__ inline int seg_block_capacity(int64_t start, int64_t end) { return (int)((end >> 6) - (start >> 6)) + 1; }
-__host__ __device__ inline int64_t seg_first_slot(int64_t start, int tile) { return 16 * ((start >> 6) + tile); }
+__host__ __device__ inline int64_t seg_first_slot(int64_t start, int tile) { return GSR_SEG_BLOCKS * ((start >> 6) + tile); }
+
+// tile_scan_kernel (gsr_binning.hip) leaves the tiles in size order (largest list class first) when a thread of its
+// one workgroup owns at most 8 tiles, i.e. T <= 8192; above that `tile_count` holds the identity order and every walk
+// over it must skip empty tiles instead of stopping at the first one.
+inline int tile_order_is_sorted(int T) { return (T + 1023) / 1024 <= 8 ? 1 : 0; }
 
 inline Dims make_dims(int P, int W, int H, int64_t max_pairs) {
   Dims d;
@@ -204,7 +223,7 @@ hipError_t launch_preprocess(const GsrSettings& s, const Dims& d, const float* m
                              const Batch& bt, hipStream_t stream);
 hipError_t launch_binning(const Dims& d, const Workspace& ws, const Batch& bt, hipStream_t stream);
 hipError_t launch_render_fwd(const GsrSettings& s, const Dims& d, const Workspace& ws,
-                             float* out_color, const Batch& bt, hipStream_t stream);
+                             float* out_color, bool record, const Batch& bt, hipStream_t stream);
 hipError_t launch_render_bwd(const GsrSettings& s, const Dims& d, const Workspace& ws,
                              const float* dL_dout, const Batch& bt, hipStream_t stream);
 hipError_t launch_preprocess_bwd(const GsrSettings& s, const Dims& d, const float* means3D,
@@ -212,7 +231,7 @@ hipError_t launch_preprocess_bwd(const GsrSettings& s, const Dims& d, const floa
                                  const int32_t* radii, const Workspace& ws,
                                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors,
                                  float* dL_dopacity, float* dL_dscales, float* dL_drotations,
-                                 float* dL_dcov3D, const Batch& bt, hipStream_t stream);
+                                 float* dL_dcov3D, int32_t* overflow_flag, const Batch& bt, hipStream_t stream);
 // SH colour path (gsr_sh.hip): runs after K1 / after K7 when `shs` is given.
 hipError_t launch_sh_color(const GsrSettings& s, const Dims& d, const float* means3D,
                            const float* shs, int sh_coeffs, const Workspace& ws, const Batch& bt,

@@ -208,7 +208,8 @@ preprocess_bwd_kernel(int P, int W, int H, float tanfovx, float tanfovy, float s
                       Workspace ws, float* __restrict__ dL_dmeans3D,
                       float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors,
                       float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales,
-                      float* __restrict__ dL_drotations, float* __restrict__ dL_dcov3D, Batch bt) {
+                      float* __restrict__ dL_drotations, float* __restrict__ dL_dcov3D,
+                      int32_t* __restrict__ overflow_flag, Batch bt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
   {
@@ -225,7 +226,11 @@ preprocess_bwd_kernel(int P, int W, int H, float tanfovx, float tanfovy, float s
     if (dL_drotations) dL_drotations += f * P * 4;
     if (dL_dcov3D) dL_dcov3D += f * P * 6;
   }
-  const bool live = radii[i] > 0;
+  // A frame whose pair buffer overflowed was rendered from truncated tile lists: it yields NO gradient (all zeros)
+  // and raises the caller's flag, which the optimiser reads to skip the step (include/gsr.h: gsr_backward)
+  const bool overflowed = ws.status[1] != 0;
+  if (overflowed && overflow_flag && i == 0) *overflow_flag = 1;
+  const bool live = radii[i] > 0 && !overflowed;
   float g[GSR_GRAD_STRIDE];
 #pragma unroll
   for (int k = 0; k < 9; ++k) g[k] = live ? ws.grad_acc[(size_t)i * GSR_GRAD_STRIDE + k] : 0.f;
@@ -404,7 +409,7 @@ hipError_t launch_preprocess_bwd(const GsrSettings& s, const Dims& d, const floa
                                  const int32_t* radii, const Workspace& ws,
                                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors,
                                  float* dL_dopacity, float* dL_dscales, float* dL_drotations,
-                                 float* dL_dcov3D, const Batch& bt, hipStream_t stream) {
+                                 float* dL_dcov3D, int32_t* overflow_flag, const Batch& bt, hipStream_t stream) {
   if (d.P == 0) return hipSuccess;
   const int block = 256;
   const int grid = (d.P + block - 1) / block;
@@ -413,7 +418,7 @@ hipError_t launch_preprocess_bwd(const GsrSettings& s, const Dims& d, const floa
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(grid, bt.frames), dim3(block), 0, stream, d.P, d.W, d.H,
                      s.tanfovx, s.tanfovy, s.scale_modifier, s.viewmatrix, s.projmatrix,
                      means3D, scales, rotations, radii, ws, dL_dmeans3D, dL_dmeans2D,
-                     dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D, bt);
+                     dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D, overflow_flag, bt);
   }
   return hipGetLastError();
 }

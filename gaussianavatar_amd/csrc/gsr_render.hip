@@ -8,13 +8,13 @@
 // ~170 instructions + an LDS round trip per 4 entries to sum gradients over pixels. This version turns
 // the mapping around:
 //
-//   * ENTRY-parallel, PIXEL-serial. A wave owns a 4x4 pixel block. It culls the tile's list against the
+//   * ENTRY-parallel, PIXEL-serial. A wave owns a 4x4 pixel block (GSR_SUB; 8x8: see "Block size" below). It culls the tile's list against the
 //     block (exact-conservative alpha_min-ellipse box, ballot + mbcnt compaction into a per-wave LDS
 //     ring) and consumes the survivors in SEGMENTS of 64: lane l holds survivor l, and the wave walks the
 //     block's 16 pixels. For one pixel, transmittance in front of each of the 64 entries is an
 //     exclusive prefix product over the lanes — ONE 6-step DPP wave scan (row_shr 1/2/4/8, row_bcast
 //     15/31) — the stop test is a ballot, colour sums are wave reductions. Per-pixel state (T, C, last
-//     contributor) lives in lanes 0..15 of a few registers (v_readlane / v_writelane).
+//     contributor) lives in lane p of a few registers (v_readlane with the pixel index in an SGPR).
 //   * the forward pass RECORDS what it consumed: per segment the 64 (Gaussian, list position) pairs and
 //     the 16 pixels' (T, C) at its start — 776 bytes, coalesced — plus the pixels' accumulated colour.
 //   * the backward pass is SEGMENT-parallel: one wave per recorded segment, no culling, no list walk,
@@ -25,7 +25,16 @@
 //     registers — no cross-lane reduction at all — and issues 9 atomics at the end of the segment.
 // Results are those of the sequential definition up to float association (prefix products / sums are
 // evaluated as trees): covered by the image / gradient tolerances of tests/test_raster_gpu.py.
-// Spec: SURVEY.md Appendix A.3 (forward) and A.4 (backward).
+//
+// Block size (round 4: 8x8 blocks built, measured, not kept; GSR_SUB selects it). The backward pass ends every segment
+// with one 64-byte atomic gradient record per entry, and gfx950 retires those at 18.3 G records/s whatever the access
+// pattern (tools/ubench/atomic_rate.hip: one line operation per ~13 clocks and L2 channel — the atomics execute
+// memory-side). With 4x4 blocks a (tile, Gaussian) pair survives the cull of 2.16 blocks, with 8x8 blocks — lane =
+// pixel — of 1.06 (tools/seg_stats.py: 1.19 M vs 0.59 M records per frame at D = 550 k), i.e. half the atomics; but a
+// segment then has 64 pixels to visit instead of 16 with half the hit density: twice the (pixel, entry) evaluations,
+// in four times fewer, four times longer wave chains. Measured in the training iteration (2 frames, D = 810 k):
+// render_bwd 149 us either way (4x4: atomic-bound; 8x8: issue-bound), render_fwd 141 -> 271 us. Atomics and pixel
+// work trade one for one, so the block stays 4x4 (profiles/r04_render_block_size.md).
 #include <cstdlib>
 #include <type_traits>
 
@@ -35,13 +44,30 @@ namespace gsr {
 
 namespace {
 
-constexpr int WAVES = GSR_TILE_PIX / GSR_WAVE;   // 4 waves per block = the 4x4 blocks of an 8x8 quadrant
-constexpr int SUB = 4;                            // the wave's pixel block is SUB x SUB
+constexpr int WAVES = GSR_TILE_PIX / GSR_WAVE;   // 4 waves per workgroup = 4 render blocks
+constexpr int SUB = GSR_SUB;                      // the wave's pixel block is SUB x SUB: 8 (lane = pixel) or 4
 constexpr int NPIX = SUB * SUB;
+constexpr int BPT = GSR_SEG_BLOCKS;               // render blocks per tile: 4 (8x8) or 16 (4x4)
+constexpr int WG_PER_TILE = BPT / WAVES;          // workgroups per tile: 1 or 4
 constexpr int RING = 2 * GSR_WAVE;                // per-wave staging ring (survivors waiting for a full segment)
 constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float ALPHA_MAX = 0.99f;
 constexpr float T_EPS = 0.0001f;
+static_assert(SUB == 4 || SUB == 8, "render block edge");
+
+// Block b of a tile (b = part * WAVES + wave: workgroup `part` of the tile, its wave): pixel offset of its corner.
+// 8x8: the four quadrants; 4x4: quadrant = part, the quadrant's four 4x4 blocks = waves.
+__device__ __forceinline__ int block_ox(int b) {
+  return SUB == 8 ? (b & 1) * 8 : ((b >> 2) & 1) * 8 + (b & 1) * 4;
+}
+__device__ __forceinline__ int block_oy(int b) {
+  return SUB == 8 ? (b >> 1) * 8 : (b >> 3) * 8 + ((b >> 1) & 1) * 4;
+}
+// inverse: block index from the corner's offset inside the tile
+__device__ __forceinline__ int block_of(int ox, int oy) {
+  return SUB == 8 ? ((oy >> 3) << 1) | (ox >> 3)
+                  : ((oy >> 3) << 3) | ((ox >> 3) << 2) | (((oy >> 2) & 1) << 1) | ((ox >> 2) & 1);
+}
 
 // The same expression tree is used by forward and backward so that both take the same
 // skip decisions for a given (pixel, Gaussian).
@@ -155,29 +181,14 @@ __device__ __forceinline__ int wave_scan_add_i(int x) {
 __device__ __forceinline__ float read_lane(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
-// v with lane `lane` := s (s wave-uniform). One v_cndmask under a constant lane mask.
-__device__ __forceinline__ float write_lane(float v, float s, int lane) {
+// v with lane `lane` := s (s and lane wave-uniform)
+__device__ __forceinline__ float write_lane_at(float v, float s, int lane) {
   return ((int)(threadIdx.x & (GSR_WAVE - 1)) == lane) ? s : v;
-}
-__device__ __forceinline__ int write_lane_i(int v, int s, int lane) {
-  return ((int)(threadIdx.x & (GSR_WAVE - 1)) == lane) ? s : v;
-}
-
-struct WaveGeom {
-  int wave, lane;
-  int bx0, by0;      // the wave's pixel block
-};
-
-__device__ __forceinline__ WaveGeom wave_geometry(int gx, int tile, int quadrant) {
-  WaveGeom g;
-  g.wave = threadIdx.x / GSR_WAVE;
-  g.lane = threadIdx.x & (GSR_WAVE - 1);
-  g.bx0 = (tile % gx) * GSR_TILE + (quadrant & 1) * 8 + (g.wave & 1) * SUB;
-  g.by0 = (tile / gx) * GSR_TILE + (quadrant >> 1) * 8 + (g.wave >> 1) * SUB;
-  return g;
 }
 
 // ------------------------------------------------------------------------------------ forward
+// RECORD = false: the forward-only render (gsr_forward_eval*): nothing is left for a backward pass.
+template <bool RECORD>
 __global__ void __launch_bounds__(GSR_TILE_PIX)
 render_fwd_kernel(int W, int H, int gx, int T, int64_t max_pairs, int seg_cap, const uint32_t* __restrict__ tile_order,
                   const uint32_t* __restrict__ tile_offset,
@@ -187,7 +198,7 @@ render_fwd_kernel(int W, int H, int gx, int T, int64_t max_pairs, int seg_cap, c
                   float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                   uint2* __restrict__ seg_entries, float4* __restrict__ seg_ckpt, uint2* __restrict__ seg_info,
                   float4* __restrict__ pix_accum, uint32_t* __restrict__ seg_count, int32_t* __restrict__ seg_heads,
-                  uint32_t* __restrict__ seg_list, int flags, size_t ws_stride) {
+                  uint32_t* __restrict__ seg_list, size_t ws_stride) {
   {   // batched launch: blockIdx.y = frame
     const size_t off = (size_t)blockIdx.y * ws_stride;
     tile_order = shift(tile_order, off); seg_count = shift_mut(seg_count, off);
@@ -203,36 +214,36 @@ render_fwd_kernel(int W, int H, int gx, int T, int64_t max_pairs, int seg_cap, c
   __shared__ int s_k[WAVES][RING];
   // blocks walk the tiles in the binning's size order (longest lists first, tile_scan_kernel): the long
   // chains of the avatar's interior start at once instead of forming the launch's tail. XCD x takes the
-  // tiles of rank = x (mod 8), all four quadrants of a tile on the same XCD (shared list, shared L2).
+  // tiles of rank = x (mod 8), all blocks of a tile on the same XCD (shared list, shared L2).
   const int xcd = blockIdx.x & 7;
   const int jb = blockIdx.x >> 3;
-  const int rank = (jb >> 2) * 8 + xcd;
+  const int rank = (jb / WG_PER_TILE) * 8 + xcd;
   if (rank >= T) return;
   const int tile = (int)tile_order[rank];
-  const WaveGeom g = wave_geometry(gx, tile, jb & 3);
-  const int wave = g.wave, lane = g.lane;
+  const int wave = threadIdx.x / GSR_WAVE, lane = threadIdx.x & (GSR_WAVE - 1);
+  const int blk = (jb % WG_PER_TILE) * WAVES + wave;             // this wave's block of the tile
+  const int bx0 = (tile % gx) * GSR_TILE + block_ox(blk), by0 = (tile / gx) * GSR_TILE + block_oy(blk);
   const int64_t start = min((int64_t)tile_offset[tile], max_pairs);
   const int64_t end = min((int64_t)tile_offset[tile + 1], max_pairs);
   const int n = (int)(end - start);
   // this block's segment slots (gsr_common.h: seg_first_slot): no counter, no overflow
-  const int blk16 = (jb & 3) * WAVES + wave;
-  const int64_t slot0 = seg_first_slot(start, tile) + (int64_t)blk16 * seg_block_capacity(start, end);
-  const float fbx = (float)g.bx0, fby = (float)g.by0;
-  // lane p < 16 <-> pixel p of the block (row-major 4x4)
-  const int ppx = g.bx0 + (lane & (SUB - 1)), ppy = g.by0 + ((lane >> 2) & (SUB - 1));
+  const int64_t slot0 = seg_first_slot(start, tile) + (int64_t)blk * seg_block_capacity(start, end);
+  const float fbx = (float)bx0, fby = (float)by0;
+  // lane p < NPIX <-> pixel p of the block (row-major SUB x SUB)
+  const int ppx = bx0 + (lane & (SUB - 1)), ppy = by0 + ((lane / SUB) & (SUB - 1));
   const bool pix_lane = lane < NPIX && ppx < W && ppy < H;
-  // per-pixel state in lanes 0..15: transmittance, accumulated colour, deepest contributor (1-based)
+  // per-pixel state in lane p: transmittance, accumulated colour, deepest contributor (1-based)
   float vT = 1.0f, vC0 = 0.f, vC1 = 0.f, vC2 = 0.f;
   int vLast = 0;
-  unsigned alive = (unsigned)(__ballot(pix_lane) & 0xffffull);     // bit p: pixel p still accumulating
+  unsigned long long alive = __ballot(pix_lane);                 // bit p: pixel p still accumulating
   int recorded = 0;
 
   if (n > 0 && alive) {
     const uint32_t* plist = point_list + start;
     // Software pipeline. Culling walks the list in batches of 64: indices three batches ahead, their
     // (centre, extent) records two ahead. A segment is FORMED (64 survivors leave the LDS ring, their
-    // records and a record slot are requested) one step before it is BLENDED; the cull of the next batch
-    // runs in between, so neither the gathers nor the returning atomic are waited for.
+    // records are requested) one step before it is BLENDED; the cull of the next batch runs in between,
+    // so the gathers are not waited for.
     uint32_t idx0 = plist[min(lane, n - 1)];
     uint32_t idx1 = plist[min(GSR_WAVE + lane, n - 1)];
     uint32_t idx2 = plist[min(2 * GSR_WAVE + lane, n - 1)];
@@ -262,7 +273,7 @@ render_fwd_kernel(int W, int H, int gx, int T, int64_t max_pairs, int seg_cap, c
         pending = true;
       }
       if (more && count < GSR_WAVE) {
-        const bool keep = (b0 + lane < n) && ((flags & 4) || may_touch(xe0, fbx, fby));
+        const bool keep = (b0 + lane < n) && may_touch(xe0, fbx, fby);
         const unsigned long long mask = __ballot(keep);
         if (keep) {
           const int pos = (head + count + lane_rank(mask)) & (RING - 1);
@@ -282,13 +293,12 @@ render_fwd_kernel(int W, int H, int gx, int T, int64_t max_pairs, int seg_cap, c
       }
       pending = false;
       const bool valid = lane < take;
-#pragma unroll
-      for (int p = 0; p < NPIX; ++p) {
-        if (flags & 8) break;
-        if (!((alive >> p) & 1u)) continue;
+      // the block's pixels that are still accumulating, one after the other (p is wave-uniform: an SGPR)
+      for (unsigned long long pm = alive; pm; pm &= pm - 1ull) {
+        const int p = __builtin_ctzll(pm);
         const float Tin = read_lane(vT, p);
         const float dx = c.x - (fbx + (float)(p & (SUB - 1)));
-        const float dy = c.y - (fby + (float)(p >> 2));
+        const float dy = c.y - (fby + (float)(p / SUB));
         const float power = eval_power(co, dx, dy);
         const float alpha = fminf(ALPHA_MAX, co.w * __expf(power));
         const float a = (valid & (power <= 0.0f) & (alpha >= ALPHA_MIN)) ? alpha : 0.f;
@@ -313,18 +323,18 @@ render_fwd_kernel(int W, int H, int gx, int T, int64_t max_pairs, int seg_cap, c
         if (cm) {
           const int hi = 63 - __clzll((long long)cm);
           const int lastk = __builtin_amdgcn_readlane(e_k, hi) + 1;
-          vLast = write_lane_i(vLast, lastk, p);
+          vLast = me ? lastk : vLast;
         }
         const float Tnew = first < GSR_WAVE ? read_lane(Texcl, first) : read_lane(Tincl, GSR_WAVE - 1);
-        vT = write_lane(vT, Tnew, p);
-        if (first < GSR_WAVE) alive &= ~(1u << p);
+        vT = write_lane_at(vT, Tnew, p);
+        if (first < GSR_WAVE) alive &= ~(1ull << p);
       }
       // record the segment for the backward pass
-      if (!(flags & 2)) {
+      if (RECORD) {
         const size_t slot = (size_t)(slot0 + recorded);
         seg_entries[slot * GSR_WAVE + lane] = make_uint2(e_idx, (uint32_t)e_k);
         if (lane < NPIX) seg_ckpt[slot * NPIX + lane] = ckpt;
-        if (lane == 0) seg_info[slot] = make_uint2((uint32_t)g.bx0 | ((uint32_t)g.by0 << 16), (uint32_t)take);
+        if (lane == 0) seg_info[slot] = make_uint2((uint32_t)bx0 | ((uint32_t)by0 << 16), (uint32_t)take);
         ++recorded;
       }
       if (!alive) break;
@@ -338,9 +348,10 @@ render_fwd_kernel(int W, int H, int gx, int T, int64_t max_pairs, int seg_cap, c
     out_color[pix] = fmaf(vT, bg[0], vC0);
     out_color[plane + pix] = fmaf(vT, bg[1], vC1);
     out_color[2 * plane + pix] = fmaf(vT, bg[2], vC2);
-    if (recorded) pix_accum[pix] = make_float4(vC0, vC1, vC2, vT);
+    if (RECORD && recorded) pix_accum[pix] = make_float4(vC0, vC1, vC2, vT);
   }
-  if (lane == 0) seg_count[tile * GSR_SEG_BLOCKS + blk16] = (uint32_t)recorded;
+  if (!RECORD) return;
+  if (lane == 0) seg_count[tile * BPT + blk] = (uint32_t)recorded;
   // The segment-parallel backward pass strides over dense lists of slot ids, one per XCD class (this block ran on XCD
   // `xcd`, so will the waves that take its segments): one returning atomic per block claims a range of the class's list
   // (seg_heads[64 xcd] = the class count, one 256-byte line per counter: ~1 k returning atomics per address and
@@ -370,10 +381,11 @@ render_bwd_kernel(int W, int H, int list_cap, const float2* __restrict__ xy,
                   const uint2* __restrict__ seg_entries, const float4* __restrict__ seg_ckpt,
                   const uint2* __restrict__ seg_info, const float4* __restrict__ pix_accum,
                   const uint32_t* __restrict__ seg_list, const int32_t* __restrict__ seg_heads,
-                  const float* __restrict__ dL_dout,
+                  const int32_t* __restrict__ status, const float* __restrict__ dL_dout,
                   float* __restrict__ grad_acc, size_t ws_stride) {
   {   // batched launch: blockIdx.y = frame
     const size_t off = (size_t)blockIdx.y * ws_stride;
+    status = shift(status, off);
     xy = shift(xy, off); conic_opacity = shift(conic_opacity, off); rgb = shift(rgb, off);
     n_contrib = shift(n_contrib, off); seg_entries = shift(seg_entries, off); seg_ckpt = shift(seg_ckpt, off);
     seg_info = shift(seg_info, off); pix_accum = shift(pix_accum, off); seg_list = shift(seg_list, off);
@@ -381,6 +393,8 @@ render_bwd_kernel(int W, int H, int list_cap, const float2* __restrict__ xy,
     grad_acc = shift_mut(grad_acc, off);
     dL_dout += (size_t)blockIdx.y * 3 * H * W;
   }
+  // a frame whose pair buffer overflowed yields no gradient at all (preprocess_bwd writes the zeros)
+  if (status[1] != 0) return;
   // per-wave transposition buffer for the gradient records: lane-major [entry][component] in, flat out
   __shared__ float s_g[WAVES][GSR_WAVE * NCOMP];
   __shared__ uint32_t s_gi[WAVES][GSR_WAVE];
@@ -415,7 +429,7 @@ render_bwd_kernel(int W, int H, int list_cap, const float2* __restrict__ xy,
     d.c = xy[idx];
     d.co = conic_opacity[idx];
     d.col = rgb[idx];
-    const int ppx = (int)(r.info.x & 0xffffu) + (p_l & (SUB - 1)), ppy = (int)(r.info.x >> 16) + (p_l >> 2);
+    const int ppx = (int)(r.info.x & 0xffffu) + (p_l & (SUB - 1)), ppy = (int)(r.info.x >> 16) + (p_l / SUB);
     const bool inside = ppx < W && ppy < H;
     const size_t pix = inside ? (size_t)ppy * W + ppx : 0;
     d.pa = pix_accum[pix];                                        // C_total, T_final
@@ -454,12 +468,12 @@ render_bwd_kernel(int W, int H, int list_cap, const float2* __restrict__ xy,
     const int kmin = __builtin_amdgcn_readfirstlane(k);            // entries are in list order
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;
     {
-#pragma unroll
-      for (int p = 0; p < NPIX; ++p) {
+      // the block's pixels that did not saturate in front of this segment, one after the other (p: an SGPR)
+      for (unsigned long long pm = __ballot(lane < NPIX && vLast > kmin); pm; pm &= pm - 1ull) {
+        const int p = __builtin_ctzll(pm);
         const int lastp = __builtin_amdgcn_readlane(vLast, p);
-        if (lastp <= kmin) continue;                                // the pixel saturated in front of this segment
         const float dx = c.x - (fbx + (float)(p & (SUB - 1)));
-        const float dy = c.y - (fby + (float)(p >> 2));
+        const float dy = c.y - (fby + (float)(p / SUB));
         const float power = eval_power(co, dx, dy);
         const float G = __expf(power);
         const float alpha = fminf(ALPHA_MAX, co.w * G);
@@ -526,7 +540,7 @@ render_bwd_kernel(int W, int H, int list_cap, const float2* __restrict__ xy,
 constexpr int BWD_WG = 1024;           // 16 waves: one workgroup per CU (LDS), all of a tile's segments on it
 constexpr int NCAP = 3072;             // list entries whose gradient rows fit the LDS table (9 floats each: 108 KiB)
 
-// Tile-grouped variant of K6: one workgroup per TILE walks the tile's recorded segments, sums each list entry's
+// Tile-grouped variant of K6 (measurements below: round 3, 4x4 blocks): one workgroup per TILE walks the tile's recorded segments, sums each list entry's
 // gradients in an LDS table indexed by list position and flushes the table once per tile (one record per (tile,
 // Gaussian) pair). Two uses:
 //   * DET (settings.debug, the reference's debug knob /root/reference/gaussian_renderer/__init__.py:33): ONE wave per
@@ -542,7 +556,7 @@ constexpr int NCAP = 3072;             // list entries whose gradient rows fit t
 // entries reach into).
 template <bool DET>
 __global__ void __launch_bounds__(DET ? GSR_WAVE : BWD_WG)
-render_bwd_tile_kernel(int W, int H, int gx, int T, int64_t max_pairs, const uint32_t* __restrict__ tile_order,
+render_bwd_tile_kernel(int W, int H, int gx, int T, int ordered, int64_t max_pairs, const uint32_t* __restrict__ tile_order,
                        const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ point_list,
                        const float2* __restrict__ xy, const float4* __restrict__ conic_opacity,
                        const float4* __restrict__ rgb, const float* __restrict__ bg,
@@ -575,13 +589,14 @@ render_bwd_tile_kernel(int W, int H, int gx, int T, int64_t max_pairs, const uin
   const size_t plane = (size_t)H * W;
   // persistent workgroups: rank = blockIdx.x, += gridDim.x over the size-ordered tiles (gridDim.x is a multiple of 8:
   // the XCD of a rank is kept); the first empty tile ends the walk — launching one workgroup per tile would dispatch
-  // thousands of 110 KiB-LDS workgroups that find their tile empty
+  // thousands of 110 KiB-LDS workgroups that find their tile empty. Above 8192 tiles tile_scan_kernel leaves the
+  // identity order (`ordered` = 0): an empty tile is then skipped, not the end of the walk.
   for (int rank = blockIdx.x; rank < T; rank += gridDim.x) {
   const int tile = (int)tile_order[rank];
   const int64_t start = min((int64_t)tile_offset[tile], max_pairs);
   const int64_t end = min((int64_t)tile_offset[tile + 1], max_pairs);
   const int n = (int)(end - start);
-  if (n == 0) break;
+  if (n == 0) { if (ordered) break; continue; }
   __syncthreads();                                 // the previous tile's LDS is free
   // segments per block -> exclusive prefix (wave 0)
   if (tid < GSR_WAVE) {
@@ -602,11 +617,11 @@ render_bwd_tile_kernel(int W, int H, int gx, int T, int64_t max_pairs, const uin
   const int capb = seg_block_capacity(start, end);
   const int64_t slot_tile = seg_first_slot(start, tile);
   const int tx0 = (tile % gx) * GSR_TILE, ty0 = (tile / gx) * GSR_TILE;
-  // the tile's pixels, block-major: entry 16 b + p = pixel p of 4x4 block b (b = quadrant * 4 + wave of the forward)
+  // the tile's pixels, block-major: entry NPIX b + p = pixel p of render block b (the forward pass's block index)
   for (int e = tid; e < GSR_TILE_PIX; e += blockDim.x) {
-    const int b = e >> 4, p = e & 15;
-    const int px = tx0 + ((b >> 2) & 1) * 8 + (b & 1) * SUB + (p & (SUB - 1));
-    const int py = ty0 + (b >> 3) * 8 + ((b >> 1) & 1) * SUB + (p >> 2);
+    const int b = e / NPIX, p = e & (NPIX - 1);
+    const int px = tx0 + block_ox(b) + (p & (SUB - 1));
+    const int py = ty0 + block_oy(b) + (p / SUB);
     const bool inside = px < W && py < H;
     const size_t pix = inside ? (size_t)py * W + px : 0;
     const int last = inside ? (int)n_contrib[pix] : 0;
@@ -667,9 +682,9 @@ render_bwd_tile_kernel(int W, int H, int gx, int T, int64_t max_pairs, const uin
       const float4 co = dat.co;
       const float4 col = dat.col;
       const int bx0 = (int)(rec.info.x & 0xffffu), by0 = (int)(rec.info.x >> 16);
-      const int b = (((by0 - ty0) >> 3) << 3) | (((bx0 - tx0) >> 3) << 2) | ((((by0 - ty0) >> 2) & 1) << 1) | (((bx0 - tx0) >> 2) & 1);
-      const float4 pa = s_pa[16 * b + p_l];
-      const float4 gp = s_g[16 * b + p_l];
+      const int b = block_of(bx0 - tx0, by0 - ty0);
+      const float4 pa = s_pa[NPIX * b + p_l];
+      const float4 gp = s_g[NPIX * b + p_l];
       const float4 ck = rec.ck;
       const int vLast = __float_as_int(gp.w);
       const float vg0 = gp.x, vg1 = gp.y, vg2 = gp.z;
@@ -679,12 +694,11 @@ render_bwd_tile_kernel(int W, int H, int gx, int T, int64_t max_pairs, const uin
                        pa.w * (bg0 * vg0 + bg1 * vg1 + bg2 * vg2);
       const float fbx = (float)bx0, fby = (float)by0;
       float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;
-#pragma unroll
-      for (int p = 0; p < NPIX; ++p) {
+      for (unsigned long long pm = __ballot(lane < NPIX && vLast > kfirst); pm; pm &= pm - 1ull) {
+        const int p = __builtin_ctzll(pm);                          // a pixel that had not saturated in front of this segment
         const int lastp = __builtin_amdgcn_readlane(vLast, p);
-        if (lastp <= kfirst) continue;                              // the pixel saturated in front of this segment
         const float dx = c.x - (fbx + (float)(p & (SUB - 1)));
-        const float dy = c.y - (fby + (float)(p >> 2));
+        const float dy = c.y - (fby + (float)(p / SUB));
         const float power = eval_power(co, dx, dy);
         const float G = __expf(power);
         const float alpha = fminf(ALPHA_MAX, co.w * G);
@@ -789,14 +803,17 @@ gather_pair_grads_kernel(int P, int gx, int64_t max_pairs, const int4* __restric
 }  // namespace
 
 hipError_t launch_render_fwd(const GsrSettings& s, const Dims& d, const Workspace& ws,
-                             float* out_color, const Batch& bt, hipStream_t stream) {
+                             float* out_color, bool record, const Batch& bt, hipStream_t stream) {
   if (d.T == 0) return hipSuccess;
   {
     ProfScope prof_(K_RENDER_FWD, stream);
-    hipLaunchKernelGGL(render_fwd_kernel, dim3(32 * ((d.T + 7) / 8), bt.frames), dim3(GSR_TILE_PIX), 0, stream, d.W,
-                       d.H, d.gx, d.T, d.max_pairs, d.seg_cap, ws.tile_count, ws.tile_offset, ws.point_list, ws.xyext,
-                       ws.conic_opacity, ws.rgb, s.bg, out_color, ws.final_T, ws.n_contrib, ws.seg_entries,
-                       ws.seg_ckpt, ws.seg_info, ws.pix_accum, ws.seg_count, ws.seg_heads, ws.seg_list, 0, bt.ws_stride);
+    const dim3 grid(8 * WG_PER_TILE * ((d.T + 7) / 8), bt.frames);
+#define GSR_FWD_ARGS d.W, d.H, d.gx, d.T, d.max_pairs, d.seg_cap, ws.tile_count, ws.tile_offset, ws.point_list, ws.xyext, \
+                     ws.conic_opacity, ws.rgb, s.bg, out_color, ws.final_T, ws.n_contrib, ws.seg_entries, ws.seg_ckpt,    \
+                     ws.seg_info, ws.pix_accum, ws.seg_count, ws.seg_heads, ws.seg_list, bt.ws_stride
+    if (record) hipLaunchKernelGGL(render_fwd_kernel<true>, grid, dim3(GSR_TILE_PIX), 0, stream, GSR_FWD_ARGS);
+    else hipLaunchKernelGGL(render_fwd_kernel<false>, grid, dim3(GSR_TILE_PIX), 0, stream, GSR_FWD_ARGS);
+#undef GSR_FWD_ARGS
   }
   return hipGetLastError();
 }
@@ -808,7 +825,7 @@ hipError_t launch_render_bwd(const GsrSettings& s, const Dims& d, const Workspac
   if (s.debug) {
     // deterministic: one wave per tile, per-pair records, per-Gaussian gather in tile order
     const size_t lds = (size_t)NCAP * NCOMP * sizeof(float);
-    static bool attr_set = false;
+    static PerDeviceFlag attr_set;       
     if (!attr_set) {
       const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(render_bwd_tile_kernel<true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -816,9 +833,9 @@ hipError_t launch_render_bwd(const GsrSettings& s, const Dims& d, const Workspac
       attr_set = true;
     }
     hipLaunchKernelGGL(render_bwd_tile_kernel<true>, dim3(d.T < 2048 ? d.T : 2048, bt.frames), dim3(GSR_WAVE), lds, stream,
-                       d.W, d.H, d.gx, d.T, d.max_pairs, ws.tile_count, ws.tile_offset, ws.point_list, ws.xy,
-                       ws.conic_opacity, ws.rgb, s.bg, ws.n_contrib, ws.seg_entries, ws.seg_ckpt, ws.seg_info,
-                       ws.pix_accum, ws.seg_count, dL_dout, ws.grad_acc, ws.pair_grad, bt.ws_stride);
+                       d.W, d.H, d.gx, d.T, tile_order_is_sorted(d.T), d.max_pairs, ws.tile_count, ws.tile_offset,
+                       ws.point_list, ws.xy, ws.conic_opacity, ws.rgb, s.bg, ws.n_contrib, ws.seg_entries, ws.seg_ckpt,
+                       ws.seg_info, ws.pix_accum, ws.seg_count, dL_dout, ws.grad_acc, ws.pair_grad, bt.ws_stride);
     hipLaunchKernelGGL(gather_pair_grads_kernel, dim3((d.P + 255) / 256, bt.frames), dim3(256), 0, stream, d.P, d.gx,
                        d.max_pairs, ws.rect, ws.depth, ws.tile_offset, ws.point_list, ws.pair_grad, ws.grad_acc,
                        bt.ws_stride);
@@ -828,7 +845,7 @@ hipError_t launch_render_bwd(const GsrSettings& s, const Dims& d, const Workspac
   const int per_frame = max(16, (GSR_BWD_BLOCKS / bt.frames) & ~15);      // waves per frame: a multiple of 64
   hipLaunchKernelGGL(render_bwd_kernel, dim3(per_frame, bt.frames), dim3(GSR_TILE_PIX), 0, stream, d.W, d.H, d.seg_cap, ws.xy,
                      ws.conic_opacity, ws.rgb, s.bg, ws.n_contrib, ws.seg_entries, ws.seg_ckpt, ws.seg_info,
-                     ws.pix_accum, ws.seg_list, ws.seg_heads, dL_dout, ws.grad_acc, bt.ws_stride);
+                     ws.pix_accum, ws.seg_list, ws.seg_heads, ws.status, dL_dout, ws.grad_acc, bt.ws_stride);
   return hipGetLastError();
 }
 

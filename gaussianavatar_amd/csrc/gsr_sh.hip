@@ -92,9 +92,11 @@ sh_bwd_kernel(int P, int M, int deg, const float* __restrict__ means3D,
   // dL/dcolour as accumulated by K6 (exactly 0 for Gaussians that were not rendered)
   const uint8_t* cl = ws.clamped + 4 * (size_t)i;
   float g[3];
+  // (a frame whose pair buffer overflowed yields no gradient: gsr_preprocess.hip, preprocess_bwd_kernel)
+  const bool overflowed = ws.status[1] != 0;
 #pragma unroll
   for (int c = 0; c < 3; ++c)
-    g[c] = cl[c] ? 0.f : ws.grad_acc[(size_t)i * GSR_GRAD_STRIDE + 6 + c];
+    g[c] = (cl[c] || overflowed) ? 0.f : ws.grad_acc[(size_t)i * GSR_GRAD_STRIDE + 6 + c];
   const float dx = means3D[3 * i] - campos[0], dy = means3D[3 * i + 1] - campos[1],
               dz = means3D[3 * i + 2] - campos[2];
   const float sum2 = dx * dx + dy * dy + dz * dz;

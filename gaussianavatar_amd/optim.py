@@ -7,6 +7,13 @@ the same `state_dict()` layout: checkpoints written by either load into the othe
 torch's default flavour keeps it, a float32 CPU scalar tensor; a device-side `step` from a fused-Adam
 checkpoint is accepted). Supported configuration = the one the reference uses: amsgrad, weight decay,
 maximize, capturable and differentiable off; float32 CUDA parameters with dense gradients.
+
+Overflow safety (no host sync): the rasterizer's backward pass raises a device-side flag when a forward pass had
+overflowed its pair buffer — that frame's gradients are zeros (rasterizer.overflow_flag). `step()` hands the flag
+to the kernel, which then changes nothing: a step computed from truncated tile lists is never applied.
+`zero_grad()` lowers the flag for the next step. (A skipped step still advances the `step` counter of the bias
+corrections; at the reference's betas that shifts the step size of the following updates by < 1e-3 relative after
+a few hundred steps.)
 """
 from __future__ import annotations
 
@@ -20,6 +27,19 @@ class Adam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, foreach=False,
                          fused=False)
         self._table = (_native.GanetAdamTensor * 64)()
+        self.skip_on_overflow = True      # read the rasterizer's overflow flag (see the module docstring)
+
+    def zero_grad(self, set_to_none: bool = True):
+        super().zero_grad(set_to_none=set_to_none)
+        if self.skip_on_overflow:
+            from . import rasterizer
+            rasterizer.clear_overflow_flag()
+
+    def _skip_flag(self, device):
+        if not self.skip_on_overflow:
+            return None
+        from . import rasterizer
+        return rasterizer.overflow_flag(device).data_ptr()
 
     def _group_step(self, group) -> int:
         """Advance the group's step counter: one shared CPU tensor referenced from every parameter's
@@ -39,7 +59,7 @@ class Adam(torch.optim.Adam):
             with torch.enable_grad():
                 loss = closure()
         lib = _native.ganet()
-        table, n, stream = self._table, 0, None
+        table, n, stream, skip = self._table, 0, None, None
         flush_args = None
         for group in self.param_groups:
             params = [p for p in group["params"] if p.grad is not None]
@@ -50,7 +70,7 @@ class Adam(torch.optim.Adam):
             beta1, beta2 = group["betas"]
             args = (float(beta1), float(beta2), float(group["eps"]))
             if flush_args is not None and args != flush_args and n:
-                _native.ganet_check(lib.ganet_adam_step(n, table, *flush_args, stream))
+                _native.ganet_check(lib.ganet_adam_step(n, table, *flush_args, skip, stream))
                 n = 0
             flush_args = args
             t = self._group_step(group)
@@ -73,16 +93,17 @@ class Adam(torch.optim.Adam):
                     p.grad = g
                 if stream is None:
                     stream = torch.cuda.current_stream(p.device).cuda_stream
+                    skip = self._skip_flag(p.device)
                 row = table[n]
                 row.param, row.grad = p.data_ptr(), g.data_ptr()
                 row.exp_avg, row.exp_avg_sq = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
                 row.n, row.lr, row.bias_correction1, row.bias_correction2 = p.numel(), lr, bc1, bc2
                 n += 1
                 if n == 64:
-                    _native.ganet_check(lib.ganet_adam_step(n, table, *args, stream))
+                    _native.ganet_check(lib.ganet_adam_step(n, table, *args, skip, stream))
                     n = 0
         if n:
-            _native.ganet_check(lib.ganet_adam_step(n, table, *flush_args, stream))
+            _native.ganet_check(lib.ganet_adam_step(n, table, *flush_args, skip, stream))
         return loss
 
     def state_dict(self):

@@ -91,6 +91,29 @@ def rank() -> int:
     return dist.get_rank(_group) if (_enabled and dist.is_initialized()) else 0
 
 
+_flag_work = None
+
+
+def post_overflow_flag(device) -> None:
+    """The rasterizer's backward pass raises a device-side flag on the rank whose forward pass overflowed (that
+    frame's gradient is zeros, rasterizer.overflow_flag); the optimiser skips the step while it is set. Ranks must
+    agree, or the replicas diverge: the flags are MAX-reduced — asynchronously, right behind the gradient
+    exchange, so that the message is long done when the step needs it (wait_overflow_flag)."""
+    global _flag_work
+    if world_size() == 1 or not torch.device(device).type == "cuda":
+        return
+    from . import rasterizer
+    _flag_work = dist.all_reduce(rasterizer.overflow_flag(device), op=dist.ReduceOp.MAX, group=_group, async_op=True)
+
+
+def wait_overflow_flag() -> None:
+    """Order the optimiser step behind the flag's reduction (stream-level wait with RCCL, no host block)."""
+    global _flag_work
+    if _flag_work is not None:
+        _flag_work.wait()
+        _flag_work = None
+
+
 class _ExchangeGrad(torch.autograd.Function):
     """Identity in forward; in backward the incoming gradient is averaged over all ranks with a
     single all-reduce (the 'all-reduce of Gaussian-parameter grads' of BASELINE.json)."""
@@ -103,6 +126,7 @@ class _ExchangeGrad(torch.autograd.Function):
     def backward(ctx, g):
         g = g.contiguous()
         dist.all_reduce(g, op=dist.ReduceOp.SUM, group=_group)
+        post_overflow_flag(g.device)
         return g / dist.get_world_size(_group)
 
 
@@ -121,6 +145,8 @@ def allreduce_param_grads(params: List[torch.Tensor], average: bool = True) -> N
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=_group)
+    if _flag_work is None:          # stage 2: no output-gradient exchange has posted the flag's reduction yet
+        post_overflow_flag(flat.device)
     if average:
         flat /= dist.get_world_size(_group)
     off = 0
@@ -283,6 +309,7 @@ class _GatherSegments(torch.autograd.Function):
         n0, n_local, n_total, seg = ctx.dims
         g = g.contiguous().clone()
         dist.all_reduce(g, op=dist.ReduceOp.SUM, group=_group)
+        post_overflow_flag(g.device)
         g /= dist.get_world_size(_group)
         parts, off = [], 0
         for c in seg:

@@ -15,6 +15,7 @@ later (see `_PairCapacity`).
 from __future__ import annotations
 
 import ctypes
+import threading
 import time
 import warnings
 from typing import NamedTuple, Optional
@@ -57,11 +58,13 @@ class _PairCapacity:
         the 8 status words are copied asynchronously into pinned memory after every forward and
         polled (never waited for) on later calls — so the buffer tracks the scene with a 2x
         margin and only a frame-to-frame doubling of the pair count can overflow it;
-      * an overflow that still happens is detected on a later poll: by default it WARNS (the capacity
-        has already been raised for the following calls, `overflow_events` counts them — a long run is
-        not aborted by one transient spike; upstream simply resizes); policy "raise" turns it into
-        RasterizerOverflow for callers that would rather stop than apply one step computed from
-        truncated tile lists;
+      * an overflow that still happens yields NO gradient: the backward pass of that frame writes zeros and
+        raises a device-side flag (`overflow_flag(device)`) that `gaussianavatar_amd.optim.Adam` reads to skip
+        its step — all without a host sync, so a step computed from truncated tile lists is never applied
+        (upstream resizes and never truncates; here the truncated step is dropped and the buffer is resized for
+        the following calls). The event itself is detected on a later poll: by default it WARNS
+        (`overflow_events` counts them — a long run is not aborted by one transient spike); policy "raise"
+        turns it into RasterizerOverflow for callers that would rather stop;
       * forwards that nobody can differentiate (evaluation) and settings.debug are always
         checked synchronously and re-rendered when needed.
     """
@@ -186,19 +189,59 @@ def pair_statistics(reset: bool = False):
     return n, (s / n if n else 0.0)
 
 
+_overflow_flags = {}
+
+
+def overflow_flag(device) -> torch.Tensor:
+    """The device-side int32[1] flag of `device` that a backward pass raises when its forward pass had overflowed
+    (that frame's gradients are zeros, include/gsr.h: gsr_backward). `optim.Adam.step` skips its update while the
+    flag is set; `clear_overflow_flag` (called by AvatarModel.zero_grad / optim.Adam.zero_grad) starts a new step."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    f = _overflow_flags.get(idx)
+    if f is None:
+        f = _overflow_flags[idx] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
+    return f
+
+
+def clear_overflow_flag(device=None) -> None:
+    """Start a new optimisation step: lower the flag(s) a previous step's overflow raised (one 4-byte fill)."""
+    for idx, f in _overflow_flags.items():
+        if device is None or torch.device(device).index in (None, idx):
+            f.zero_()
+
+
 PROFILE_KERNELS = ("preprocess", "tile_scan", "scatter", "tile_sort", "render_fwd", "render_bwd", "preprocess_bwd")
+_profile = None       # the GsrProfile object of this module (caller-owned, bound to the launching threads)
+_profile_mask = 0
+_profile_tls = threading.local()
+
+
+def _profile_bind_this_thread() -> None:
+    """The binding is per thread (include/gsr.h) and autograd runs backward on its own thread: every entry into the
+    library re-binds when the requested mask differs from what this thread last bound (one integer compare)."""
+    if getattr(_profile_tls, "mask", 0) != _profile_mask and _profile is not None:
+        _native.gsr_check(_native.gsr().gsr_profile_bind(_profile, _profile_mask))
+        _profile_tls.mask = _profile_mask
 
 
 def profile_enable(on=True) -> None:
-    """Bracket rasterizer kernel launches with HIP events on their stream (bench only). `on`: True =
-    every kernel, False = off, or an iterable of kernel names (PROFILE_KERNELS) to time only those."""
+    """Bracket rasterizer kernel launches of the calling thread with HIP events on their stream (bench only).
+    `on`: True = every kernel, False = off, or an iterable of kernel names (PROFILE_KERNELS) to time only those."""
+    global _profile, _profile_mask
+    lib = _native.gsr()
     if on is True:
         mask = (1 << len(PROFILE_KERNELS)) - 1
     elif not on:
         mask = 0
     else:
         mask = sum(1 << PROFILE_KERNELS.index(k) for k in on)
-    _native.gsr_check(_native.gsr().gsr_profile_enable(mask))
+    if _profile is None:
+        if not mask:
+            return
+        _profile = ctypes.c_void_p(lib.gsr_profile_create())
+    _profile_mask = mask
+    _profile_bind_this_thread()
 
 
 def profile_read(reset: bool = True) -> dict:
@@ -207,7 +250,8 @@ def profile_read(reset: bool = True) -> dict:
     lib = _native.gsr()
     ms = (ctypes.c_double * 7)()
     n = (ctypes.c_int64 * 7)()
-    _native.gsr_check(lib.gsr_profile_read(ms, n, 1 if reset else 0))
+    if _profile is not None:
+        _native.gsr_check(lib.gsr_profile_read(_profile, ms, n, 1 if reset else 0))
     return {lib.gsr_profile_kernel_name(i).decode(): (ms[i], int(n[i])) for i in range(7)}
 
 
@@ -252,7 +296,9 @@ def workspace_views(workspace: torch.Tensor, P: int, W: int, H: int, max_pairs: 
     L = _native.GsrLayout()
     _native.gsr_check(lib.gsr_workspace_layout(P, W, H, max_pairs, ctypes.byref(L)))
     T = ((W + 15) // 16) * ((H + 15) // 16)
-    S = max_pairs // 4 + 16 * T + 16             # segment slots (gsr_common.h: seg_capacity)
+    edge = lib.gsr_render_block_edge()           # pixel block of a wave: 8 -> 4 blocks per tile
+    Bk, npx = (16 // edge) ** 2, edge * edge
+    S = max_pairs * Bk // 64 + Bk * T + Bk       # segment slots (gsr_common.h: seg_capacity)
 
     def view(off, nbytes, dtype, shape):
         return workspace[off:off + nbytes].view(dtype).reshape(shape)
@@ -273,35 +319,43 @@ def workspace_views(workspace: torch.Tensor, P: int, W: int, H: int, max_pairs: 
         grad_acc=view(L.grad_acc, P * 64, torch.float32, (P, 16)),
         status=view(L.status, 32, torch.int32, (8,)),
         seg_entries=view(L.seg_entries, S * 512, torch.int32, (S, 64, 2)),
-        seg_ckpt=view(L.seg_ckpt, S * 256, torch.float32, (S, 16, 4)),
+        seg_ckpt=view(L.seg_ckpt, S * npx * 16, torch.float32, (S, npx, 4)),
         seg_info=view(L.seg_info, S * 8, torch.int32, (S, 2)),
         pix_accum=view(L.pix_accum, W * H * 16, torch.float32, (H * W, 4)),
-        seg_count=view(L.seg_count, T * 64, torch.int32, (T, 16)),
+        seg_count=view(L.seg_count, T * Bk * 4, torch.int32, (T, Bk)),
     )
 
 
+def _ws_mode(rs, record: bool) -> int:
+    """Workspace mode of a call (include/gsr.h GSR_WS_*): forward-only renders use the small workspace."""
+    if not record:
+        return _native.GSR_WS_EVAL
+    return _native.GSR_WS_DEBUG if bool(rs.debug) else _native.GSR_WS_TRAIN
+
+
 def _forward_once(rs, means3D, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                  max_pairs, shs=None):
+                  max_pairs, shs=None, record=True):
     lib = _native.gsr()
+    _profile_bind_this_thread()
     dev = means3D.device
     P = means3D.shape[0]
     H, W = int(rs.image_height), int(rs.image_width)
-    nbytes = lib.gsr_workspace_bytes(P, W, H, max_pairs)
+    nbytes = lib.gsr_workspace_bytes_for(P, W, H, max_pairs, _ws_mode(rs, record))
     if nbytes == 0:
-        raise RuntimeError("gsr_workspace_bytes: invalid arguments")
+        raise RuntimeError("gsr_workspace_bytes_for: invalid arguments")
     workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
     radii = torch.empty((P,), dtype=torch.int32, device=dev)
     keep = []
     st = _settings_struct(rs, keep)
-    rc = lib.gsr_forward(ctypes.byref(st), P, _ptr(means3D), _ptr(colors_precomp), _ptr(shs),
-                         0 if shs is None else int(shs.shape[1]), _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
-                         _ptr(workspace), nbytes, max_pairs, _ptr(color), _ptr(radii),
-                         _stream_ptr(dev))
+    fwd = lib.gsr_forward if record else lib.gsr_forward_eval
+    rc = fwd(ctypes.byref(st), P, _ptr(means3D), _ptr(colors_precomp), _ptr(shs),
+             0 if shs is None else int(shs.shape[1]), _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
+             _ptr(workspace), nbytes, max_pairs, _ptr(color), _ptr(radii), _stream_ptr(dev))
     _native.gsr_check(rc)
     L = _native.GsrLayout()
     lib.gsr_workspace_layout(P, W, H, max_pairs, ctypes.byref(L))
-    status = workspace[L.status:L.status + 32].view(torch.int32)
+    status = workspace[L.status:L.status + 32].view(torch.int32)      # (the offsets do not depend on the mode)
     return color, radii, workspace, status
 
 
@@ -355,11 +409,14 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         _capacity.poll()
         key = (P, int(rs.image_width), int(rs.image_height))
+        # sync_check is set by rasterize_gaussians when nobody can call backward (evaluation, torch.no_grad()): such a
+        # render records nothing for a backward pass (gsr_forward_eval: no segment records, the small workspace)
+        record = not bool(sync_check)
         sync_check = bool(rs.debug) or bool(sync_check) or not _capacity.known(key)
         max_pairs = _capacity.capacity(key)
         while True:
             color, radii, workspace, status = _forward_once(
-                rs, means3D, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, max_pairs, sh)
+                rs, means3D, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, max_pairs, sh, record)
             _capacity.post(status, max_pairs, key)
             if not sync_check:
                 break
@@ -372,6 +429,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.max_pairs = max_pairs
         ctx.has_sr = scales is not None
         ctx.has_sh = sh is not None
+        ctx.recorded = record
         ctx.save_for_backward(means3D, sh if sh is not None else colors_precomp, opacities,
                               scales if scales is not None else torch.empty(0, device=means3D.device),
                               rotations if rotations is not None else torch.empty(0, device=means3D.device),
@@ -385,11 +443,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         lib = _native.gsr()
         rs = ctx.raster_settings
         means3D, colors_precomp, opacities, scales, rotations, cov3D, radii, workspace = ctx.saved_tensors
+        if not ctx.recorded:
+            raise RuntimeError("GaussianRasterizer: this render was made without gradient tracking (forward-only path)")
         if not ctx.has_sr:
             scales = rotations = None
         else:
             cov3D = None
         _capacity.poll()
+        _profile_bind_this_thread()
         dev = means3D.device
         P = means3D.shape[0]
         H, W = int(rs.image_height), int(rs.image_width)
@@ -417,7 +478,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                               _ptr(radii), _ptr(workspace), workspace.numel(), ctx.max_pairs,
                               _ptr(grad_color), _ptr(d_means3D), _ptr(d_means2D), _ptr(d_colors),
                               _ptr(d_sh), _ptr(d_opac), _ptr(d_scales), _ptr(d_rots), _ptr(d_cov),
-                              _stream_ptr(dev))
+                              _ptr(overflow_flag(dev)), _stream_ptr(dev))
         _native.gsr_check(rc)
         return d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rots, d_cov, None, None
 
@@ -449,6 +510,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
             raise RuntimeError("GaussianRasterizer: tensors must live on a HIP device "
                                "(there is no CPU fallback)")
         lib = _native.gsr()
+        _profile_bind_this_thread()
         dev = means3D.device
         B, P = means3D.shape[0], means3D.shape[1]
         H, W = int(rs.image_height), int(rs.image_width)
@@ -468,22 +530,24 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         bt = _native.GsrBatch(B, P * 3, s_col, s_opa, s_sca, s_rot, 0, s_view, s_proj, 0, 0)
         _capacity.poll()
         key = (P, W, H)
+        record = not bool(sync_check)            # nobody can call backward: forward-only kernels, small workspace
         sync_check = bool(rs.debug) or bool(sync_check) or not _capacity.known(key)
         max_pairs = _capacity.capacity(key)
-        L = _native.GsrLayout()
+        mode = _ws_mode(rs, record)
+        fwd = lib.gsr_forward_batch if record else lib.gsr_forward_eval_batch
         while True:
-            frame_bytes = lib.gsr_workspace_bytes(P, W, H, max_pairs)
+            frame_bytes = lib.gsr_workspace_bytes_for(P, W, H, max_pairs, mode)
             workspace = torch.empty(B * frame_bytes, dtype=torch.uint8, device=dev)
             color = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
             radii = torch.empty((B, P), dtype=torch.int32, device=dev)
-            _native.gsr_check(lib.gsr_forward_batch(
+            _native.gsr_check(fwd(
                 ctypes.byref(st), ctypes.byref(bt), P, _ptr(means3D), _ptr(col), None, 0, _ptr(opa),
                 _ptr(sca), _ptr(rot), None, _ptr(workspace), workspace.numel(), max_pairs,
                 _ptr(color), _ptr(radii), _stream_ptr(dev)))
             # one record for the whole launch: [max pairs of a frame, any overflow, -, longest tile
             # list, total pairs of all frames, frames, -, -] (gsr_batch_status, one tiny kernel)
             worst = torch.empty(8, dtype=torch.int32, device=dev)
-            _native.gsr_check(lib.gsr_batch_status(_ptr(workspace), B, P, W, H, max_pairs, _ptr(worst),
+            _native.gsr_check(lib.gsr_batch_status(_ptr(workspace), B, P, W, H, max_pairs, mode, _ptr(worst),
                                                    _stream_ptr(dev)))
             _capacity.post(worst, max_pairs, key)
             if not sync_check:
@@ -494,6 +558,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
             max_pairs = _capacity.capacity(key)
         ctx.raster_settings = rs
         ctx.max_pairs = max_pairs
+        ctx.recorded = record
         # (original shape, has a leading frame dimension) of every differentiable input
         ctx.meta = (B, P, H, W, (s_col, s_opa, s_sca, s_rot, s_view, s_proj),
                     (tuple(colors_precomp.shape), colors_precomp.dim() == 3),
@@ -510,9 +575,12 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         rs = ctx.raster_settings
         means3D, col, opa, sca, rot, view, proj, bg, campos, radii, workspace = ctx.saved_tensors
         B, P, H, W, strides, col_shape, opa_shape, sca_shape, rot_shape = ctx.meta
+        if not ctx.recorded:
+            raise RuntimeError("rasterize_gaussians_batch: this render was made without gradient tracking")
         s_col, s_opa, s_sca, s_rot, s_view, s_proj = strides
         dev = means3D.device
         _capacity.poll()
+        _profile_bind_this_thread()
         grad_color = _f32c(grad_color, (B, 3, H, W))
         need = ctx.needs_input_grad
 
@@ -532,7 +600,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
             ctypes.byref(st), ctypes.byref(bt), P, _ptr(means3D), _ptr(col), None, 0, _ptr(opa), _ptr(sca),
             _ptr(rot), None, _ptr(radii), _ptr(workspace), workspace.numel(), ctx.max_pairs,
             _ptr(grad_color), _ptr(d_means), None, _ptr(d_col), None, _ptr(d_opa), _ptr(d_sca), _ptr(d_rot),
-            None, _stream_ptr(dev)))
+            None, _ptr(overflow_flag(dev)), _stream_ptr(dev)))
 
         def fold(g, info):
             """Per-frame gradients [B, ...] back to the shape the caller passed: summed over frames

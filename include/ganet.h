@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GANET_ABI_VERSION 5
+#define GANET_ABI_VERSION 6
 #define GANET_MAX_TERMS 8
 
 /* ---- dW[N,K] = sum_m g[m,n] x[m,k] ; db[N] = sum_m g[m,n] (db may be NULL).
@@ -273,7 +273,10 @@ int ganet_mean_sq_bwd(int64_t n, const float* x, float norm, const float* d_out,
  * weight decay and maximize off — m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
  * p -= (lr / bias_correction1) * m / (sqrt(v) / sqrt(bias_correction2) + eps) — for the optimiser step of
  * /root/reference/model/avatar_model.py:152-161,264-266. tensors: HOST array, n_tensors <=
- * GANET_MAX_ADAM_TENSORS; all pointers device float32, n elements each, contiguous. */
+ * GANET_MAX_ADAM_TENSORS; all pointers device float32, n elements each, contiguous.
+ * skip_flag: device int32[1] or NULL. When it is non-zero the launch changes NOTHING (no parameter, no moment):
+ * the rasterizer raises this flag when a backward pass had to drop a frame's gradient (include/gsr.h: gsr_backward,
+ * `overflow_flag`), so that a step computed from incomplete gradients is never applied — without a host sync. */
 #define GANET_MAX_ADAM_TENSORS 64
 typedef struct GanetAdamTensor {
   float* param;
@@ -284,7 +287,7 @@ typedef struct GanetAdamTensor {
   float lr, bias_correction1, bias_correction2;
 } GanetAdamTensor;
 int ganet_adam_step(int32_t n_tensors, const GanetAdamTensor* tensors, float beta1, float beta2, float eps,
-                    void* stream);
+                    const int32_t* skip_flag, void* stream);
 
 /* out[0] = bias + sum_{i<n} weights[i] * terms[i][0]: the scalar objective of the training loop
  * (/root/reference/train.py:70-82) in one launch. terms: HOST array of n device pointers, weights: HOST

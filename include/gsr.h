@@ -22,8 +22,9 @@
  *     transposed matrix, i.e. element (row i, col j) of the column-vector-form
  *     matrix is m[j*4+i]  (/root/reference/scene/dataset_mono.py:248-255);
  *   - return value 0 = success; non-zero = error, text via gsr_last_error()
- *     (thread-local). Apart from the opt-in profiler (gsr_profile_*) the library has no
- *     global state and is re-entrant.
+ *     (thread-local). The library has no process-global mutable state and is re-entrant: the
+ *     opt-in profiler records into a caller-owned object bound to the calling thread
+ *     (gsr_profile_*).
  *
  * Plain C; no HIP or torch types appear in any signature.
  */
@@ -37,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 4
+#define GSR_ABI_VERSION 5
 #define GSR_TILE 16              /* tile edge in pixels (BLOCK_X = BLOCK_Y = 16)       */
 #define GSR_NUM_CHANNELS 3
 
@@ -99,12 +100,12 @@ typedef struct GsrLayout {
                                            [2]=unused  [3]=max pairs in one tile              */
   uint64_t seg_heads;      /* int32   [8,64] word 0 of row x = recorded segments of XCD class x (entries of
                                            seg_list[x]); one 256-byte line per counter         */
-  uint64_t seg_count;      /* uint32  [T,16] segments the forward pass recorded per (tile, 4x4 block)     */
+  uint64_t seg_count;      /* uint32  [T,B]  segments the forward pass recorded per (tile, render block); B = 16 blocks of 4x4 pixels */
   uint64_t xyext;          /* float4  [P]    (pixel-space centre, half extents of the alpha>=1/255 box) */
   /* what the forward pass consumed, for the backward pass: segments of up to 64 list entries that survived the
-   * cull of one 4x4 pixel block. Slots are addressed without counters: the 16 blocks of tile t own the slots
-   * 16 (tile_offset[t] / 64 + t) + b c + s  (block b, its s-th segment, c = the tile's per-block capacity) — an
-   * exact bound, S = max_pairs / 4 + 16 T + 16 slots, so recording never overflows */
+   * cull of one 4x4 pixel block. Slots are addressed without counters: the B = 16 blocks of tile t own the slots
+   * B (tile_offset[t] / 64 + t) + b c + s  (block b, its s-th segment, c = the tile's per-block capacity) — an
+   * exact bound, S = max_pairs B / 64 + B T + B slots, so recording never overflows */
   uint64_t seg_entries;    /* uint32  [S,64,2] (Gaussian index, position in the tile's list)  */
   uint64_t seg_ckpt;       /* float   [S,16,4] (T, C.rgb) of the block's pixels at the segment's start */
   uint64_t seg_info;       /* uint32  [S,2]    (block x0 | y0<<16, entries in the segment)    */
@@ -114,11 +115,30 @@ typedef struct GsrLayout {
                                               (settings.debug) backward pass                 */
   uint64_t seg_list;       /* uint32  [8,S]  the recorded segments as dense lists of slot ids, one per XCD class
                                               (tiles of rank = x mod 8), what the segment-parallel backward strides over */
+  /* The sub-arrays are ordered by who needs them, so that a workspace may stop early:
+   *   [0, eval_bytes)    everything a forward-only render touches (gsr_forward_eval*)
+   *   [0, train_bytes)   + what the forward pass leaves for the backward pass (grad_acc, seg_*, pix_accum)
+   *   [0, total_bytes)   + pair_grad, the per-pair records of the deterministic backward (settings.debug) */
+  uint64_t eval_bytes;
+  uint64_t train_bytes;
 } GsrLayout;
 
+/* workspace modes (gsr_workspace_bytes_for): per (tile, Gaussian) pair of capacity a forward-only workspace holds
+ * 20 bytes, a training workspace ~240 bytes (segment records), the deterministic backward 36 more */
+#define GSR_WS_EVAL 0
+#define GSR_WS_TRAIN 1
+#define GSR_WS_DEBUG 2
+
 /* Size in bytes of the workspace for P Gaussians, a W x H image and room for
- * `max_pairs` (tile,Gaussian) pairs. Returns 0 on invalid arguments. */
+ * `max_pairs` (tile,Gaussian) pairs, large enough for every mode (= GSR_WS_DEBUG). Returns 0 on
+ * invalid arguments. */
 size_t gsr_workspace_bytes(int32_t P, int32_t W, int32_t H, int64_t max_pairs);
+
+/* The same for one mode: GSR_WS_EVAL (gsr_forward_eval*), GSR_WS_TRAIN (gsr_forward + gsr_backward with
+ * settings.debug = 0), GSR_WS_DEBUG (settings.debug = 1). In the batched calls the frames' workspaces lie
+ * gsr_workspace_bytes_for(mode of the call) apart: eval for gsr_forward_eval_batch, debug when settings.debug is
+ * set, train otherwise — forward and backward of one render must therefore agree on settings.debug. */
+size_t gsr_workspace_bytes_for(int32_t P, int32_t W, int32_t H, int64_t max_pairs, int32_t mode);
 
 /* Fill `out` with the sub-array offsets for the same arguments. */
 int gsr_workspace_layout(int32_t P, int32_t W, int32_t H, int64_t max_pairs, GsrLayout* out);
@@ -149,6 +169,21 @@ int gsr_forward(const GsrSettings* settings, int32_t P,
                 float* out_color, int32_t* out_radii, void* stream);
 
 /*
+ * Forward without a backward pass to follow (the reference's evaluation / novel-pose renders under
+ * torch.no_grad(), /root/reference/eval.py:42,65, /root/reference/render_novel_pose.py:30-32): same arguments and
+ * results as gsr_forward, but the blend kernel records nothing for a backward pass (no segment records, no
+ * per-pixel accumulators: ~40 bytes per (tile, Gaussian) pair and 16 per pixel less written) and the workspace
+ * may be the small one (GSR_WS_EVAL). gsr_backward must not be called on such a workspace.
+ */
+int gsr_forward_eval(const GsrSettings* settings, int32_t P,
+                     const float* means3D, const float* colors_precomp,
+                     const float* shs, int32_t sh_coeffs,
+                     const float* opacities, const float* scales, const float* rotations,
+                     const float* cov3D_precomp,
+                     void* workspace, size_t workspace_bytes, int64_t max_pairs,
+                     float* out_color, int32_t* out_radii, void* stream);
+
+/*
  * Backward: replaces `_C.rasterize_gaussians_backward` (SURVEY.md §2.1 rows 7-9,
  * Appendix A.4-A.5). Same inputs as forward plus the forward's workspace and
  *   dL_dout_color [3,H,W].
@@ -157,6 +192,10 @@ int gsr_forward(const GsrSettings* settings, int32_t P,
  *   dL_dopacity [P], dL_dscales [P,3], dL_drotations [P,4], dL_dcov3D [P,6].
  * Every non-NULL output is fully overwritten (zeros for Gaussians with radii == 0).
  * The workspace is not consumed: backward may be called repeatedly (retain_graph).
+ * Overflowed forward passes (status[1] == 1: the tile lists were truncated) yield NO gradient: every output of
+ * that frame is written as zeros, and if `overflow_flag` (device int32[1], may be NULL) is given it is set to 1
+ * — without a host sync. An optimiser that reads the flag (ganet_adam_step) skips its step, so a step computed
+ * from truncated tile lists is never applied; the caller clears the flag when it starts a new step.
  */
 int gsr_backward(const GsrSettings* settings, int32_t P,
                  const float* means3D, const float* colors_precomp,
@@ -168,7 +207,7 @@ int gsr_backward(const GsrSettings* settings, int32_t P,
                  const float* dL_dout_color,
                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors, float* dL_dsh,
                  float* dL_dopacity, float* dL_dscales, float* dL_drotations,
-                 float* dL_dcov3D, void* stream);
+                 float* dL_dcov3D, int32_t* overflow_flag, void* stream);
 
 /*
  * Batched variants: `frames` frames that share P, image size, FoV and background are rendered by
@@ -203,6 +242,14 @@ int gsr_forward_batch(const GsrSettings* settings, const GsrBatch* batch, int32_
                       void* workspace, size_t workspace_bytes, int64_t max_pairs,
                       float* out_color, int32_t* out_radii, void* stream);
 
+int gsr_forward_eval_batch(const GsrSettings* settings, const GsrBatch* batch, int32_t P,
+                           const float* means3D, const float* colors_precomp,
+                           const float* shs, int32_t sh_coeffs,
+                           const float* opacities, const float* scales, const float* rotations,
+                           const float* cov3D_precomp,
+                           void* workspace, size_t workspace_bytes, int64_t max_pairs,
+                           float* out_color, int32_t* out_radii, void* stream);
+
 int gsr_backward_batch(const GsrSettings* settings, const GsrBatch* batch, int32_t P,
                        const float* means3D, const float* colors_precomp,
                        const float* shs, int32_t sh_coeffs,
@@ -213,35 +260,44 @@ int gsr_backward_batch(const GsrSettings* settings, const GsrBatch* batch, int32
                        const float* dL_dout_color,
                        float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors, float* dL_dsh,
                        float* dL_dopacity, float* dL_dscales, float* dL_drotations,
-                       float* dL_dcov3D, void* stream);
+                       float* dL_dcov3D, int32_t* overflow_flag, void* stream);
 
 /* Replaces `_C.mark_visible`: out_visible[i] = 1 if Gaussian i passes the near-plane
  * test of the forward pass (view-space z > 0.2). out_visible is uint8 [P]. */
 int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,
                      const float* projmatrix, uint8_t* out_visible, void* stream);
 
-/* Batched launches: combine the per-frame status words of `frames` consecutive workspaces into ONE
- * device record status_dev[8] = [max pairs needed by a frame, any overflow, sum of word 2, longest
- * tile list, total pairs of all frames, frames, max word 6, max word 7] (asynchronous, on `stream`). */
+/* Batched launches: combine the per-frame status words of `frames` consecutive workspaces (`mode`: the
+ * GSR_WS_* mode of the call that filled them, i.e. their spacing) into ONE device record status_dev[8] = [max
+ * pairs needed by a frame, any overflow, sum of word 2, longest tile list, total pairs of all frames, frames, max
+ * word 6, max word 7] (asynchronous, on `stream`). */
 int gsr_batch_status(const void* workspace, int32_t frames, int32_t P, int32_t W, int32_t H,
-                     int64_t max_pairs, int32_t* status_dev, void* stream);
+                     int64_t max_pairs, int32_t mode, int32_t* status_dev, void* stream);
 
 /* Blocking helper: waits for `stream`, copies the 8 status words to status_host. */
 int gsr_read_status(const void* workspace, int32_t P, int32_t W, int32_t H,
                     int64_t max_pairs, int32_t* status_host, void* stream);
 
 /*
- * Optional per-kernel timing (bench/profiling only; off by default, the one piece of
- * process-global state in the library). When enabled every kernel launch is bracketed by
- * hipEvents recorded on the launch stream; gsr_profile_read waits for them and returns, per
- * kernel id, the summed GPU time in milliseconds and the number of launches since the last
- * reset. Kernel ids: 0 preprocess, 1 tile_scan, 2 scatter, 3 tile_sort, 4 render_fwd,
- * 5 render_bwd, 6 preprocess_bwd.
+ * Optional per-kernel timing (bench/profiling only). The caller owns a GsrProfile object and binds it to the
+ * calling thread; from then on every kernel this thread launches through the library whose id is in `mask` is
+ * bracketed by hipEvents recorded on the launch stream and accounted to that object (bind NULL or mask 0 to stop).
+ * gsr_profile_read waits for the recorded events and returns, per kernel id, the summed GPU time in milliseconds and
+ * the number of launches since the last reset. Kernel ids: 0 preprocess, 1 tile_scan, 2 scatter, 3 tile_sort,
+ * 4 render_fwd, 5 render_bwd, 6 preprocess_bwd. No process-global state: the binding is thread-local, like the
+ * error text.
  */
 #define GSR_NUM_KERNELS 7
-int gsr_profile_enable(int mask);   /* bit k = time kernel id k; 0 = off; 0x7f = all */
-int gsr_profile_read(double* ms_sum, int64_t* launches, int reset);
+typedef struct GsrProfile GsrProfile;
+GsrProfile* gsr_profile_create(void);
+void gsr_profile_destroy(GsrProfile* profile);       /* unbinds it from the calling thread if bound */
+int gsr_profile_bind(GsrProfile* profile, int mask); /* bit k = time kernel id k; 0x7f = all */
+int gsr_profile_read(GsrProfile* profile, double* ms_sum, int64_t* launches, int reset);
 const char* gsr_profile_kernel_name(int id);
+
+/* Edge in pixels of the square pixel block one wave renders (4): a tile has (16 / edge)^2 blocks, the shapes of
+ * seg_count [T, blocks], seg_ckpt [S, edge^2, 4] and S = max_pairs * blocks / 64 + blocks * (T + 1) follow from it. */
+int gsr_render_block_edge(void);
 
 /* Text of the last error raised on the calling thread ("" if none). */
 const char* gsr_last_error(void);

@@ -33,8 +33,24 @@ def test_layout_is_consistent_without_gpu():
     L = _native.GsrLayout()
     assert lib.gsr_workspace_layout(1000, 100, 70, 5000, ctypes.byref(L)) == 0
     assert L.total_bytes == lib.gsr_workspace_bytes(1000, 100, 70, 5000)
-    offs = [getattr(L, f) for f in _native._LAYOUT_FIELDS[1:]]
-    assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
+    offs = [getattr(L, f) for f in _native._LAYOUT_FIELDS[1:] if not f.endswith("_bytes")]
+    assert len(set(offs)) == len(offs) and all(o % 256 == 0 and o < L.total_bytes for o in offs)
+    # the sub-arrays are ordered by who needs them: forward-only < + backward state < + deterministic backward
+    assert 0 < L.eval_bytes < L.train_bytes < L.total_bytes
+    for mode, want in ((_native.GSR_WS_EVAL, L.eval_bytes), (_native.GSR_WS_TRAIN, L.train_bytes),
+                       (_native.GSR_WS_DEBUG, L.total_bytes)):
+        assert lib.gsr_workspace_bytes_for(1000, 100, 70, 5000, mode) == want
+    assert lib.gsr_workspace_bytes_for(1000, 100, 70, 5000, 3) == 0
+    for f in ("depth", "point_list", "final_T", "n_contrib", "status", "xyext", "seg_count"):
+        assert getattr(L, f) < L.eval_bytes, f
+    for f in ("grad_acc", "seg_entries", "seg_ckpt", "seg_info", "pix_accum", "seg_list"):
+        assert L.eval_bytes <= getattr(L, f) < L.train_bytes, f
+    assert L.pair_grad == L.train_bytes
+    # a forward-only workspace is several times smaller per (tile, Gaussian) pair of capacity
+    big = lib.gsr_workspace_bytes_for(1000, 100, 70, 1 << 20, _native.GSR_WS_TRAIN)
+    small = lib.gsr_workspace_bytes_for(1000, 100, 70, 1 << 20, _native.GSR_WS_EVAL)
+    assert small < big // 4
+    assert lib.gsr_render_block_edge() == 4
     assert lib.gsr_workspace_bytes(-1, 100, 70, 5000) == 0
     assert lib.gsr_workspace_layout(10, 0, 70, 5000, ctypes.byref(L)) != 0
     assert b"invalid" in lib.gsr_last_error()
@@ -45,9 +61,17 @@ def test_forward_rejects_bad_arguments_before_touching_the_device():
     from gaussianavatar_amd import _native
     lib = _native.gsr()
     st = _native.GsrSettings(64, 64, 0.5, 0.5, 1.0, 0, 0, 0, None, None, None, None)
-    rc = lib.gsr_forward(ctypes.byref(st), 10, None, None, None, 0, None, None, None, None, None, 0, 100,
-                         None, None, None)
-    assert rc == 1 and b"device pointers" in lib.gsr_last_error()
+    for fwd in (lib.gsr_forward, lib.gsr_forward_eval):
+        rc = fwd(ctypes.byref(st), 10, None, None, None, 0, None, None, None, None, None, 0, 100, None, None, None)
+        assert rc == 1 and b"device pointers" in lib.gsr_last_error()
+    # the profiler is a caller-owned object bound to the calling thread: no process-global state
+    prof = ctypes.c_void_p(lib.gsr_profile_create())
+    assert prof.value
+    assert lib.gsr_profile_bind(prof, 0x7f) == 0 and lib.gsr_profile_bind(None, 0) == 0
+    ms, n = (ctypes.c_double * 7)(), (ctypes.c_int64 * 7)()
+    assert lib.gsr_profile_read(prof, ms, n, 1) == 0 and sum(n) == 0
+    assert lib.gsr_profile_read(None, ms, n, 1) == 1
+    lib.gsr_profile_destroy(prof)
 
 
 def test_dropin_package_surface():

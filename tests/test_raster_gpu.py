@@ -175,6 +175,106 @@ def test_overflow_is_flagged_and_recovered(raster_oracle):
         R._capacity.pending.clear()
 
 
+def test_steady_state_overflow_never_reaches_the_parameters(raster_oracle):
+    """A steady-state forward pass that overflows its pair buffer is detected by the host only iterations later (the
+    status words are polled, never waited for). Until then nothing computed from the truncated tile lists may reach
+    the parameters: the backward pass writes zeros and raises the device-side flag, optim.Adam's kernel reads it and
+    changes nothing — parameters and moments bit-identical across that step — and training continues on the next
+    one with the resized buffer (the reference resizes and never truncates)."""
+    import time
+    import torch
+    from gaussianavatar_amd import rasterizer as R
+    from gaussianavatar_amd.optim import Adam
+    from tests.hip_helpers import scene_tensors, settings_from_scene
+    sc = random_scene(3000, 128, 128, seed=4, kind="avatar", scale_med=0.03)
+    ref = oracle_forward(raster_oracle, sc)
+    key = (3000, 128, 128)
+    saved = (R._capacity.pairs_per_gaussian, R._capacity.floor, dict(R._capacity.seen))
+    try:
+        R._capacity.pairs_per_gaussian, R._capacity.floor = 0, 64
+        rs = settings_from_scene(sc)
+        t = scene_tensors(sc, requires_grad=True)
+        names = ("means3D", "colors", "scales")
+        params = [t[k] for k in names]
+        opt = Adam(params, lr=1e-3)
+
+        def iteration():
+            opt.zero_grad()
+            color, _ = R.GaussianRasterizer(rs)(means3D=t["means3D"], means2D=None, opacities=t["opacities"],
+                                                colors_precomp=t["colors"], scales=t["scales"], rotations=t["rotations"])
+            ((color - 0.25) ** 2).mean().backward()
+            return color.detach()
+
+        R._capacity.seen.pop(key, None)
+        iteration()                                   # first call of the shape: sized synchronously, no overflow
+        opt.step()
+        assert int(R.overflow_flag("cuda")) == 0
+        state = lambda: [p.detach().clone() for p in params] + [opt.state[p][k].clone() for p in params
+                                                                for k in ("exp_avg", "exp_avg_sq")]
+        # steady state with a stale history: the scene needs far more pairs than the buffer holds
+        R._capacity.seen[key] = 10
+        R._capacity.stamp[key] = time.monotonic()
+        before = state()
+        with pytest.warns(UserWarning, match="pair buffer overflow"):     # (raised by whichever poll sees it first)
+            iteration()
+            assert int(R.overflow_flag("cuda")) == 1
+            for p in params:
+                assert float(p.grad.abs().max()) == 0.0     # no gradient from truncated lists
+            opt.step()
+            for a, b in zip(before, state()):
+                assert torch.equal(a, b)                    # the step changed nothing
+            R.check_overflow(block=True)                    # the host learns of it at the latest here: capacity raised
+        # training continues: the next step renders the full lists and moves the parameters
+        color = iteration()
+        assert int(R.overflow_flag("cuda")) == 0
+        assert np.abs(color.cpu().numpy() - oracle_forward(
+            raster_oracle, {**sc, **{k: t[k].detach().cpu().numpy() for k in names}})["color"]).mean() <= IMG_L1_TOL
+        opt.step()
+        R.check_overflow(block=True)
+        assert not torch.equal(before[0], params[0].detach())
+        assert ref["D"] > 64
+    finally:
+        R._capacity.pairs_per_gaussian, R._capacity.floor = saved[0], saved[1]
+        R._capacity.seen = saved[2]
+        R._capacity.pending.clear()
+        R.clear_overflow_flag()
+
+
+def test_forward_only_render_records_nothing_and_matches(raster_oracle):
+    """torch.no_grad() / no input requires grad (the reference's eval.py:42,65 and render_novel_pose.py:30-32): the
+    forward-only kernels — no segment records, the small workspace — must give the same image, bit for bit, as the
+    recording render; per-frame and batched."""
+    import torch
+    from gaussianavatar_amd import _native, rasterizer as R
+    from tests.hip_helpers import scene_tensors, settings_from_scene
+    sc = random_scene(20000, 320, 200, seed=9, kind="general", scale_med=0.01)
+    rs = settings_from_scene(sc)
+    kw = lambda t: dict(means3D=t["means3D"], means2D=None, opacities=t["opacities"], colors_precomp=t["colors"],
+                        scales=t["scales"], rotations=t["rotations"])
+    t = scene_tensors(sc, requires_grad=True)
+    color_rec, radii_rec = R.GaussianRasterizer(rs)(**kw(t))
+    with torch.no_grad():
+        color_eval, radii_eval = R.GaussianRasterizer(rs)(**kw(t))
+    t2 = scene_tensors(sc)                                  # nothing requires grad
+    color_eval2, _ = R.GaussianRasterizer(rs)(**kw(t2))
+    assert torch.equal(color_rec.detach(), color_eval) and torch.equal(color_rec.detach(), color_eval2)
+    assert torch.equal(radii_rec, radii_eval)
+    ref = oracle_forward(raster_oracle, sc)
+    assert np.abs(color_eval.cpu().numpy() - ref["color"]).mean() <= IMG_L1_TOL
+    # batched
+    B = 3
+    means = torch.stack([t2["means3D"] + 0.01 * f for f in range(B)])
+    args = (t2["colors"], t2["opacities"], t2["scales"], t2["rotations"], rs)
+    img_rec, _ = R.rasterize_gaussians_batch(means.clone().requires_grad_(True), *args)
+    img_eval, _ = R.rasterize_gaussians_batch(means, *args)
+    assert torch.equal(img_rec.detach(), img_eval)
+    # the forward-only workspace is the small one
+    lib = _native.gsr()
+    cap = 1 << 20
+    assert lib.gsr_workspace_bytes_for(20000, 320, 200, cap, _native.GSR_WS_EVAL) * 4 < \
+        lib.gsr_workspace_bytes_for(20000, 320, 200, cap, _native.GSR_WS_TRAIN)
+
+
 def test_api_errors_and_retain_graph():
     import torch
     from gaussianavatar_amd.rasterizer import GaussianRasterizer

@@ -305,3 +305,39 @@ def test_debug_backward_is_bitwise_repeatable(raster_oracle, P, W, H, kind, scal
         scale_ = np.abs(want).max() + 1e-12
         assert np.abs(got.cpu().numpy() - want).max() <= 2e-3 * scale_, key
         assert float((got - fast).abs().max()) <= 2e-3 * scale_, key
+
+
+@pytest.mark.parametrize("spread", [0.06, 0.025])
+def test_more_than_8192_tiles_long_lists_and_debug_backward(raster_oracle, spread):
+    """Above 8192 tiles (here 2048 x 1152: 9216) tile_scan leaves the identity tile order, so every walk over it must
+    SKIP empty tiles instead of stopping at the first one (the deterministic backward stopped, its
+    per-pair records stayed unwritten and the gather summed uninitialised memory). The scene is one dense cluster:
+    spread 0.06 gives lists above 2048 and 4096 keys (chunk sort + both merge passes in their unordered form),
+    spread 0.025 lists above 8192 (the one-workgroup path). Checked: bit-exact lists, the default backward and the
+    deterministic one against the oracle, the deterministic one bitwise repeatable."""
+    import torch
+    from gaussianavatar_amd.rasterizer import GaussianRasterizer
+    from tests.hip_helpers import scene_tensors, settings_from_scene
+    W, H = 2048, 1152
+    assert ((W + 15) // 16) * ((H + 15) // 16) > 8192
+    sc = random_scene(60_000, W, H, seed=31, kind="avatar", spread=spread, scale_med=0.004)
+    ref, got = assert_forward_parity(raster_oracle, sc)
+    assert got["status"][3] > (8192 if spread < 0.05 else 4096), got["status"]
+    g = torch.tensor(np.random.default_rng(6).normal(0, 1, (3, H, W)).astype(np.float32), device="cuda")
+    rb = raster_oracle.backward(ref, g.cpu().numpy())
+
+    def run(debug):
+        rs = settings_from_scene(sc, debug=debug)
+        t = scene_tensors(sc, requires_grad=True)
+        color, radii = GaussianRasterizer(rs)(means3D=t["means3D"], means2D=None, opacities=t["opacities"],
+                                              colors_precomp=t["colors"], scales=t["scales"], rotations=t["rotations"])
+        color.backward(g)
+        return [t[k].grad.clone() for k in ("means3D", "colors", "opacities", "scales", "rotations")]
+
+    ga, gb, gc = run(True), run(True), run(False)
+    for a, b, c, key in zip(ga, gb, gc, ("dmeans3D", "dcolors", "dopacity", "dscales", "drots")):
+        assert torch.equal(a, b), key
+        want = rb[key].reshape(a.shape)
+        bar = 2e-3 * (np.abs(want).max() + 1e-12)
+        assert np.abs(a.cpu().numpy() - want).max() <= bar, ("debug", key)
+        assert np.abs(c.cpu().numpy() - want).max() <= bar, ("default", key)
