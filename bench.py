@@ -240,6 +240,13 @@ def plumbing_config1(budget_s: float = 10.0) -> dict:
                              "sample": f"{n} iterations, {el:.1f} s wall, {best[0]} of {cores} host threads; CPU: {_cpu_model()}"}}
 
 
+def _traffic_file():
+    """The newest committed PMC-traffic summary (profiles/rNN_traffic.json; tools/pmc_traffic.sh writes them)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    return files[-1] if files else None
+
+
 def _cpu_model() -> str:
     try:
         with open("/proc/cpuinfo") as f:
@@ -306,6 +313,57 @@ def fixed_global_batch_line(args, dev, rank, world, global_batch=8):
                             f"statistics, outputs assembled with one all-reduce" if world > 1 else "single GPU")}
 
 
+def secondary_stage2_line(args, dev):
+    """A second, shorter measurement every default bench line carries (`secondary`): the stage-2 iteration
+    (pose-encoder UNet on, the decoder evaluated per frame: M = frames x S^2 rows) at the headline size — the workload
+    of BASELINE.json configs[4] on SMPL, one GPU. Same loop as `--stage 2` (/root/reference/train.py:78-86)."""
+    from gaussianavatar_amd import rasterizer
+    from gaussianavatar_amd.avatar_model import AvatarModel, collate_frames, default_params
+    from gaussianavatar_amd.losses import l1_loss_w, ssim, weighted_sum
+    B = args.frames_per_gpu
+    torch.manual_seed(0)
+    mp, npar, op = default_params(batch_size=B, num_points=args.points, image_width=args.size,
+                                  image_height=args.height or args.size, num_frames=16, train_stage=2,
+                                  smpl_type=args.smpl_type,
+                                  query_posmap_size=args.uv or (1024 if args.points > 512 * 512 else 512))
+    model = AvatarModel(mp, npar, op, train=True, device=dev)
+    model.training_setup()
+    model.net.train()
+    with torch.no_grad():      # stand-in for the stage-1 checkpoint stage 2 starts from (see main())
+        model.net.decoder.conv8N.weight.mul_(0.01)
+        model.net.decoder.conv8N.bias.fill_(-5.65)
+    ds = model.train_dataset
+    W, H = args.size, args.height or args.size
+    gt = torch.ones(B, 3, H, W, device=dev)
+    gt[:, :, H // 5: 4 * H // 5, 2 * W // 5: 3 * W // 5] = 0.6
+    batches = [collate_frames([ds[(s * B + k) % len(ds)] for k in range(B)], dev) for s in range(2)]
+    l = op.lambda_dssim
+
+    def step(i):
+        image, points, pose_loss, offset_loss = model.train_stage2(batches[i % 2], args.iteration)
+        loss = weighted_sum([offset_loss, l1_loss_w(image, gt), ssim(image, gt), pose_loss],
+                            [op.lambda_rgl, 1.0 - l, -l, 10.0], bias=l)
+        model.zero_grad(1)
+        loss.backward()
+        model.step(1)
+
+    steps, warm = min(args.steps, 30), min(max(args.warmup, 3), 8)
+    for i in range(warm):
+        step(i)
+    rasterizer.check_overflow(block=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warm + i)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    N = int(model.query_points.shape[1])
+    return {"workload": f"stage-2 train iteration (pose-encoder UNet + per-frame decoder, M = {B} x {int(model.uv_coord_map.shape[0])} "
+                        f"rows), {N} Gaussians, {W}x{H}, {B} frames, {args.smpl_type.upper()}-shaped body, 1 GPU "
+                        f"(the single-GPU share of BASELINE.json configs[4]'s stage 2; `bench.py --stage 2`)",
+            "value": steps / el, "unit": "iters/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "warmup": warm}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -342,6 +400,8 @@ def main():
     ap.add_argument("--share-device0", action="store_true", help="development: every rank on GPU 0")
     ap.add_argument("--no-fixed-batch", action="store_true",
                     help="skip the second, shorter measurement with a fixed global batch of 8 frames (fixed_global_batch)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the second short measurement of the default line: the stage-2 iteration (secondary)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket rasterizer kernels with HIP events in the timed region")
@@ -486,14 +546,17 @@ def main():
         assert backend == "nccl", f"multi-GPU bench must run over RCCL (backend nccl), got {backend}"
     dflops = decoder_flops(model, 1 if args.stage == 1 else B)
     dbytes = decoder_bytes(model, 1 if args.stage == 1 else B)
-    fixed = None
-    if args.stage == 1 and not args.global_batch and args.config in (0, 3) and not args.no_fixed_batch:
-        Nq = model.query_points.shape[1]
+    fixed, secondary = None, None
+    headline = args.stage == 1 and not args.global_batch and args.config in (0, 3)
+    Nq = model.query_points.shape[1]
+    if headline and not (args.no_fixed_batch and (args.no_secondary or world > 1)):
         del model, batches
         torch.cuda.empty_cache()
-        fixed = fixed_global_batch_line(args, dev, rank, world)
-    else:
-        Nq = model.query_points.shape[1]
+        if not args.no_fixed_batch:
+            fixed = fixed_global_batch_line(args, dev, rank, world)
+            torch.cuda.empty_cache()
+        if world == 1 and not args.no_secondary:
+            secondary = [secondary_stage2_line(args, dev)]
 
     if rank != 0:
         return
@@ -509,6 +572,7 @@ def main():
         "scaling": "strong" if args.global_batch else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "ranks": world, "dist_backend": backend, **({"fixed_global_batch": fixed} if fixed else {}),
+        **({"secondary": secondary} if secondary else {}),
         "config": {"workload": f"stage-{args.stage} train iteration (LBS + feature net + skinning + Gaussian rasterizer "
                                f"fwd+bwd + L1/DSSIM + Adam), {N} Gaussians, {W}x{H}, {B} frames per GPU "
                                + ("(BASELINE.json configs[2])" if (args.stage, N, W, H) == (1, 200_000, 1024, 1024)
@@ -571,23 +635,34 @@ def main():
         if dom_family in dflops:
             # HBM bytes of one 128->128 launch of this family (PMC passes committed under profiles/)
             traffic, traffic_note = None, None
-            tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
-            if os.path.exists(tpath):
+            tpath = _traffic_file()
+            if tpath:
                 t = json.load(open(tpath)).get(dom_family)
                 if t:
                     traffic = (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0
                     traffic_note = ("HBM bytes of one 128->128 launch (M = 262,144) of this family: rocprofv3 --pmc "
-                                    "FETCH_SIZE / WRITE_SIZE, separate passes of this command, profiles/r03_pmc_traffic.txt; "
+                                    f"FETCH_SIZE / WRITE_SIZE, separate passes of this command ({os.path.relpath(tpath, ROOT)}; "
+                                    "tools/pmc_traffic.sh re-measures it: PMC passes cannot ride inside the timed run); "
                                     "2*FETCH+WRITE (gfx950 wide-read correction); equals the algorithmic traffic of that "
                                     "launch (4 x 134 MB of activations + 17 MB of partial weight-gradient tiles)")
             mfma = {"bound": "mfma", "achieved": d["TFLOPs"], "peak": mfma_peak, "unit": "TFLOP/s",
                     "frac": d["frac_of_mfma_peak"], "algorithmic_flops_per_iter": d["flops_per_iter"]}
             hbm = {"bound": "hbm", "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": d["frac_of_hbm_peak"], "algorithmic_bytes_per_iter": d["bytes_per_iter"]}
+            # how far the backward pass is from its byte minimum (every tensor of every layer touched once)
+            bw_launched = dbytes.get("layer_bwd", dbytes.get("mlp_bwd_data", 0.0) + dbytes.get("wgrad_act", 0.0)) + dbytes["head_bwd"]
+            byte_minimum = {"backward_minimum_bytes_per_iter": dbytes["backward_minimum"],
+                            "backward_launched_bytes_per_iter": bw_launched,
+                            "backward_launched_over_minimum": bw_launched / dbytes["backward_minimum"],
+                            "note": "algorithmic bytes of the decoder backward's launches (layer_bwd + head_bwd) against the "
+                                    "bytes it would move if every layer touched each of its tensors once; the excess is the "
+                                    "three conv6 branches accumulating into conv5's gradient through HBM and re-reading z5, and "
+                                    "conv5 / conv1 as separate input-half launches (DESIGN.md section 4.3: why a three-branch "
+                                    "kernel does not fit the register file)"}
             first, second = (mfma, hbm) if d["bound"] == "mfma" else (hbm, mfma)
             roof = {"kernel": dom_family, **first, "traffic": traffic, "traffic_note": traffic_note,
                     "avg_us": d["avg_us"], "launches_per_iter": d["launches_per_iter"], "us_per_iter": d["us_per_iter"],
-                    "other_roof": second,
+                    "other_roof": second, "byte_minimum": byte_minimum,
                     "note": "a tall-skinny fp32 GEMM family (activations 134 MB per operand, 8.6 GFLOP per 128x128 "
                             "layer). Both roofs are priced and the one that demands more time is reported as the bound: "
                             "HBM (8 TB/s, algorithmic bytes) and the matrix pipe — "
@@ -612,13 +687,13 @@ def main():
         if "render_bwd" in kern:
             rb = kern["render_bwd"]
             traffic, traffic_note = None, None
-            tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
-            if os.path.exists(tpath) and (N, H, B) == (200_000, 1024, 2):
+            tpath = _traffic_file()
+            if tpath and (N, H, B) == (200_000, 1024, 2):
                 t = json.load(open(tpath)).get("render_bwd")
                 if t:
                     traffic = (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0
                     traffic_note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of this command, "
-                                    "profiles/r03_pmc_traffic.txt; 2*FETCH+WRITE (gfx950 wide-read correction)")
+                                    f"{os.path.relpath(tpath, ROOT)}; 2*FETCH+WRITE (gfx950 wide-read correction)")
             out["roofline_raster_bwd"] = {
                 "kernel": "render_bwd", "bound": "hbm", "achieved": rb["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": rb["frac_of_peak"], "traffic": traffic, "traffic_note": traffic_note, "avg_us": rb["avg_us"],

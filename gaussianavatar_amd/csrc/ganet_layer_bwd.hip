@@ -63,10 +63,13 @@ constexpr int LTILE = 128 * 128 + 128;      // partial tile + bias, as wgrad_spl
 #ifdef GANET_LBWD_TRACE
 // development: phase time stamps (s_memtime) of block 0's consumer wave 0 and producer wave 4, 16 stamps per round
 __device__ unsigned long long g_lbwd_trace[2][64][16];
+__device__ unsigned long long g_lbwd_blocks[256][4];     // per workgroup: start, loop start, loop end, end (s_memrealtime, 100 MHz)
 #define LBWD_STAMP(ROLE, R, I) do { if (blockIdx.x == 0 && lane == 0 && (R) < 64 && wave == ((ROLE) ? 4 : 0)) \
     g_lbwd_trace[ROLE][R][I] = __builtin_amdgcn_s_memtime(); } while (0)
+#define LBWD_BLOCK(I) do { if (lane == 0 && wave == 0) g_lbwd_blocks[blockIdx.x][I] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define LBWD_STAMP(ROLE, R, I) do {} while (0)
+#define LBWD_BLOCK(I) do {} while (0)
 #endif
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -91,23 +94,13 @@ layer_bwd_spec_kernel(int64_t M, const float* __restrict__ g, const float* __res
   extern __shared__ u32x4 s_mem[];
   char* const lds = reinterpret_cast<char*>(s_mem);
   constexpr int BUFB = ACCUM ? BUF_ACC : BUF;  // bytes of one slab buffer
-  // the coefficient staging overlays the second slab buffer: the producers read it into registers behind the first
-  // barrier, the buffer is first written behind the second
-  float* const s_coef = reinterpret_cast<float*>(lds + BUFB);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int kg = lane >> 5, c = lane & 31;
   const bool consumer = wave < 4;              // uniform
   constexpr int ldo = KIN == 128 ? 128 : KIN;  // row stride of `out`: [M,128], or [M,72] like the padded input
   LBWD_STAMP(0, 63, 0); LBWD_STAMP(1, 63, 0);
-
-  for (int i = threadIdx.x; i < 128; i += LWG) {
-    s_coef[i] = gcoef[i];
-    s_coef[128 + i] = gcoef[128 + i];
-    s_coef[256 + i] = gcoef[256 + i];
-    s_coef[384 + i] = KIN == 128 ? src_scale[i] * kLog2e : 0.f;
-    s_coef[512 + i] = KIN == 128 ? src_shift[i] * kLog2e : 0.f;
-  }
+  LBWD_BLOCK(0);
   const int64_t nslab = M / LSLAB;
   const int rounds = (int)((nslab + gridDim.x - 1) / gridDim.x);
   auto slab_of = [&](int r) -> int64_t { return (int64_t)r * gridDim.x + blockIdx.x; };
@@ -143,12 +136,24 @@ layer_bwd_spec_kernel(int64_t M, const float* __restrict__ g, const float* __res
         r.o1 = *reinterpret_cast<const f32x4*>(out + oo + 4);
       }
     };
-    // per-column coefficients of this lane's 8 columns: registers (a producer holds little else)
-    __syncthreads();                                     // coefficients staged
-    const float4* cf = reinterpret_cast<const float4*>(s_coef);
-    const float4 A0 = cf[2 * pq], A1 = cf[2 * pq + 1], Q0 = cf[32 + 2 * pq], Q1 = cf[32 + 2 * pq + 1];
-    const float4 P0 = cf[64 + 2 * pq], P1 = cf[64 + 2 * pq + 1];
-    const float4 C0 = cf[96 + 2 * pq], C1 = cf[96 + 2 * pq + 1], H0 = cf[128 + 2 * pq], H1 = cf[128 + 2 * pq + 1];
+    // The kernel's start is a chain of cold misses (2-4 k cycles each): everything a producer needs first is requested
+    // at once — the rows of slab 0, then its 8 columns' coefficients straight from global memory (they used to be staged
+    // through LDS behind a workgroup barrier: 21.8 k cycles of prologue, tools/lbwd_trace.py), then the rows of slab 1.
+    Raw a0, a1, b0, b1;
+    load_raw(a0, phys(slab_of(0)), 0); load_raw(a1, phys(slab_of(0)), 1);
+    const float4* cf = reinterpret_cast<const float4*>(gcoef) + 2 * pq;
+    const float4 A0 = cf[0], A1 = cf[1], Q0 = cf[32], Q1 = cf[33], P0 = cf[64], P1 = cf[65];
+    float4 C0 = make_float4(0.f, 0.f, 0.f, 0.f), C1 = C0, H0 = C0, H1 = C0;
+    if (KIN == 128) {
+      const float4* sc4 = reinterpret_cast<const float4*>(src_scale) + 2 * pq;
+      const float4* sh4 = reinterpret_cast<const float4*>(src_shift) + 2 * pq;
+      C0 = sc4[0]; C1 = sc4[1]; H0 = sh4[0]; H1 = sh4[1];
+    }
+    load_raw(b0, phys(slab_of(1)), 0); load_raw(b1, phys(slab_of(1)), 1);
+    if (KIN == 128) {      // softplus in log2 units
+      C0.x *= kLog2e; C0.y *= kLog2e; C0.z *= kLog2e; C0.w *= kLog2e; C1.x *= kLog2e; C1.y *= kLog2e; C1.z *= kLog2e; C1.w *= kLog2e;
+      H0.x *= kLog2e; H0.y *= kLog2e; H0.z *= kLog2e; H0.w *= kLog2e; H1.x *= kLog2e; H1.y *= kLog2e; H1.z *= kLog2e; H1.w *= kLog2e;
+    }
     float bias[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias[e] = 0.f;
@@ -196,10 +201,7 @@ layer_bwd_spec_kernel(int64_t M, const float* __restrict__ g, const float* __res
     };
     // two slabs of raw rows in flight: sets (a0, a1) and (b0, b1); the round loop is unrolled by two so that a set is
     // a fixed group of registers (a loop-carried copy would wait for the loads)
-    Raw a0, a1, b0, b1;
-    load_raw(a0, phys(slab_of(0)), 0); load_raw(a1, phys(slab_of(0)), 1);
     produce(a0, 0, 0, slab_of(0) < nslab); produce(a1, 0, 1, slab_of(0) < nslab);
-    load_raw(b0, phys(slab_of(1)), 0); load_raw(b1, phys(slab_of(1)), 1);
     load_raw(a0, phys(slab_of(2)), 0); load_raw(a1, phys(slab_of(2)), 1);
     __syncthreads();                                     // slab 0 in LDS
     const int rounds2 = (rounds + 1) & ~1;
@@ -299,10 +301,10 @@ layer_bwd_spec_kernel(int64_t M, const float* __restrict__ g, const float* __res
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) wacc[a][b][r] = 0.f;
-    __syncthreads();                                     // coefficients staged (producers' barrier)
     __syncthreads();                                     // slab 0 in LDS
     const int rounds2 = (rounds + 1) & ~1;
     LBWD_STAMP(0, 63, 1);
+    LBWD_BLOCK(1);
     for (int r = 0; r < rounds2; ++r) {
       const char* const base = lds + (r & 1) * BUFB;
       const int64_t ps = phys(slab_of(r));
@@ -383,6 +385,7 @@ layer_bwd_spec_kernel(int64_t M, const float* __restrict__ g, const float* __res
       LBWD_STAMP(0, r, 4);
     }
     LBWD_STAMP(0, 63, 2);
+    LBWD_BLOCK(2);
     if (SIG) {       // column sums of G_src and G_src z_src: one wave owns a column tile
       const float s = csum + __shfl_xor(csum, 32);
       const float q = csz + __shfl_xor(csz, 32);
@@ -404,6 +407,7 @@ layer_bwd_spec_kernel(int64_t M, const float* __restrict__ g, const float* __res
   __syncthreads();
   for (int n = threadIdx.x; n < 128; n += LWG) wout[128 * 128 + n] = (s_red[n] + s_red[128 + n]) + (s_red[256 + n] + s_red[384 + n]);
   LBWD_STAMP(0, 63, 3); LBWD_STAMP(1, 63, 3);
+  LBWD_BLOCK(3);
 }
 
 }  // namespace
@@ -416,6 +420,7 @@ extern "C" {
 
 #ifdef GANET_LBWD_TRACE
 int ganet_dev_lbwd_trace(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lbwd_trace), sizeof(g_lbwd_trace)); }
+int ganet_dev_lbwd_blocks(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lbwd_blocks), sizeof(g_lbwd_blocks)); }
 #endif
 int32_t ganet_mlp_bwd_fused_parts(void) { return LBLOCKS; }
 
@@ -471,9 +476,9 @@ int ganet_mlp_bwd_fused(int64_t M, const float* g, const float* gz, const float*
                         size_t workspace_bytes, int32_t row_order, void* stream_) {
   if (M <= 0 || (M % LSLAB) || !g || !gz || !gcoef || !W || ldw < 128 || !out || !src_z || !src_scale ||
       !src_shift || (apply_act && !col_part) || !wgrad_workspace || !aligned16(g) || !aligned16(gz) ||
-      !aligned16(src_z)) {
+      !aligned16(src_z) || !aligned16(gcoef) || !aligned16(src_scale) || !aligned16(src_shift)) {
     set_error("ganet_mlp_bwd_fused: invalid arguments (M must be a multiple of %d, activations [M,128] contiguous "
-              "and 16-byte aligned, W [128, >=128] with row stride ldw)", LSLAB);
+              "and 16-byte aligned like the coefficient vectors, W [128, >=128] with row stride ldw)", LSLAB);
     return 1;
   }
   return layer_bwd_launch(M, 128, g, gz, gcoef, W, ldw, 128, out, accumulate, src_z, src_scale, src_shift, apply_act,
@@ -484,7 +489,8 @@ int ganet_mlp_bwd_fused_input(int64_t M, const float* g, const float* gz, const 
                               int64_t ldw, int32_t O, float* out, int64_t ldo, int32_t accumulate, const float* x,
                               void* wgrad_workspace, size_t workspace_bytes, int32_t row_order, void* stream_) {
   if (M <= 0 || (M % LSLAB) || !g || !gz || !gcoef || !W || O <= 0 || O > 72 || ldw < O || !out || ldo != 72 ||
-      !x || !wgrad_workspace || !aligned16(g) || !aligned16(gz) || !aligned16(x) || !aligned16(out)) {
+      !x || !wgrad_workspace || !aligned16(g) || !aligned16(gz) || !aligned16(x) || !aligned16(out) ||
+      !aligned16(gcoef)) {
     set_error("ganet_mlp_bwd_fused_input: invalid arguments (M a multiple of %d; g, gz [M,128]; x and out [M,72] contiguous, "
               "all 16-byte aligned; W [128, >= O], O <= 72)", LSLAB);
     return 1;

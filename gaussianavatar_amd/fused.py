@@ -664,15 +664,14 @@ class _DecoderFn(torch.autograd.Function):
             bn = getattr(dec, layers[i][1])
             return bn.running_mean if (training and bn.track_running_stats) else None
 
-        def bn_stats(i, z):
+        def bn_stats(i, cp):
+            """statistics of layer i from its column-sum partials `cp` (already summed over the ranks when sync)"""
             bn = getattr(dec, layers[i][1])
             if training:
                 mean, rstd, sc, sh = (torch.empty(128, dtype=torch.float32, device=dev) for _ in range(4))
                 track = bn.track_running_stats
-                if sync:
-                    _allreduce_partials(col_part, 256)
                 _native.ganet_check(lib.ganet_mlp_stats(
-                    Mg, 128, _ptr(col_part), _ptr(gammas[i]), _ptr(betas[i]), float(bn.eps), _ptr(mean), _ptr(rstd),
+                    Mg, 128, _ptr(cp), _ptr(gammas[i]), _ptr(betas[i]), float(bn.eps), _ptr(mean), _ptr(rstd),
                     _ptr(sc), _ptr(sh), _ptr(bn.running_mean if track else None),
                     _ptr(bn.running_var if track else None), float(bn.momentum),
                     _ptr(bn.num_batches_tracked if track else None), _ptr(stat_shift_of(i)), _stream(dev)))
@@ -683,14 +682,33 @@ class _DecoderFn(torch.autograd.Function):
                 sh = (betas[i] - mean * sc).contiguous()
             return mean, rstd, sc, sh
 
+        # column-sum partials: one buffer per layer of a LEVEL (the three heads' conv6 / conv7 are independent of
+        # each other): with synchronised statistics a level's layers share ONE all-reduce (11 -> 7 messages per pass)
+        col_parts = [col_part] + ([torch.empty_like(col_part) for _ in range(2)] if (training and sync) else [])
+
+        def hidden_level(items):
+            """items: [(layer i, x1, W, src)], layers that do not depend on each other: z = [x1 | act(src)] W^T + b for
+            each, then their BatchNorm statistics (column sums all-reduced in one message when sync)."""
+            cps = []
+            for k, (i, x1, W, src) in enumerate(items):
+                x2 = sc = sh = None
+                if src is not None:
+                    x2, (_, _, sc, sh) = zs[src], stats[src]
+                cp = col_parts[k] if (training and sync) else col_part
+                while len(zs) <= i:
+                    zs.append(None)
+                    stats.append(None)
+                zs[i] = _mlp_fwd(lib, M, 128, x1, x2, sc, sh, W, conv_b[i], cp, dev, sweep.next(), stat_shift_of(i))
+                cps.append(cp)
+                if not (training and sync):
+                    stats[i] = bn_stats(i, cp)
+            if training and sync:
+                _allreduce_partials(cps, 256)
+                for (i, _x1, _W, _src), cp in zip(items, cps):
+                    stats[i] = bn_stats(i, cp)
+
         def hidden(i, x1, W, src):
-            """layer i: z = [x1 | act(src)] W^T + b, then its BatchNorm statistics."""
-            x2 = sc = sh = None
-            if src is not None:
-                x2, (_, _, sc, sh) = zs[src], stats[src]
-            z = _mlp_fwd(lib, M, 128, x1, x2, sc, sh, W, conv_b[i], col_part, dev, sweep.next(), stat_shift_of(i))
-            zs.append(z)
-            stats.append(bn_stats(i, z))
+            hidden_level([(i, x1, W, src)])
 
         w1p = pad_w(conv_w[0])
         hidden(0, xp, w1p, None)
@@ -700,10 +718,14 @@ class _DecoderFn(torch.autograd.Function):
         w5p = torch.cat([pad_w(w5[:, :cin]), w5[:, cin:]], 1).contiguous()      # [128, 72 + 128]
         hidden(4, xp, w5p, 3)
         outs = []
+        if training and sync:      # the three heads level by level: one statistics message per level
+            hidden_level([(5 + 2 * j, None, conv_w[5 + 2 * j].contiguous(), 4) for j in range(3)])
+            hidden_level([(6 + 2 * j, None, conv_w[6 + 2 * j].contiguous(), 5 + 2 * j) for j in range(3)])
         for j in range(3):
             i6, i7 = 5 + 2 * j, 6 + 2 * j
-            hidden(i6, None, conv_w[i6].contiguous(), 4)
-            hidden(i7, None, conv_w[i7].contiguous(), i6)
+            if not (training and sync):
+                hidden(i6, None, conv_w[i6].contiguous(), 4)
+                hidden(i7, None, conv_w[i7].contiguous(), i6)
             _, _, sc, sh = stats[i7]
             outs.append(_mlp_fwd(lib, M, out_w[j].shape[0], None, zs[i7], sc, sh, out_w[j].contiguous(),
                                  out_b[j], None, dev, sweep.next()))
@@ -723,11 +745,10 @@ class _DecoderFn(torch.autograd.Function):
         lib = _native.ganet()
         nl, cin = ctx.nl, ctx.cin
         sv = ctx.saved_tensors
-        if ctx.native and all(d is not None for d in d_outs):
-            return _DecoderFn._backward_native(ctx, lib, sv, d_outs)
         if ctx.native:
-            raise RuntimeError("fused decoder: every head needs a gradient on the one-call path "
-                               "(set fused._NATIVE_DECODER = False for partial objectives)")
+            # the one-call path back-propagates all three heads; a head the objective does not use (autograd.grad on
+            # a partial objective, set_materialize_grads(False)) contributes a zero gradient
+            return _DecoderFn._backward_native(ctx, lib, sv, d_outs)
         xp = sv[0]
         zs = sv[1:1 + nl]
         fs = sv[1 + nl:1 + 5 * nl]
@@ -783,13 +804,15 @@ class _DecoderFn(torch.autograd.Function):
             njobs[0] = j + 1
             return dW, db          # filled by the batched reduction at the end of backward
 
-        def finish(i, nparts):
-            """column sums of (G_i, G_i z_i) -> coefficients of layer i, d gamma_i, d beta_i."""
+        def finish(i, nparts, cp=None, reduced=False):
+            """column sums of (G_i, G_i z_i) (partials `cp`, default col_part) -> coefficients of layer i, d gamma_i,
+            d beta_i. reduced: the partials were already summed over the ranks (level-batched all-reduce)."""
+            cp = col_part if cp is None else cp
             mean, rstd, sc, _ = stats[i]
             coef, dg, dbt = f32(3 * 128), f32(128), f32(128)
-            if ctx.sync:
-                _allreduce_partials(col_part[:nparts * 256], 256)
-            _native.ganet_check(lib.ganet_mlp_bwd_stats(ctx.Mg, nparts, _ptr(col_part), _ptr(mean), _ptr(rstd), _ptr(sc),
+            if ctx.sync and not reduced:
+                _allreduce_partials([cp[:nparts * 256]], 256)
+            _native.ganet_check(lib.ganet_mlp_bwd_stats(ctx.Mg, nparts, _ptr(cp), _ptr(mean), _ptr(rstd), _ptr(sc),
                                                         _ptr(coef), _ptr(dg), _ptr(dbt), st))
             if ctx.sync:
                 # d gamma / d beta come out of the GLOBAL sums, i.e. complete on every rank, while the other
@@ -798,33 +821,35 @@ class _DecoderFn(torch.autograd.Function):
                 dg, dbt = dg / parallel.world_size(), dbt / parallel.world_size()
             coefs[i], g_gamma[i], g_beta[i] = coef, dg, dbt
 
-        def data_grad(gi, W, out, accumulate, src):
+        def data_grad(gi, W, out, accumulate, src, cp=None):
             """out[:, :O] (+)= dz_gi . W (W [128, O], possibly a column slice of a wider weight); with
-            src: out = G_src (and its column sums in col_part)."""
+            src: out = G_src (and its column sums in cp, default col_part)."""
+            cp = col_part if cp is None else cp
             O = W.shape[1]
             sz = None if src is None else zs[src]
             sc, sh = (None, None) if src is None else stats[src][2:]
             _native.ganet_check(lib.ganet_mlp_bwd_data(
                 M, O, _ptr(Gs[gi]), Gs[gi].stride(0), _ptr(zs[gi]), zs[gi].stride(0), _ptr(coefs[gi]), _ptr(W),
                 W.stride(0), _ptr(out), out.stride(0), int(accumulate), _ptr(sz), 0 if sz is None else sz.stride(0),
-                _ptr(sc), _ptr(sh), _ptr(col_part) if src is not None else None, sweep.next(), st))
+                _ptr(sc), _ptr(sh), _ptr(cp) if src is not None else None, sweep.next(), st))
 
         fuse_ok = _FUSED_BWD and M % 32 == 0 and wg_bytes >= lib.ganet_mlp_bwd_fused_workspace()
         n_fused = lib.ganet_mlp_bwd_fused_parts()
         if fuse_ok and n_fused * 256 > col_part.numel():
             col_part = torch.empty(n_fused * 256, dtype=torch.float32, device=dev)
 
-        def layer_bwd(i, src, W=None, out=None, accumulate=False, act=True):
+        def layer_bwd(i, src, W=None, out=None, accumulate=False, act=True, cp=None):
             """hidden layer i (input = act(bn(zs[src])) times W [128 out, 128 in], default conv_w[i]): d weight,
-            d bias, and out (+)= dz_i . W — with act: out = G of the source layer, its column sums in col_part.
+            d bias, and out (+)= dz_i . W — with act: out = G of the source layer, its column sums in cp (col_part).
             One pass over the activations when the fused kernel applies, else weight gradient + data gradient.
             Returns (dW, db, number of col_part rows)."""
             W = conv_w[i] if W is None else W
+            cp = col_part if cp is None else cp
             if out is None:
                 out = Gs[src] = f32(M, 128)
             if not fuse_ok:
                 dW, db = wgrad(None, i, src)
-                data_grad(i, W, out, accumulate, src if act else None)
+                data_grad(i, W, out, accumulate, src if act else None, cp)
                 return dW, db, n_data
             dW, db = f32(128, 128), f32(128)
             j = njobs[0]
@@ -832,7 +857,7 @@ class _DecoderFn(torch.autograd.Function):
             assert W.stride(1) == 1
             _native.ganet_check(lib.ganet_mlp_bwd_fused(
                 M, _ptr(Gs[i]), _ptr(zs[i]), _ptr(coefs[i]), _ptr(W), W.stride(0), _ptr(out), int(accumulate),
-                _ptr(zs[src]), _ptr(stats[src][2]), _ptr(stats[src][3]), int(act), _ptr(col_part), ws, wg_bytes,
+                _ptr(zs[src]), _ptr(stats[src][2]), _ptr(stats[src][3]), int(act), _ptr(cp), ws, wg_bytes,
                 sweep.next(), st))
             jobs[j].workspace, jobs[j].M, jobs[j].N, jobs[j].K = ws, M, 128, 128
             jobs[j].dW, jobs[j].db, jobs[j].nblocks = dW.data_ptr(), db.data_ptr(), n_fused
@@ -842,27 +867,58 @@ class _DecoderFn(torch.autograd.Function):
         Gs, coefs = [None] * nl, [None] * nl
         heads = [j for j in range(3) if d_outs[j] is not None]
         G5 = f32(M, 128) if heads else None
-        for pos, j in enumerate(heads):
-            i6, i7 = 5 + 2 * j, 6 + 2 * j
+        # With synchronised statistics the heads run level by level, so that a level's column sums travel in ONE
+        # all-reduce (22 -> 14 messages per iteration together with the forward pass); without, head after head.
+        level_order = ctx.sync and len(heads) > 1
+        cps = [col_part] + ([torch.empty_like(col_part) for _ in range(len(heads) - 1)] if level_order else [])
+        cp_of = (lambda pos: cps[pos]) if level_order else (lambda pos: col_part)
+
+        def head_level(pos, j):          # conv8 of head j: G_7 and its column sums
+            i7 = 6 + 2 * j
             g = d_outs[j].contiguous()
             N8 = g.shape[1]
             Gs[i7] = f32(M, 128)
             _, _, sc7, sh7 = stats[i7]
             dW, db = wgrad(g, None, i7)
-            ws = None
             g_out_w[j], g_out_b[j] = dW.unsqueeze(-1), db
             _native.ganet_check(lib.ganet_mlp_head_bwd(M, N8, _ptr(g), _ptr(out_w[j].contiguous()), _ptr(zs[i7]),
                                                        zs[i7].stride(0), _ptr(sc7), _ptr(sh7), _ptr(Gs[i7]),
-                                                       Gs[i7].stride(0), _ptr(col_part), ws, st))
-            finish(i7, n_head)
-            dW, db, nparts = layer_bwd(i7, i6)
+                                                       Gs[i7].stride(0), _ptr(cp_of(pos)), None, st))
+
+        def conv7_level(pos, j):         # conv7 of head j: G_6 and its column sums; returns the partial-row count
+            i6, i7 = 5 + 2 * j, 6 + 2 * j
+            dW, db, nparts = layer_bwd(i7, i6, cp=cp_of(pos))
             g_conv_w[i7], g_conv_b[i7] = dW.unsqueeze(-1), db
             Gs[i7] = None
-            finish(i6, nparts)
+            return nparts
+
+        def conv6_level(pos, j):         # conv6 of head j into G_5 (accumulating; the last one applies softplus')
+            i6 = 5 + 2 * j
             last = pos == len(heads) - 1
             dW, db, nparts5 = layer_bwd(i6, 4, out=G5, accumulate=pos > 0, act=last)
             g_conv_w[i6], g_conv_b[i6] = dW.unsqueeze(-1), db
             Gs[i6] = None
+            return nparts5
+
+        if level_order:
+            for pos, j in enumerate(heads):
+                head_level(pos, j)
+            _allreduce_partials([cps[pos][:n_head * 256] for pos in range(len(heads))], 256)
+            for pos, j in enumerate(heads):
+                finish(6 + 2 * j, n_head, cps[pos], reduced=True)
+            nps = [conv7_level(pos, j) for pos, j in enumerate(heads)]
+            _allreduce_partials([cps[pos][:nps[pos] * 256] for pos in range(len(heads))], 256)
+            for pos, j in enumerate(heads):
+                finish(5 + 2 * j, nps[pos], cps[pos], reduced=True)
+            for pos, j in enumerate(heads):
+                nparts5 = conv6_level(pos, j)
+        else:
+            for pos, j in enumerate(heads):
+                head_level(pos, j)
+                finish(6 + 2 * j, n_head)
+                nparts = conv7_level(pos, j)
+                finish(5 + 2 * j, nparts)
+                nparts5 = conv6_level(pos, j)
         dx = None
         if heads:
             Gs[4] = G5
@@ -925,7 +981,9 @@ def _decoder_bwd_native(ctx, lib, sv, d_outs):
         # [M, x_cols]: the pad columns of a zero-padded input belong to a constant and stay unwritten
         dx = torch.empty((M, ctx.x_cols), dtype=torch.float32, device=dev)
         G.dx, G.x_cols = dx.data_ptr(), ctx.x_cols
-    douts = [d.contiguous() for d in d_outs]
+    widths = [int(p.shape[0]) for p in params[4 * nl::2]]          # conv8 / conv8N / conv8SH: 3, 1, 3 columns
+    douts = [d.contiguous() if d is not None else torch.zeros((M, w), dtype=torch.float32, device=dev)
+             for d, w in zip(d_outs, widths)]
     dptrs = (ctypes.c_void_p * 3)(*[d.data_ptr() for d in douts])
     wsb = lib.ganet_decoder_bwd_workspace(M)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
@@ -940,15 +998,20 @@ def _decoder_bwd_native(ctx, lib, sv, d_outs):
 _DecoderFn._backward_native = staticmethod(_decoder_bwd_native)
 
 
-def _allreduce_partials(col_part: torch.Tensor, width: int) -> None:
-    """Per-workgroup partial column sums [nparts, width] -> the same buffer holding the sums over ALL ranks'
-    partials in its first row and zeros elsewhere (the statistics kernels add the rows up). The local
-    reduction and the all-reduce run in float64."""
-    part = col_part.view(-1, width)
-    tot = part.double().sum(0)
+def _allreduce_partials(col_parts, width: int) -> None:
+    """col_parts: list of per-workgroup partial column sums [nparts_k, width] (layers of one level) -> every buffer
+    holds the sums over ALL ranks' partials in its first row and zeros elsewhere (the statistics kernels add the rows
+    up). ONE all-reduce for the whole list; the local reductions and the all-reduce run in float64."""
+    parts = [cp.view(-1, width) for cp in col_parts]
+    if len({p.shape for p in parts}) == 1:
+        tot = torch.stack(parts).double().sum(1)                 # [k, width] in one reduction launch
+    else:
+        tot = torch.stack([p.double().sum(0) for p in parts])
     parallel.all_reduce_sum_(tot)
-    part.zero_()
-    part[0] = tot.float()
+    totf = tot.float()
+    for k, p in enumerate(parts):
+        p.zero_()
+        p[0] = totf[k]
 
 
 def decoder_mlp(dec, x, m_global=None):

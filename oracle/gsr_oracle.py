@@ -21,7 +21,7 @@ _BUILD = os.path.join(_HERE, "_build")
 
 def build(force: bool = False) -> None:
     """Compile the oracle with gcc (a few hundred ms)."""
-    outs = [os.path.join(_BUILD, f"libgsr_oracle_{p}.so") for p in ("f32", "f64")]
+    outs = [os.path.join(_BUILD, f"libgsr_oracle_{p}.so") for p in ("f32", "f64", "f32_fma")]
     src = os.path.join(_HERE, "gsr_oracle.c")
     fresh = all(os.path.exists(o) and os.path.getmtime(o) >= os.path.getmtime(src) for o in outs)
     if fresh and not force:
@@ -54,9 +54,12 @@ class RasterOracle:
     """CPU restatement of the rasterizer forward/backward. `f64=True` selects the double
     build (gradient reference); the default float build fixes the integer outputs."""
 
-    def __init__(self, f64: bool = False):
+    def __init__(self, f64: bool = False, fma: bool = False):
+        """fma=True (float32 only): the build with FMA contraction allowed (-ffp-contract=fast -mfma), for the
+        contraction-sensitivity measurement; every parity test uses the contraction-off builds."""
         build()
-        name = "libgsr_oracle_f64.so" if f64 else "libgsr_oracle_f32.so"
+        assert not (f64 and fma)
+        name = "libgsr_oracle_f64.so" if f64 else ("libgsr_oracle_f32_fma.so" if fma else "libgsr_oracle_f32.so")
         self.lib = ctypes.CDLL(os.path.join(_BUILD, name))
         self.dtype = np.float64 if f64 else np.float32
         self.creal = ctypes.c_double if f64 else ctypes.c_float

@@ -270,3 +270,29 @@ def check_net_full(device, tol_out=2e-5, tol_grad=2e-4):
 
 def test_production_width_nets_match_reference_outputs_and_grads():
     check_net_full("cpu")
+
+
+@pytest.mark.parametrize("kind", ["avatar", "general"])
+def test_fma_contraction_sensitivity(kind):
+    """What "bit-exact against upstream" can mean. The un-vendored upstream is built by nvcc with FMA contraction
+    on (-fmad=true); this repository's oracle and its HIP preprocess kernel are built with contraction OFF so that
+    both follow one operation order. The measurable bound on the difference: build the SAME oracle source with
+    contraction allowed (oracle/Makefile: -ffp-contract=fast -mfma, 185 fused instructions) and count the integer
+    decisions that change at the headline size — radii (ceil of 3 sigma), tile rectangles ((int) casts), and with
+    them tiles_touched and the pair count D. Measured in round 4: 0 of 200,000 Gaussians in both scenes, image mean
+    |diff| 5e-7. The bars below leave room for a handful of flips on another compiler (a flip moves one Gaussian's
+    radius by one pixel); DESIGN.md section 2 records the measured numbers."""
+    from oracle.gsr_oracle import RasterOracle
+    sc = random_scene(200_000, 1024, 1024, seed=1, kind=kind, scale_med=0.0035, spread=0.45)
+    args = (sc["means3D"], sc["colors"], sc["opacities"], sc["scales"], sc["rotations"])
+    off = RasterOracle().forward(*args, **cam_kwargs(sc))
+    on = RasterOracle(fma=True).forward(*args, **cam_kwargs(sc))
+    radii = int((off["radii"] != on["radii"]).sum())
+    rect = int((off["rect"] != on["rect"]).any(1).sum())
+    print(f"\n{kind}: radii differing {radii}, rects {rect} of 200000; D {off['D']} vs {on['D']}; "
+          f"image mean |diff| {np.abs(off['color'] - on['color']).mean():.2e}")
+    assert radii <= 5 and rect <= 5
+    assert abs(int(off["D"]) - int(on["D"])) <= 16
+    assert np.abs(off["color"] - on["color"]).mean() <= 1e-5
+    if radii == 0 and rect == 0:
+        np.testing.assert_array_equal(off["point_list"], on["point_list"])      # then the sorted tile lists agree too

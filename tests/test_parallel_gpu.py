@@ -73,15 +73,17 @@ def _iterate(m, op, frames, steps=2, stage=1):
     return out
 
 
-def _worker(rank, world, port, ret, mode, stage=1):
+def _worker(rank, world, port, ret, mode, stage=1, backend="gloo"):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port))
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     from gaussianavatar_amd import parallel
     if mode:
         parallel.set_mode(mode)
-    parallel.init_from_env(backend="gloo")          # both ranks share GPU 0: gloo carries the collectives
-    torch.cuda.set_device(0)
+    # gloo: both ranks share GPU 0 and gloo carries the collectives; nccl (tests/test_parallel_nccl_gpu.py): one GPU
+    # per rank over RCCL, the production setup
+    parallel.init_from_env(backend=backend)
+    torch.cuda.set_device(rank if backend == "nccl" else 0)
     torch.manual_seed(1000 + rank)                 # replicas start DIFFERENT: sync_replicas must fix that
     m, op = _build(2, stage)
     res = _iterate(m, op, FRAMES[2 * rank:2 * rank + 2], stage=stage)

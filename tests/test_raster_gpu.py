@@ -11,8 +11,20 @@ from tests.scenes import cam_kwargs, random_scene
 pytestmark = pytest.mark.gpu
 
 IMG_L1_TOL = 1e-4          # mean |diff| per pixel-channel (north_star tolerance)
-IMG_MAX_TOL = 2e-2         # one borderline alpha<1/255 decision may flip a pixel by ~T/255
+IMG_MAX_TOL = 2.0 / 255    # a borderline alpha < 1/255 decision moves a pixel by at most T/255; two of them in one pixel
+IMG_ROUND_TOL = 1e-5       # what pure rounding (different association of the same blends) may move a pixel by
 GRAD_REL_TOL = 2e-3        # relative to the largest |gradient| of that tensor
+
+_oracle64 = []
+
+
+def oracle64():
+    """The float64 build of the oracle: the yardstick for how many per-pixel decisions of a scene are float32 coin
+    tosses (the bars of assert_forward_parity are derived from its disagreement with the float32 oracle)."""
+    if not _oracle64:
+        from oracle.gsr_oracle import RasterOracle
+        _oracle64.append(RasterOracle(f64=True))
+    return _oracle64[0]
 
 
 def oracle_forward(oracle, sc):
@@ -39,8 +51,17 @@ def assert_forward_parity(oracle, sc, max_pairs=None):
     diff = np.abs(got["color"] - ref["color"])
     assert diff.mean() <= IMG_L1_TOL, diff.mean()
     assert diff.max() <= IMG_MAX_TOL, diff.max()
-    mism = (got["n_contrib"].astype(np.int64) != ref["n_contrib"].astype(np.int64)).mean()
-    assert mism <= 2e-3, mism
+    # How many pixels may differ by more than rounding, and how many n_contrib values may differ at all, is not a
+    # constant: it is the number of per-pixel decisions (alpha < 1/255, T < 1e-4) that are float32 coin tosses in THIS
+    # scene — measured as the disagreement of the float32 oracle with the float64 one. The HIP kernels evaluate
+    # transmittance as a prefix-product tree, i.e. a third rounding of the same numbers: allowed twice that count.
+    ref64 = oracle_forward(oracle64(), sc)
+    toss_img = int((np.abs(ref["color"].astype(np.float64) - ref64["color"]) > IMG_ROUND_TOL).any(0).sum())
+    toss_n = int((ref["n_contrib"].astype(np.int64) != ref64["n_contrib"].astype(np.int64)).sum())
+    off_img = int((diff > IMG_ROUND_TOL).any(0).sum())
+    off_n = int((got["n_contrib"].astype(np.int64) != ref["n_contrib"].astype(np.int64)).sum())
+    assert off_img <= 2 * toss_img + 4, (off_img, toss_img)
+    assert off_n <= 2 * toss_n + 4, (off_n, toss_n)
     return ref, got
 
 

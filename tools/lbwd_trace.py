@@ -35,3 +35,11 @@ print("first rounds, producer stamps relative:", (p[:6, :7] - c[0, 0]).tolist())
 print("whole kernel, consumer: prologue %d  loop %d  tail %d | producer: prologue %d loop %d tail %d" % (
     c[63, 1] - c[63, 0], c[63, 2] - c[63, 1], c[63, 3] - c[63, 2], p[63, 1] - p[63, 0], p[63, 2] - p[63, 1], p[63, 3] - p[63, 2]))
 print("rounds (consumer, start to start):", (c[1:32, 0] - c[0:31, 0]).tolist())
+bl = np.zeros((256, 4), dtype=np.uint64)
+lib.ganet_dev_lbwd_blocks.argtypes = [ctypes.c_void_p]
+assert lib.ganet_dev_lbwd_blocks(bl.ctypes.data) == 0
+b = bl.astype(np.int64); t0 = b[:, 0].min(); u = (b - t0) / 100.0
+print("workgroups (us): start max %.1f | prologue median %.1f max %.1f | loop median %.1f min %.1f max %.1f | loop end: min %.1f median %.1f max %.1f | end max %.1f" % (
+    u[:, 0].max(), np.median(u[:, 1] - u[:, 0]), (u[:, 1] - u[:, 0]).max(), np.median(u[:, 2] - u[:, 1]), (u[:, 2] - u[:, 1]).min(),
+    (u[:, 2] - u[:, 1]).max(), u[:, 2].min(), np.median(u[:, 2]), u[:, 2].max(), u[:, 3].max()))
+print("loop time by XCD (block %% 8):", [round(float(np.median((u[:, 2] - u[:, 1])[x::8])), 1) for x in range(8)])
