@@ -23,6 +23,7 @@ Rodrigues call — restated below).
 """
 from __future__ import annotations
 
+import collections
 import os
 import pickle
 from os.path import join
@@ -229,6 +230,12 @@ class _MonoBase(Dataset):
 
     with_images = True
     with_pose = False          # items carry pose_data / transl_data (all but the training set)
+    # Training-loader fast path (AvatarModel.getTrainDataloader sets it): `original_image` leaves the worker as the
+    # composited uint8 [3,H,W] — a quarter of the bytes through shared memory, pinning and PCIe — and becomes the
+    # reference's float image / 255 on the device (avatar_model._DeviceLoader). Items read directly keep the
+    # reference's format (float [3,H,W] in [0,1]).
+    raw_uint8 = False
+    CACHE_MB = 1024            # decoded (mask-composited) uint8 frames kept per process, least recently used first out
 
     def __init__(self, dataset_parms, folder, device=torch.device("cuda:0"), predicted_poses=None):
         super().__init__()
@@ -275,9 +282,16 @@ class _MonoBase(Dataset):
         cam = np.load(join(self.data_folder, "cam_parms", name_idx + ".npz"))
         return np.asarray(cam["extrinsic"], np.float32), np.asarray(cam["intrinsic"], np.float32).reshape(3, 3)
 
-    def _image(self, name_idx):
-        """RGB in [0,1] as [3,H,W]; background set to white through the mask
-        (dataset_mono.py:208-233: mask < 128 -> 0, else 1; image*mask + (1-mask)*255)."""
+    def _image_u8(self, name_idx):
+        """The frame as uint8 [H,W,C], background set to white through the mask (dataset_mono.py:208-233: mask < 128
+        -> 0, else 1; image*mask + (1-mask)*255). Decoding a 1024^2 PNG pair costs ~10-20 ms of a worker's time — more
+        than a whole training iteration on the GPU — so decoded frames are kept (per process, CACHE_MB, LRU): the
+        reference decodes every frame again in every epoch."""
+        cache = self.__dict__.setdefault("_frames", collections.OrderedDict())
+        hit = cache.get(name_idx)
+        if hit is not None:
+            cache.move_to_end(name_idx)
+            return hit
         from PIL import Image
         image = np.array(Image.open(join(self.data_folder, "images", name_idx + "." + self.image_fix)))
         if not self.no_mask:
@@ -286,9 +300,24 @@ class _MonoBase(Dataset):
                 mask = mask[..., None]
             fg = mask >= 128
             image = np.where(fg, image if image.ndim == 3 else image[..., None], 255).astype(np.uint8)
+        if image.ndim < 3:
+            image = image[..., None]
+        budget = int(getattr(self.dataset_parms, "cache_mb", self.CACHE_MB)) << 20
+        if image.nbytes <= budget:
+            cache[name_idx] = image
+            self._frames_bytes = self.__dict__.get("_frames_bytes", 0) + image.nbytes
+            while self._frames_bytes > budget:
+                _, old = cache.popitem(last=False)
+                self._frames_bytes -= old.nbytes
+        return image
+
+    def _image(self, name_idx):
+        """RGB in [0,1] as [3,H,W] float (raw_uint8: the same pixels as uint8 [3,H,W], divided by 255 on the device)."""
+        image = self._image_u8(name_idx)
+        if self.raw_uint8:
+            return torch.from_numpy(np.ascontiguousarray(image.transpose(2, 0, 1)))
         t = torch.from_numpy(image) / 255.0
-        t = t.permute(2, 0, 1) if t.dim() == 3 else t.unsqueeze(-1).permute(2, 0, 1)
-        return t.clamp(0.0, 1.0)
+        return t.permute(2, 0, 1).clamp(0.0, 1.0)
 
     def _inp_posmap(self, pose_idx):
         S = self.dataset_parms.inp_posmap_size

@@ -135,3 +135,59 @@ def test_model_from_disk_equals_model_from_memory(tmp_path, stage):
         assert batch["inp_pos_map"].shape == (2, 3, 16, 16) and batch["inp_pos_map"].dtype == torch.float32
     for getter in (m_disk.getTestDataset, m_disk.getNovelposeDataset):
         assert "pose_data" in getter()[0]
+
+
+def test_frame_cache_and_uint8_transfer_path(tmp_path):
+    """The training loader's fast path: frames leave the reader as the composited uint8 [3,H,W] and become the
+    reference's float image on the consumer's side (/ 255, avatar_model._DeviceLoader) — bit-identical to the float
+    item; decoded frames are cached per process within a byte budget (least recently used out)."""
+    _assets, _frames, paths = dataset_fixture(str(tmp_path), "smpl")
+    p = _parms(paths, "smpl", 1)
+    ds = D.MonoDataset_train(p)
+    ref = [ds[i]["original_image"] for i in range(len(ds))]
+    assert ref[0].dtype == torch.float32 and len(ds._frames) == len(ds)          # all four frames cached
+    again = ds[1]["original_image"]
+    assert torch.equal(again, ref[1])
+    ds.raw_uint8 = True
+    for i in range(len(ds)):
+        u = ds[i]["original_image"]
+        assert u.dtype == torch.uint8 and u.shape == ref[i].shape and u.is_contiguous()
+        assert torch.equal(u.float().div_(255.0), ref[i])
+    # a budget of one frame: the cache never holds more
+    p2 = _parms(paths, "smpl", 1)
+    p2.cache_mb = 0
+    ds2 = D.MonoDataset_train(p2)
+    for i in range(len(ds2)):
+        assert torch.equal(ds2[i]["original_image"], ref[i])
+    assert len(ds2.__dict__.get("_frames", {})) == 0
+
+
+def test_training_loader_serves_later_epochs_from_the_resident_cache(tmp_path):
+    """The first epoch streams through the DataLoader and leaves every sample on the device; the following epochs
+    are assembled from that cache with the DataLoader's own batch sampler. Every batch of every epoch must hold
+    exactly the dataset's items for its pose_idx (image = float / 255 of the composited frame); a budget the
+    dataset does not fit keeps streaming."""
+    _assets, _frames, paths = dataset_fixture(str(tmp_path), "smpl")
+    m = AvatarModel(*default_params(train_stage=1, query_posmap_size=32, inp_posmap_size=16, **paths), device="cpu")
+    plain = D.MonoDataset_train(m.model_parms)                 # float items, the reference's format
+    loader = m.getTrainDataloader()
+    seen = []
+    for epoch in range(3):
+        n = 0
+        for batch in loader:
+            assert batch["original_image"].dtype == torch.float32 and batch["original_image"].shape == (2, 3, 48, 64)
+            for b, i in enumerate(batch["pose_idx"].tolist()):
+                ref = plain[i]
+                assert torch.equal(batch["original_image"][b], ref["original_image"])
+                assert torch.equal(batch["full_proj_transform"][b], ref["full_proj_transform"])
+                assert batch["FovX"][b] == ref["FovX"] and batch["width"][b] == ref["width"]
+                seen.append(i)
+            n += 1
+        assert n == len(loader) == 2
+        assert len(loader.samples) == 4 and not loader.streaming   # all four frames resident after the first epoch
+    assert sorted(seen) == sorted(list(range(4)) * 3)
+    from gaussianavatar_amd.avatar_model import _DeviceLoader
+    small = _DeviceLoader(loader.loader, "cpu", budget_gb=1e-5)
+    for _ in range(2):
+        assert sum(1 for _b in small) == 2
+    assert small.streaming and not small.samples

@@ -16,7 +16,13 @@ batches = [collate_frames([ds[(s * B + k) % len(ds)] for k in range(B)], dev) fo
 gt = torch.ones(B, 3, 1024, 1024, device=dev)
 
 
+SYNC = os.environ.get("SYNC", "0") == "1"      # drain the GPU before every iteration: pure enqueue time per section,
+                                                # i.e. what a loop with a per-iteration .item() (the reference's train.py:101) pays
+
+
 def step(i, marks=None):
+    if SYNC:
+        torch.cuda.synchronize()
     t = [time.perf_counter()]
     image, points, offset_loss, geo_loss, scale_loss = model.train_stage1(batches[i % 8], 7)
     t.append(time.perf_counter())
@@ -29,6 +35,9 @@ def step(i, marks=None):
     t.append(time.perf_counter())
     model.step(1)
     t.append(time.perf_counter())
+    if SYNC:
+        torch.cuda.synchronize()
+        t.append(time.perf_counter())
     if marks is not None:
         marks.append([1e3 * (b - a) for a, b in zip(t, t[1:])])
 
@@ -45,7 +54,7 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 import statistics
-names = ["forward", "loss", "backward", "optimizer"]
+names = ["forward", "loss", "backward", "optimizer"] + (["drain (GPU tail after the last enqueue)"] if SYNC else [])
 print("wall per iteration %.3f ms; CPU in the loop %.3f ms; final drain %.3f ms" % (1e3 * (t2 - t0) / N, 1e3 * (t1 - t0) / N, 1e3 * (t2 - t1)))
 for j, n in enumerate(names):
     print("  CPU %-10s median %.3f ms" % (n, statistics.median(m[j] for m in marks)))
