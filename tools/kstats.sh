@@ -2,7 +2,7 @@
 # rocprofv3 --kernel-trace --stats of the bench command -> per-kernel table (stdout); usage: tools/kstats.sh [filter words...]
 R=$PWD; cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/prof_ks
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -o p -- python $R/bench.py --steps 25 --warmup 10 --no-cpu-baseline --no-kernel-events --no-fixed-batch > /tmp/prof_ks.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -o p -- python $R/bench.py --steps 25 --warmup 10 --no-cpu-baseline --no-kernel-events --no-fixed-batch --no-secondary > /tmp/prof_ks.log 2>&1
 f=$(find /tmp/prof_ks -name "*kernel_stats.csv" | head -1)
 python - "$f" "$@" <<'PY'
 import csv, sys
@@ -10,7 +10,7 @@ flt = sys.argv[2:]
 tot = 0.0
 rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows: tot += float(r["TotalDurationNs"])
-print("rocprofv3 --kernel-trace --stats -- python bench.py --steps 25 --warmup 10 --no-cpu-baseline --no-kernel-events --no-fixed-batch  (35 iterations incl. warm-up)")
+print("rocprofv3 --kernel-trace --stats -- python bench.py --steps 25 --warmup 10 --no-cpu-baseline --no-kernel-events --no-fixed-batch --no-secondary  (35 iterations incl. warm-up)")
 print("%-84s %7s %11s %9s %6s" % ("kernel", "calls", "total_us", "avg_us", "%"))
 for r in rows[:60]:
     n = r["Name"]

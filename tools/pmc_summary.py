@@ -8,7 +8,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     k = r["Kernel_Name"]
     if any(f in k for f in filt):
-        agg[k[:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        agg[k[:110]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in sorted(agg.items()):
     print(k)
     for c, v in sorted(d.items()):
