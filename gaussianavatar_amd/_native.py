@@ -165,7 +165,7 @@ GANET_SYMBOLS = ["ganet_linear_wgrad_workspace", "ganet_linear_wgrad", "ganet_bn
                  "ganet_mlp_bwd_fused_parts", "ganet_mlp_bwd_fused_workspace", "ganet_mlp_bwd_fused", "ganet_mlp_bwd_fused_input",
                  "ganet_decoder_saved_floats", "ganet_decoder_fwd_workspace", "ganet_decoder_fwd",
                  "ganet_decoder_bwd_workspace", "ganet_decoder_bwd",
-                 "ganet_decode_pack_fwd", "ganet_decode_pack_bwd", "ganet_records_bwd", "ganet_mean_sq_fwd", "ganet_mean_sq_bwd", "ganet_weighted_sum_fwd", "ganet_weighted_sum_bwd", "ganet_upsample_cat_fwd", "ganet_upsample_cat_bwd", "ganet_profile_enable", "ganet_profile_count", "ganet_profile_read", "ganet_profile_kernel_name",
+                 "ganet_decode_pack_fwd", "ganet_decode_pack_bwd", "ganet_records_bwd", "ganet_mean_sq_fwd", "ganet_mean_sq_bwd", "ganet_weighted_sum_fwd", "ganet_weighted_sum_bwd", "ganet_upsample_cat_fwd", "ganet_upsample_cat_bwd", "ganet_profile_create", "ganet_profile_destroy", "ganet_profile_bind", "ganet_profile_count", "ganet_profile_read", "ganet_profile_kernel_name",
                  "ganet_conv5_packed_bytes", "ganet_conv5_pack", "ganet_conv5_apply",
                  "ganet_conv5_wgrad_workspace", "ganet_conv5_wgrad", "ganet_last_error", "ganet_abi_version"]
 
@@ -284,9 +284,15 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_upsample_cat_fwd.argtypes = [c_int32, c_int32, c_int32, c_int32, P, P, P, P, P, P, P, c_int64, P]
         lib.ganet_upsample_cat_bwd.restype = c_int
         lib.ganet_upsample_cat_bwd.argtypes = [c_int32, c_int32, c_int32, c_int32, P, c_int64, P, P, P, P, P, P, P, P, P]
-        lib.ganet_profile_enable.argtypes = [c_int]
+        lib.ganet_profile_create.restype = c_void_p
+        lib.ganet_profile_create.argtypes = []
+        lib.ganet_profile_destroy.restype = None
+        lib.ganet_profile_destroy.argtypes = [P]
+        lib.ganet_profile_bind.restype = c_int
+        lib.ganet_profile_bind.argtypes = [P, c_int]
         lib.ganet_profile_count.restype = c_int
-        lib.ganet_profile_read.argtypes = [P, P, c_int]
+        lib.ganet_profile_read.restype = c_int
+        lib.ganet_profile_read.argtypes = [P, P, P, c_int]
         lib.ganet_profile_kernel_name.restype = c_char_p
         lib.ganet_profile_kernel_name.argtypes = [c_int]
         lib.ganet_conv5_packed_bytes.restype = c_size_t

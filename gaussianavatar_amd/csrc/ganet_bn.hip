@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <vector>
 
 #include "ganet.h"
@@ -295,32 +296,43 @@ void set_error(const char* fmt, ...) {
 }
 
 // ---------------------------------------------------------------- opt-in profiler
+// A caller-owned object (include/ganet.h: GanetProfile) bound to the calling thread; nothing process-global.
+}  // namespace ganet
+
+struct GanetProfile {
+  struct Rec { hipEvent_t start, stop; int id; };
+  std::mutex mu;                      // read may come from another thread than the one that launches
+  std::vector<Rec> recs;              // recorded, not yet read
+  std::vector<Rec> free_;             // recycled event pairs
+  double ms[ganet::K_COUNT] = {0};
+  long long n[ganet::K_COUNT] = {0};
+};
+
+namespace ganet {
+
 namespace {
-struct ProfRec { hipEvent_t start, stop; int id; };
-std::mutex g_prof_mu;
-unsigned g_prof_mask = 0;     // bit k: time kernel id k
-std::vector<ProfRec> g_prof_recs;     // recorded, not yet read
-std::vector<ProfRec> g_prof_free;     // recycled event pairs
-double g_prof_ms[K_COUNT] = {0};
-long long g_prof_n[K_COUNT] = {0};
+thread_local GanetProfile* t_prof = nullptr;
+thread_local unsigned t_prof_mask = 0;     // bit k: time kernel id k
 }  // namespace
 
 ProfScope::ProfScope(KernelId id, hipStream_t s) : slot(-1), stream(s) {
-  if (!((g_prof_mask >> id) & 1u)) return;
-  std::lock_guard<std::mutex> lk(g_prof_mu);
-  ProfRec r;
-  if (!g_prof_free.empty()) { r = g_prof_free.back(); g_prof_free.pop_back(); }
+  GanetProfile* p = t_prof;
+  if (!p || !((t_prof_mask >> id) & 1u)) return;
+  std::lock_guard<std::mutex> lk(p->mu);
+  GanetProfile::Rec r;
+  if (!p->free_.empty()) { r = p->free_.back(); p->free_.pop_back(); }
   else { if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return; }
   r.id = id;
   if (hipEventRecord(r.start, s) != hipSuccess) return;
-  g_prof_recs.push_back(r);
-  slot = (int)g_prof_recs.size() - 1;
+  p->recs.push_back(r);
+  slot = (int)p->recs.size() - 1;
 }
 
 ProfScope::~ProfScope() {
-  if (slot < 0) return;
-  std::lock_guard<std::mutex> lk(g_prof_mu);
-  if (slot < (int)g_prof_recs.size()) (void)hipEventRecord(g_prof_recs[slot].stop, stream);
+  GanetProfile* p = t_prof;
+  if (slot < 0 || !p) return;
+  std::lock_guard<std::mutex> lk(p->mu);
+  if (slot < (int)p->recs.size()) (void)hipEventRecord(p->recs[slot].stop, stream);
 }
 
 int check_hip(hipError_t e, const char* what) {
@@ -389,30 +401,41 @@ int ganet_bn_act_bwd(int64_t M, int32_t C, const float* x, const float* gamma, c
   return check_hip(hipGetLastError(), "ganet_bn_act_bwd");
 }
 
-int ganet_profile_enable(int mask) {
-  std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_prof_mask = (unsigned)mask;
+GanetProfile* ganet_profile_create(void) { return new (std::nothrow) GanetProfile(); }
+
+void ganet_profile_destroy(GanetProfile* p) {
+  if (!p) return;
+  if (t_prof == p) { t_prof = nullptr; t_prof_mask = 0; }
+  for (auto* v : {&p->recs, &p->free_})
+    for (auto& r : *v) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+  delete p;
+}
+
+int ganet_profile_bind(GanetProfile* p, int mask) {
+  t_prof = (p && mask) ? p : nullptr;
+  t_prof_mask = p ? (unsigned)mask : 0u;
   return 0;
 }
 
 int ganet_profile_count(void) { return K_COUNT; }
 
-int ganet_profile_read(double* ms_sum, int64_t* launches, int reset) {
-  std::lock_guard<std::mutex> lk(g_prof_mu);
-  for (auto& r : g_prof_recs) {
+int ganet_profile_read(GanetProfile* p, double* ms_sum, int64_t* launches, int reset) {
+  if (!p) { set_error("ganet_profile_read: profile is NULL"); return 1; }
+  std::lock_guard<std::mutex> lk(p->mu);
+  for (auto& r : p->recs) {
     float ms = 0.f;
     if (hipEventSynchronize(r.stop) == hipSuccess &&
         hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
-      g_prof_ms[r.id] += ms;
-      g_prof_n[r.id] += 1;
+      p->ms[r.id] += ms;
+      p->n[r.id] += 1;
     }
-    g_prof_free.push_back(r);
+    p->free_.push_back(r);
   }
-  g_prof_recs.clear();
+  p->recs.clear();
   for (int k = 0; k < K_COUNT; ++k) {
-    if (ms_sum) ms_sum[k] = g_prof_ms[k];
-    if (launches) launches[k] = g_prof_n[k];
-    if (reset) { g_prof_ms[k] = 0; g_prof_n[k] = 0; }
+    if (ms_sum) ms_sum[k] = p->ms[k];
+    if (launches) launches[k] = p->n[k];
+    if (reset) { p->ms[k] = 0; p->n[k] = 0; }
   }
   return 0;
 }

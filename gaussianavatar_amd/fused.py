@@ -8,6 +8,7 @@ exercise), so the two formulations are checked against each other on the GPU box
 from __future__ import annotations
 
 import ctypes
+import threading
 
 import torch
 import torch.nn.functional as F
@@ -20,10 +21,19 @@ def _ptr(t):
 
 
 def _stream(device):
+    """The current HIP stream of `device` as the void* every ganet entry point takes. Every launch passes through here, so
+    this is also where the calling thread is (re-)bound to the module's profile object: the binding is per thread
+    (include/ganet.h) and autograd runs backward on its own thread — one integer compare per call."""
+    if getattr(_profile_tls, "mask", 0) != _profile_mask and _profile is not None:
+        _native.ganet_check(_native.ganet().ganet_profile_bind(_profile, _profile_mask))
+        _profile_tls.mask = _profile_mask
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 _profiling = False        # per-kernel HIP events on: launches stay on ONE stream, so that a kernel's events time that kernel
+_profile = None           # the GanetProfile object of this module (caller-owned, bound to the launching threads)
+_profile_mask = 0
+_profile_tls = threading.local()
 
 
 def profile_kernels() -> tuple:
@@ -41,8 +51,10 @@ def profile_enable(on=True) -> None:
         mask = 0
     else:
         mask = sum(1 << names.index(k) for k in on)
-    _native.ganet_check(_native.ganet().ganet_profile_enable(mask))
-    global _profiling
+    global _profiling, _profile, _profile_mask
+    if _profile is None and mask:
+        _profile = ctypes.c_void_p(_native.ganet().ganet_profile_create())
+    _profile_mask = mask
     _profiling = bool(mask)
 
 
@@ -52,7 +64,8 @@ def profile_read(reset: bool = True) -> dict:
     n = lib.ganet_profile_count()
     ms = (ctypes.c_double * n)()
     cnt = (ctypes.c_int64 * n)()
-    _native.ganet_check(lib.ganet_profile_read(ms, cnt, 1 if reset else 0))
+    if _profile is not None:
+        _native.ganet_check(lib.ganet_profile_read(_profile, ms, cnt, 1 if reset else 0))
     return {lib.ganet_profile_kernel_name(i).decode(): (ms[i], int(cnt[i])) for i in range(n)}
 
 

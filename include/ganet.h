@@ -330,16 +330,20 @@ int ganet_upsample_cat_bwd(int32_t frames, int32_t S, int32_t R, int32_t C, cons
                            const int32_t* col_ptr, const int32_t* col_src, const float* col_w,
                            float* tmp, float* dfeat, void* stream);
 
-/* Optional per-kernel timing (bench/profiling only; off by default, the one piece of process-global
- * state in the library): every instrumented launch is bracketed by hipEvents recorded on the launch
- * stream; ganet_profile_read waits for them and returns, per kernel id < ganet_profile_count(), the
- * summed GPU time in ms and the launch count since the last reset. */
-int ganet_profile_enable(int mask);   /* bit k = time kernel id k; 0 = off */
+/* Optional per-kernel timing (bench/profiling only). The caller owns a GanetProfile object and binds it to the
+ * calling thread; from then on every instrumented launch this thread makes whose kernel id is in `mask` is bracketed by
+ * hipEvents recorded on the launch stream and accounted to that object (bind NULL or mask 0 to stop). ganet_profile_read
+ * waits for the recorded events and returns, per kernel id < ganet_profile_count(), the summed GPU time in ms and the
+ * launch count since the last reset. No process-global state: the binding is thread-local, like the error text. */
+typedef struct GanetProfile GanetProfile;
+GanetProfile* ganet_profile_create(void);
+void ganet_profile_destroy(GanetProfile* profile);
+int ganet_profile_bind(GanetProfile* profile, int mask);   /* bit k = time kernel id k */
 int ganet_profile_count(void);
-int ganet_profile_read(double* ms_sum, int64_t* launches, int reset);
+int ganet_profile_read(GanetProfile* profile, double* ms_sum, int64_t* launches, int reset);
 const char* ganet_profile_kernel_name(int id);
 
-/* Decoder GEMM arithmetic (not switchable: the library has no process-global state besides the optional profiling):
+/* Decoder GEMM arithmetic (not switchable: the library has no process-global state):
  * fp32 operands split exactly into three bf16 pieces, six bf16 MFMAs per step accumulated in fp32 (csrc/ganet_split.h:
  * fp32-accurate against float64, 6/16 of the fp32-MFMA pipe time). */
 const char* ganet_last_error(void);

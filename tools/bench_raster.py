@@ -38,3 +38,26 @@ prof = rasterizer.profile_read(True)
 n, pairs = rasterizer.pair_statistics(True)
 print(f"ABLATE={os.environ.get('GSR_ABLATE','0')} pairs/frame={pairs:.0f} wall fwd+bwd={wall:.0f}us  " +
       "  ".join(f"{k}={ms/c*1e3:.1f}" for k, (ms, c) in prof.items() if c))
+
+# forward-only renders (torch.no_grad(): the reference's eval.py / render_novel_pose.py): no segment records, small workspace;
+# two frames per launch as in the training iteration, per-kernel HIP events
+from gaussianavatar_amd.rasterizer import GaussianRasterizationSettings, rasterize_gaussians_batch
+import math
+B = 2
+bt = collate_frames([m.train_dataset[i] for i in range(B)], "cuda")
+rs = GaussianRasterizationSettings(size, size, math.tan(float(bt["FovX"][0]) * 0.5), math.tan(float(bt["FovY"][0]) * 0.5), m.background,
+                                   1.0, bt["world_view_transform"][:B], bt["full_proj_transform"][:B], 0, bt["camera_center"][0], False, False)
+pts2 = torch.stack([pts.detach(), pts.detach() + 0.003]).contiguous()
+for grad in (False, True):
+    def it2():
+        p_ = pts2.clone().requires_grad_(grad)
+        with torch.set_grad_enabled(grad):
+            return rasterize_gaussians_batch(p_, colors.detach(), m.fix_opacity, scales.detach(), m.fix_rotation, rs)[0]
+    for _ in range(5): it2()
+    rasterizer.check_overflow(True); rasterizer.profile_read(True)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps): it2()
+    torch.cuda.synchronize(); wall = (time.perf_counter() - t0) / reps * 1e6
+    prof = rasterizer.profile_read(True)
+    print(f"2 frames per launch, forward only, {'recording (requires_grad)' if grad else 'no_grad (gsr_forward_eval_batch)'}: wall {wall:.0f} us  " +
+          "  ".join(f"{k}={ms/c*1e3:.1f}" for k, (ms, c) in prof.items() if c))
