@@ -293,7 +293,10 @@ def fixed_global_batch_line(args, dev, rank, world, global_batch=8):
         loss.backward()
         model.step(1)
 
-    steps, warm = min(args.steps, 50), min(args.warmup, 10)
+    # (secondary measurement: its own warm-up, whatever --warmup says — on a fresh box the first iterations of a new
+    # model in the same process still grow the allocator's pools and the rasterizer's pair capacity: with 5 warm-up steps the
+    # 20 timed ones read 107-145 it/s, with 20 they read the steady 200)
+    steps, warm = max(20, min(args.steps, 50)), max(20, min(args.warmup, 30))
     for i in range(warm):
         step(i)
     rasterizer.check_overflow(block=True)
@@ -347,7 +350,10 @@ def secondary_stage2_line(args, dev):
         loss.backward()
         model.step(1)
 
-    steps, warm = min(args.steps, 30), min(max(args.warmup, 3), 8)
+    # own warm-up (see fixed_global_batch_line); stage 2 needs more of it: in the first GPU process on a fresh box the
+    # first ~50 iterations of this model are host-bound (11 ms instead of 7.7 ms per iteration; a 300-step run reads
+    # 131-134 it/s in every 50-step window after the first 50 iterations)
+    steps, warm = max(20, min(args.steps, 30)), 60
     for i in range(warm):
         step(i)
     rasterizer.check_overflow(block=True)

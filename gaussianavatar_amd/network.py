@@ -134,6 +134,28 @@ class ShapeDecoder(nn.Module):
         return back(r), back(s), back(c)
 
 
+def conv4s2_gemm(x, weight):
+    """Conv2d(k = 4, stride 2, padding 1, no bias) as im2col + ONE GEMM: [co, ci*16] x [B, ci*16, L]. On a HIP device the
+    pose-encoder UNet's convolutions take this form instead of the vendor convolution library: MIOpen picks its solver from
+    a per-user find database that does not exist in a fresh process — there (a cold box, e.g. the driver's) it falls back to
+    its naive kernels (`naive_conv_ab_nonpacked_*`: 5.2 ms per backward call, 55 % of a stage-2 iteration, 90 instead of 129
+    it/s; rocprofv3 of a cold process: profiles/r04_stage2_cold_miopen_kernel_stats.txt). The maps are tiny (64^2 .. 4^2), the
+    GEMMs come precompiled with rocBLAS; autograd differentiates unfold / matmul / fold."""
+    B, ci, H, W = x.shape
+    co = weight.shape[0]
+    cols = F.unfold(x, kernel_size=4, padding=1, stride=2)                 # [B, ci*16, (H/2)(W/2)]
+    return torch.matmul(weight.reshape(co, ci * 16), cols).reshape(B, co, H // 2, W // 2)
+
+
+def convT4s2_gemm(x, weight, bias=None):
+    """ConvTranspose2d(k = 4, stride 2, padding 1): ONE GEMM [co*16, ci] x [B, ci, L] + col2im (see conv4s2_gemm)."""
+    B, ci, H, W = x.shape
+    co = weight.shape[1]                                                    # weight [ci, co, 4, 4]
+    cols = torch.matmul(weight.reshape(ci, co * 16).t(), x.reshape(B, ci, H * W))
+    y = F.fold(cols, output_size=(2 * H, 2 * W), kernel_size=4, padding=1, stride=2)
+    return y if bias is None else y + bias.view(1, -1, 1, 1)
+
+
 class _Down(nn.Module):
     """LeakyReLU(0.2) -> conv4x4/s2 -> BN(affine=False) (modules.py:62-78)."""
 
@@ -145,7 +167,7 @@ class _Down(nn.Module):
             self.bn = nn.BatchNorm2d(co, affine=False)
 
     def forward(self, x):
-        x = self.conv(x)
+        x = conv4s2_gemm(x, self.conv.weight) if x.is_cuda else self.conv(x)
         return self.bn(x) if self.use_bn else x
 
 
@@ -166,7 +188,11 @@ class _Up(nn.Module):
             self.drop = nn.Dropout(0.5)
 
     def forward(self, x, skip=None):
-        x = self.up(F.relu(x))
+        x = F.relu(x)
+        if x.is_cuda and isinstance(self.up, nn.ConvTranspose2d):
+            x = convT4s2_gemm(x, self.up.weight, self.up.bias)
+        else:
+            x = self.up(x)
         if self.use_bn:
             x = self.bn(x)
         if self.use_dropout:

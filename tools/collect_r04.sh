@@ -7,9 +7,11 @@
 R=$PWD; tag=${1:-r04}; shift; O=$R/gpurun_out/$tag; mkdir -p $O
 names=${@:-config2 stage2 config5 headline}
 declare -A ARGS=( [config2]="--config 2" [stage2]="--stage 2" [config5]="--config 5 --global-batch 1" [headline]="" )
+# stage 2 settles later than stage 1 in a fresh process (bench.py: secondary_stage2_line): warm-up of 60 iterations
+declare -A WARM=( [config2]=5 [stage2]=60 [config5]=60 [headline]=5 )
 for n in $names; do
   a=${ARGS[$n]}
-  timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 $a --no-fixed-batch > $O/$n.json 2> $O/$n.err
+  timeout 600 python bench.py --gpus 1 --steps 20 --warmup ${WARM[$n]} $a --no-fixed-batch > $O/$n.json 2> $O/$n.err
   python - $O/$n.json <<'PY'
 import json, sys
 try:
