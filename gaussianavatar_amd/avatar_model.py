@@ -266,6 +266,12 @@ class AvatarModel:
                                uv_feat_dim=2).to(self.device)
         S_in = self.model_parms.inp_posmap_size
         geo = torch.ones(1, np_.c_geom, S_in, S_in).normal_(mean=0.0, std=0.01).float().to(self.device)
+        if geo.is_cuda and np_.c_geom == 64 and S_in % 64 == 0:
+            # same values, channels-last in memory: the layout the hand-written convolution / up-sampling kernels read
+            # and the one their input gradient comes back in (no layout copy each way, gradient contributions add
+            # without strides). Only where those kernels apply (fused.geom_convs_supported): the vendor convolutions
+            # pick other, non-reproducible algorithms for channels-last inputs
+            geo = geo.contiguous(memory_format=torch.channels_last)
         self.geo_feature = nn.Parameter(geo.requires_grad_(True))
         if self.model_parms.train_stage == 2:
             self.pose_encoder = UnetNoCond5DS(input_nc=3, output_nc=np_.c_pose, nf=np_.nf,

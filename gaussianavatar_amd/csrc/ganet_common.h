@@ -46,6 +46,9 @@ int bwd_stats_launch(int njobs, const BwdStatsJob* jobs, int64_t M, hipStream_t 
 int layer_fwd_spec(int64_t M, const float* x, int64_t ldx, const float* in_scale, const float* in_shift, const float* W,
                    const float* bias, float* z, int64_t ldz, float* col_part, const float* stat_shift, int reverse,
                    hipStream_t stream);
+int layer_fwd_spec3(int64_t M, const float* x, const float* in_scale, const float* in_shift, const float* const* W,
+                    const float* const* bias, float* const* z, float* const* col_part, const float* const* stat_shift,
+                    int reverse, hipStream_t stream);
 int mlp_fwd_split(int64_t M, int N, int K1, int K2, const float* x1, int64_t ld1, const float* x2, int64_t ld2,
                   const float* in_scale, const float* in_shift, const float* W, const float* bias, float* z,
                   int64_t ldz, float* col_part, const float* stat_shift, int reverse, hipStream_t stream);

@@ -98,7 +98,7 @@ extern "C" {
 size_t ganet_decoder_saved_floats(int64_t M) { return M <= 0 ? 0 : (size_t)NL * M * H + (size_t)NL * 4 * H; }
 
 size_t ganet_decoder_fwd_workspace(void) {
-  return (ganet_mlp_stats_floats(H) + (size_t)H * XP + (size_t)H * (XP + H)) * sizeof(float);
+  return (3 * ganet_mlp_stats_floats(H) + (size_t)H * XP + (size_t)H * (XP + H)) * sizeof(float);
 }
 
 int ganet_decoder_fwd(int64_t M, const float* x, const GanetDecoderParams* p, float* saved, float* const* out,
@@ -113,8 +113,8 @@ int ganet_decoder_fwd(int64_t M, const float* x, const GanetDecoderParams* p, fl
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const SavedView sv = view_saved(saved, M);
-  float* col_part = static_cast<float*>(workspace);
-  float* w1p = col_part + ganet_mlp_stats_floats(H);
+  float* col_part = static_cast<float*>(workspace);      // three sets: the conv6 branches' statistics in one launch
+  float* w1p = col_part + 3 * ganet_mlp_stats_floats(H);
   float* w5p = w1p + (size_t)H * XP;
   hipLaunchKernelGGL(pad_weights_kernel, dim3(H), dim3(256), 0, stream, p->cin, p->W[0], p->W[4], w1p, w5p);
   GA_TRY(check_hip(hipGetLastError(), "pad_weights_kernel"));
@@ -144,9 +144,27 @@ int ganet_decoder_fwd(int64_t M, const float* x, const GanetDecoderParams* p, fl
   GA_TRY(hidden(4, x, w5p, 3));
   // (the heads level by level with batched statistics launches, as the backward pass runs them, measured 0.4 % slower
   // here than head after head: 274.0 vs 275.0 it/s)
+  // conv6 of the three heads: ONE launch (they share their input z5: the branch workgroups of a slab sit on the same
+  // XCD, the slab leaves HBM once — ganet_layer_fwd.hip) and one statistics launch; shapes it does not take: head by head
+  bool conv6_done = false;
+  {
+    const float* Ws[3] = {p->W[5], p->W[7], p->W[9]};
+    const float* bs[3] = {p->bias[5], p->bias[7], p->bias[9]};
+    float* zs3[3] = {sv.z[5], sv.z[7], sv.z[9]};
+    float* cps[3] = {col_part, col_part + ganet_mlp_stats_floats(H), col_part + 2 * ganet_mlp_stats_floats(H)};
+    const float* shifts[3] = {p->running_mean[5], p->running_mean[7], p->running_mean[9]};
+    const int rc = layer_fwd_spec3(M, sv.z[4], sv.stat[4] + 2 * H, sv.stat[4] + 3 * H, Ws, bs, zs3, cps, shifts,
+                                   sweep.next() == GANET_ROWS_DOWN ? 1 : 0, stream);
+    if (rc > 0) return rc;
+    if (rc == 0) {
+      const FwdStatsJob jobs[3] = {stats_job(5, cps[0]), stats_job(7, cps[1]), stats_job(9, cps[2])};
+      GA_TRY(mlp_stats_launch(3, jobs, M, H, stream));
+      conv6_done = true;
+    }
+  }
   for (int j = 0; j < 3; ++j) {
     const int i6 = 5 + 2 * j, i7 = 6 + 2 * j;
-    GA_TRY(hidden(i6, nullptr, p->W[i6], 4));
+    if (!conv6_done) GA_TRY(hidden(i6, nullptr, p->W[i6], 4));
     GA_TRY(hidden(i7, nullptr, p->W[i7], i6));
     GA_TRY(ganet_mlp_fwd(M, p->n8[j], 0, H, nullptr, 0, sv.z[i7], H, sv.stat[i7] + 2 * H, sv.stat[i7] + 3 * H,
                          p->W8[j], p->b8[j], out[j], p->n8[j], nullptr, nullptr, sweep.next(), stream));

@@ -54,15 +54,29 @@ __device__ unsigned long long g_lfwd_blocks[256][4];     // per workgroup: start
 #define LFWD_STAMP(ROLE, R, I) do {} while (0)
 #endif
 
+#ifndef GANET_LFWD_ABLATE
+#define GANET_LFWD_ABLATE 0   // development (tools/lfwd_ablate.sh): 1 = no softplus in the producers, 2 = one product of six,
+#endif                        // 4 = output tiles not stored, 8 = every branch reads its own copy of the input
 #ifndef GANET_LFWD_CHAINS
 #define GANET_LFWD_CHAINS 1   // 2: even / odd k-steps on separate accumulators — 16 registers more than three waves per SIMD leave
 #endif
 
+// NB = 3: the three conv6 branches of the decoder (same input z5, three weight sets) in ONE launch. A branch is not a
+// second loop over the rows — the register file has no room for three sets of W fragments — but its own workgroups:
+// 240 = 8 XCDs x 10 groups x 3 branches, the three workgroups of a group on the SAME XCD (block indices 8 apart) walking
+// the same slabs round by round, so that the input slab comes out of HBM once and the other two reads hit the XCD's L2.
+struct FwdBranches {
+  const float* W[3];
+  const float* bias[3];
+  float* z[3];
+  float* col_part[3];
+  const float* stat_shift[3];
+};
+
+template <int NB>
 __global__ void __attribute__((amdgpu_flat_work_group_size(FWG, FWG), amdgpu_waves_per_eu(3, 3)))
 layer_fwd_spec_kernel(int64_t M, const float* __restrict__ x, const float* __restrict__ in_scale,
-                      const float* __restrict__ in_shift, const float* __restrict__ W, const float* __restrict__ bias,
-                      float* __restrict__ z, float* __restrict__ col_part, const float* __restrict__ stat_shift,
-                      int reverse) {
+                      const float* __restrict__ in_shift, FwdBranches br, int reverse) {
   extern __shared__ u32x4 s_mem[];
   char* const lds = reinterpret_cast<char*>(s_mem);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -71,10 +85,23 @@ layer_fwd_spec_kernel(int64_t M, const float* __restrict__ x, const float* __res
   const bool consumer = wave < 4;              // uniform
   LFWD_BLOCK(0);
 
+  // branch of this workgroup, its index among the branch's workgroups and their number
+  const int branch = NB == 1 ? 0 : (int)(blockIdx.x >> 3) % NB;
+  const int vblock = NB == 1 ? (int)blockIdx.x : (int)(blockIdx.x / (8 * NB)) * 8 + (int)(blockIdx.x & 7);
+  const int vgrid = NB == 1 ? (int)gridDim.x : (int)gridDim.x / NB;
+#if GANET_LFWD_ABLATE & 8
+  x += (size_t)branch * M * 128;
+#endif
+  const float* __restrict__ const W = br.W[branch];
+  const float* __restrict__ const bias = br.bias[branch];
+  float* __restrict__ const z = br.z[branch];
+  float* __restrict__ const col_part = br.col_part[branch];
+  const float* __restrict__ const stat_shift = br.stat_shift[branch];
+
   const int64_t nslab = M / FSLAB;
-  const int rounds = (int)((nslab + gridDim.x - 1) / gridDim.x);
+  const int rounds = (int)((nslab + vgrid - 1) / vgrid);
   const int roundsN = (rounds + 3) & ~3;            // both roles run the same number of barriers
-  auto slab_of = [&](int r) -> int64_t { return (int64_t)r * gridDim.x + blockIdx.x; };
+  auto slab_of = [&](int r) -> int64_t { return (int64_t)r * vgrid + vblock; };
   auto phys = [&](int64_t slab) -> int64_t {
     const int64_t sl = slab < nslab ? slab : nslab - 1;        // past the end: re-read the last slab (never used)
     return reverse ? nslab - 1 - sl : sl;
@@ -100,10 +127,14 @@ layer_fwd_spec_kernel(int64_t M, const float* __restrict__ x, const float* __res
     auto produce = [&](const Raw& r, int buf) {
       char* const base = lds + buf * BUF;
       float v[8];
+#if GANET_LFWD_ABLATE & 1
+      v[0] = r.s0.x; v[1] = r.s0.y; v[2] = r.s0.z; v[3] = r.s0.w; v[4] = r.s1.x; v[5] = r.s1.y; v[6] = r.s1.z; v[7] = r.s1.w;
+#else
       v[0] = softplus_log2(fmaf(C0.x, r.s0.x, H0.x)); v[1] = softplus_log2(fmaf(C0.y, r.s0.y, H0.y));
       v[2] = softplus_log2(fmaf(C0.z, r.s0.z, H0.z)); v[3] = softplus_log2(fmaf(C0.w, r.s0.w, H0.w));
       v[4] = softplus_log2(fmaf(C1.x, r.s1.x, H1.x)); v[5] = softplus_log2(fmaf(C1.y, r.s1.y, H1.y));
       v[6] = softplus_log2(fmaf(C1.z, r.s1.z, H1.z)); v[7] = softplus_log2(fmaf(C1.w, r.s1.w, H1.w));
+#endif
       u32x4 p1, p2, p3;
       split8(v, p1, p2, p3);
       *reinterpret_cast<u32x4*>(base + p_img) = p1;
@@ -113,6 +144,9 @@ layer_fwd_spec_kernel(int64_t M, const float* __restrict__ x, const float* __res
     // the output tile of round r (buffer r & 1): the lane that owns those 32 bytes stores them
     auto drain = [&](int r) {
       if (r < 0 || !(slab_of(r) < nslab && r < rounds)) return;
+#if GANET_LFWD_ABLATE & 4
+      if (M > 0) return;
+#endif
       const char* const zs = lds + (r & 1) * BUF + IMG + prow * 512 + pq * 32;
       const float4 o0 = *reinterpret_cast<const float4*>(zs);
       const float4 o1 = *reinterpret_cast<const float4*>(zs + 16);
@@ -195,7 +229,12 @@ layer_fwd_spec_kernel(int64_t M, const float* __restrict__ x, const float* __res
       for (int s = 0; s < 8; ++s) {
         if (s < 7) read_a(s + 1, fnxt);
         __builtin_amdgcn_sched_barrier(0);
+#if GANET_LFWD_ABLATE & 2
+        acc[0] = mfma_bf16(fcur[0], Bw[s][0], acc[0]);
+        asm volatile("" :: "v"(fcur[1]), "v"(fcur[2]));
+#else
         GANET_SPLIT_PRODUCTS(acc[s % GANET_LFWD_CHAINS], fcur[0], fcur[1], fcur[2], Bw[s][0], Bw[s][1], Bw[s][2]);
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int p = 0; p < 3; ++p) fcur[p] = fnxt[p];
@@ -226,8 +265,13 @@ layer_fwd_spec_kernel(int64_t M, const float* __restrict__ x, const float* __res
       const float s = csum + __shfl_xor(csum, 32);
       const float q = csq + __shfl_xor(csq, 32);
       if (kg == 0) {
-        col_part[(size_t)blockIdx.x * 256 + 32 * wave + c] = s;
-        col_part[(size_t)blockIdx.x * 256 + 128 + 32 * wave + c] = q;
+        col_part[(size_t)vblock * 256 + 32 * wave + c] = s;
+        col_part[(size_t)vblock * 256 + 128 + 32 * wave + c] = q;
+        // the statistics kernel adds up all FBLOCKS rows: the rows no workgroup of this branch owns are zeroed here
+        for (int row = vblock + vgrid; NB > 1 && row < FBLOCKS; row += vgrid) {
+          col_part[(size_t)row * 256 + 32 * wave + c] = 0.f;
+          col_part[(size_t)row * 256 + 128 + 32 * wave + c] = 0.f;
+        }
       }
     }
   }
@@ -235,6 +279,11 @@ layer_fwd_spec_kernel(int64_t M, const float* __restrict__ x, const float* __res
 
 }  // namespace
 
+#if defined(GANET_LFWD_TRACE) || GANET_LFWD_ABLATE
+// development: the three-branch launch on its own (tools/lfwd_trace.py, tools/lfwd_ablate.py)
+extern "C" int ganet_dev_layer_fwd3(int64_t M, const float* x, const float* in_scale, const float* in_shift, const float* W,
+                                    const float* bias, float* z, float* col_part, void* stream);
+#endif
 #ifdef GANET_LFWD_TRACE
 extern "C" int ganet_dev_lfwd_blocks(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lfwd_blocks), sizeof(g_lfwd_blocks)); }
 extern "C" int ganet_dev_lfwd_trace(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lfwd_trace), sizeof(g_lfwd_trace)); }
@@ -242,22 +291,53 @@ extern "C" int ganet_dev_lfwd_trace(void* out) { return (int)hipMemcpyFromSymbol
 
 // Hidden layer forward, [M,128] -> [M,128], contiguous rows, M a multiple of 32: returns -1 for anything else (the
 // caller then takes mlp_fwd_split_kernel).
-int layer_fwd_spec(int64_t M, const float* x, int64_t ldx, const float* in_scale, const float* in_shift, const float* W,
-                   const float* bias, float* z, int64_t ldz, float* col_part, const float* stat_shift, int reverse,
-                   hipStream_t stream) {
-  if (M < FSLAB || (M % FSLAB) != 0 || ldx != 128 || ldz != 128 || !aligned16(z)) return -1;
+template <int NB>
+static int launch_layer_fwd(int blocks, int64_t M, const float* x, const float* in_scale, const float* in_shift,
+                            const FwdBranches& br, int reverse, hipStream_t stream) {
   const size_t lds = (size_t)2 * BUF;
-  static PerDeviceFlag attr_set;       
+  static PerDeviceFlag attr_set;
   if (!attr_set) {
-    if (int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_fwd_spec_kernel),
+    if (int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_fwd_spec_kernel<NB>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "layer_fwd lds"))
       return rc;
     attr_set = true;
   }
   ProfScope prof_(K_MLP_FWD, stream);
-  hipLaunchKernelGGL(layer_fwd_spec_kernel, dim3(FBLOCKS), dim3(FWG), lds, stream, M, x, in_scale, in_shift, W, bias, z,
-                     col_part, stat_shift, reverse);
+  hipLaunchKernelGGL(layer_fwd_spec_kernel<NB>, dim3(blocks), dim3(FWG), lds, stream, M, x, in_scale, in_shift, br, reverse);
   return check_hip(hipGetLastError(), "layer_fwd_spec_kernel");
 }
 
+int layer_fwd_spec(int64_t M, const float* x, int64_t ldx, const float* in_scale, const float* in_shift, const float* W,
+                   const float* bias, float* z, int64_t ldz, float* col_part, const float* stat_shift, int reverse,
+                   hipStream_t stream) {
+  if (M < FSLAB || (M % FSLAB) != 0 || ldx != 128 || ldz != 128 || !aligned16(z)) return -1;
+  FwdBranches br{};
+  br.W[0] = W; br.bias[0] = bias; br.z[0] = z; br.col_part[0] = col_part; br.stat_shift[0] = stat_shift;
+  return launch_layer_fwd<1>(FBLOCKS, M, x, in_scale, in_shift, br, reverse, stream);
+}
+
+// Three layers on the same input (the decoder's conv6 branches) in one launch: -1 when the shape does not qualify.
+int layer_fwd_spec3(int64_t M, const float* x, const float* in_scale, const float* in_shift, const float* const* W,
+                    const float* const* bias, float* const* z, float* const* col_part, const float* const* stat_shift,
+                    int reverse, hipStream_t stream) {
+  constexpr int blocks = (FBLOCKS / 24) * 24;          // 240: 8 XCDs x 10 groups x 3 branches
+  if (M < (int64_t)FSLAB * (blocks / 3) || (M % FSLAB) != 0) return -1;
+  FwdBranches br{};
+  for (int j = 0; j < 3; ++j) {
+    if (!aligned16(z[j]) || !col_part[j]) return -1;
+    br.W[j] = W[j]; br.bias[j] = bias[j]; br.z[j] = z[j]; br.col_part[j] = col_part[j]; br.stat_shift[j] = stat_shift[j];
+  }
+  return launch_layer_fwd<3>(blocks, M, x, in_scale, in_shift, br, reverse, stream);
+}
+
 }  // namespace ganet
+
+#if defined(GANET_LFWD_TRACE) || GANET_LFWD_ABLATE
+// W [3][128][128], bias [3][128], z [3][M][128], col_part [3][256][256]
+extern "C" int ganet_dev_layer_fwd3(int64_t M, const float* x, const float* in_scale, const float* in_shift, const float* W,
+                                    const float* bias, float* z, float* col_part, void* stream) {
+  const float* Wp[3]; const float* bp[3]; float* zp[3]; float* cp[3]; const float* sp[3] = {nullptr, nullptr, nullptr};
+  for (int j = 0; j < 3; ++j) { Wp[j] = W + j * 128 * 128; bp[j] = bias + j * 128; zp[j] = z + (size_t)j * M * 128; cp[j] = col_part + j * 256 * 256; }
+  return ganet::layer_fwd_spec3(M, x, in_scale, in_shift, Wp, bp, zp, cp, sp, 0, static_cast<hipStream_t>(stream));
+}
+#endif

@@ -226,7 +226,8 @@ class _MeanSqFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         lib = _native.ganet()
-        xc = x.contiguous()
+        # element order does not matter: any dense layout (channels-last parameters) is read in place
+        xc = x if (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)) else x.contiguous()
         out = torch.empty(1, dtype=torch.float32, device=x.device)
         _native.ganet_check(lib.ganet_mean_sq_fwd(xc.numel(), _ptr(xc), 1.0 / float(xc.numel()), _ptr(out),
                                                   _stream(x.device)))
@@ -237,7 +238,7 @@ class _MeanSqFn(torch.autograd.Function):
     def backward(ctx, g):
         lib = _native.ganet()
         (xc,) = ctx.saved_tensors
-        dx = torch.empty_like(xc)
+        dx = torch.empty_like(xc, memory_format=torch.preserve_format)
         _native.ganet_check(lib.ganet_mean_sq_bwd(xc.numel(), _ptr(xc), 1.0 / float(xc.numel()),
                                                   _ptr(g.reshape(1).float().contiguous()), _ptr(dx), _stream(xc.device)))
         return dx

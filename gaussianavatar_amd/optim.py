@@ -22,6 +22,11 @@ import torch
 from . import _native
 
 
+def _same_layout(a: torch.Tensor, b: torch.Tensor) -> bool:
+    """Same shape and the same memory order (strides of size-1 dimensions do not matter)."""
+    return a.shape == b.shape and all(sa == sb for sa, sb, n in zip(a.stride(), b.stride(), a.shape) if n > 1)
+
+
 class Adam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, foreach=False,
@@ -86,11 +91,16 @@ class Adam(torch.optim.Adam):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] = shared
-                if not p.is_contiguous():
-                    raise RuntimeError("gaussianavatar_amd.optim.Adam: parameters must be contiguous")
-                if not g.is_contiguous():
-                    g = g.contiguous()
+                # the update is element-wise over memory: parameter, gradient and moments must be dense and share
+                # ONE layout (row-major or channels-last; the moments are created with the parameter's)
+                if not (p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))):
+                    raise RuntimeError("gaussianavatar_amd.optim.Adam: parameters must be dense (contiguous or channels-last)")
+                if not _same_layout(g, p):
+                    g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
                     p.grad = g
+                for key in ("exp_avg", "exp_avg_sq"):      # (a checkpoint written with another layout)
+                    if not _same_layout(st[key], p):
+                        st[key] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st[key])
                 if stream is None:
                     stream = torch.cuda.current_stream(p.device).cuda_stream
                     skip = self._skip_flag(p.device)

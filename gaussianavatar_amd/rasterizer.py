@@ -104,6 +104,11 @@ class _PairCapacity:
     def post(self, status_dev: torch.Tensor, cap: int, key):
         host = self._pinned()
         host.copy_(status_dev, non_blocking=True)
+        self.posted(host, cap, key)
+
+    def posted(self, host: torch.Tensor, cap: int, key):
+        """`host` (from _pinned()) is being written by work already queued on the current stream — by a copy (post)
+        or by the status kernel itself (pinned host memory is device-addressable: the batched path saves the copy)."""
         ev = torch.cuda.Event()
         ev.record()
         self.pending.append((ev, host, cap, key))
@@ -436,6 +441,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                               cov3Ds_precomp if cov3Ds_precomp is not None else torch.empty(0, device=means3D.device),
                               radii, workspace)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)         # (no [P] zero tensor for radii's "gradient")
         return color, radii
 
     @staticmethod
@@ -445,6 +451,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         means3D, colors_precomp, opacities, scales, rotations, cov3D, radii, workspace = ctx.saved_tensors
         if not ctx.recorded:
             raise RuntimeError("GaussianRasterizer: this render was made without gradient tracking (forward-only path)")
+        if grad_color is None:
+            return (None,) * 10
         if not ctx.has_sr:
             scales = rotations = None
         else:
@@ -546,10 +554,10 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
                 _ptr(color), _ptr(radii), _stream_ptr(dev)))
             # one record for the whole launch: [max pairs of a frame, any overflow, -, longest tile
             # list, total pairs of all frames, frames, -, -] (gsr_batch_status, one tiny kernel)
-            worst = torch.empty(8, dtype=torch.int32, device=dev)
+            worst = _capacity._pinned()          # written by the kernel over the host link: no device-to-host copy
             _native.gsr_check(lib.gsr_batch_status(_ptr(workspace), B, P, W, H, max_pairs, mode, _ptr(worst),
                                                    _stream_ptr(dev)))
-            _capacity.post(worst, max_pairs, key)
+            _capacity.posted(worst, max_pairs, key)
             if not sync_check:
                 break
             needed, overflow = _capacity.wait_last()
@@ -567,6 +575,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
                     (tuple(rotations.shape), rotations.dim() == 3))
         ctx.save_for_backward(means3D, col, opa, sca, rot, view, proj, bg, campos, radii, workspace)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)         # (autograd would otherwise fill a [B,P] zero tensor for radii's "gradient")
         return color, radii
 
     @staticmethod
@@ -577,6 +586,8 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         B, P, H, W, strides, col_shape, opa_shape, sca_shape, rot_shape = ctx.meta
         if not ctx.recorded:
             raise RuntimeError("rasterize_gaussians_batch: this render was made without gradient tracking")
+        if grad_color is None:
+            return (None,) * 7
         s_col, s_opa, s_sca, s_rot, s_view, s_proj = strides
         dev = means3D.device
         _capacity.poll()

@@ -606,6 +606,37 @@ def test_one_launch_adam_matches_torch_adam():
     assert float(oa3.state_dict()["state"][0]["step"]) == 2.0
 
 
+def test_adam_on_a_channels_last_parameter():
+    """The geometry feature map is kept channels-last on a HIP device (avatar_model.net_set): the one-launch Adam walks
+    memory, so parameter, gradient and moments must share one layout whatever layout gradients arrive in or a checkpoint
+    was written with. Against torch.optim.Adam on the row-major twin."""
+    from gaussianavatar_amd.optim import Adam
+    torch.manual_seed(9)
+    base = torch.randn(1, 64, 16, 24, device="cuda")
+    pa = torch.nn.Parameter(base.clone().contiguous(memory_format=torch.channels_last))
+    pb = torch.nn.Parameter(base.clone())
+    oa, ob = Adam([pa], lr=2e-3), torch.optim.Adam([pb], lr=2e-3)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for step in range(4):
+        grad = torch.randn(base.shape, device="cuda", generator=g)
+        # gradients arrive row-major, channels-last, or as a permuted view of an NHWC buffer (what geom_convs returns)
+        pa.grad = (grad.clone(), grad.contiguous(memory_format=torch.channels_last),
+                   grad.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2), grad.clone())[step]
+        pb.grad = grad.clone()
+        oa.step(); ob.step()
+        assert pa.is_contiguous(memory_format=torch.channels_last) and pa.grad.stride() == pa.stride()
+    torch.testing.assert_close(pa.detach().contiguous(), pb.detach(), rtol=2e-6, atol=2e-7)
+    # a checkpoint written by the row-major optimiser continues on the channels-last parameter
+    oa2 = Adam([pa], lr=2e-3)
+    oa2.load_state_dict(ob.state_dict())
+    grad = torch.randn(base.shape, device="cuda", generator=g)
+    pa.grad, pb.grad = grad.clone(), grad.clone()
+    oa2.step(); ob.step()
+    torch.testing.assert_close(pa.detach().contiguous(), pb.detach(), rtol=4e-6, atol=4e-7)
+    st = oa2.state[pa]
+    assert st["exp_avg"].stride() == pa.stride() and st["exp_avg_sq"].stride() == pa.stride()
+
+
 def test_production_width_nets_match_reference_on_the_fused_path():
     """The reference's own POP_no_unet / UnetNoCond5DS at c_geom 64 / hsize 128 / nf 32 (golden outputs AND
     gradients, oracle/make_golden.py:make_net_full) against the HIP path these widths select: fused

@@ -12,8 +12,15 @@ x = torch.randn(M, 128, device=dev); W = torch.randn(128, 128, device=dev) * 0.1
 sc = torch.rand(128, device=dev) + 0.5; sh = torch.randn(128, device=dev)
 z = torch.empty(M, 128, device=dev); part = torch.zeros(lib.ganet_mlp_stats_floats(128), device=dev)
 st = fused._stream(dev); P = fused._ptr
+if os.environ.get("THREE"):     # the three-branch launch (block 0 = branch 0 of group 0)
+    W = torch.randn(3, 128, 128, device=dev) * 0.1; b = torch.randn(3, 128, device=dev)
+    z = torch.empty(3, M, 128, device=dev); part = torch.zeros(3, 256, 256, device=dev)
+    lib.ganet_dev_layer_fwd3.argtypes = [ctypes.c_int64] + [ctypes.c_void_p] * 8
 for _ in range(5):
-    _native.ganet_check(lib.ganet_mlp_fwd(M, 128, 0, 128, None, 0, P(x), 128, P(sc), P(sh), P(W), P(b), P(z), 128, P(part), None, 1, st))
+    if os.environ.get("THREE"):
+        _native.ganet_check(lib.ganet_dev_layer_fwd3(M, P(x), P(sc), P(sh), P(W), P(b), P(z), P(part), st))
+    else:
+        _native.ganet_check(lib.ganet_mlp_fwd(M, 128, 0, 128, None, 0, P(x), 128, P(sc), P(sh), P(W), P(b), P(z), 128, P(part), None, 1, st))
 torch.cuda.synchronize()
 buf = np.zeros((2, 64, 8), dtype=np.uint64)
 lib.ganet_dev_lfwd_trace.argtypes = [ctypes.c_void_p]
