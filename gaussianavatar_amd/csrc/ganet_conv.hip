@@ -69,6 +69,17 @@ conv5_pack_kernel(PackJobs jobs, u32x4* __restrict__ packed) {
   out[2 * 8 * C + at] = p3;
 }
 
+#ifdef GANET_CONV_TRACE
+// development (tools/conv_trace.py): s_memtime stamps of waves 0 and 7 of block 0, s_memrealtime start / end per block
+__device__ unsigned long long g_conv_trace[2][8];
+__device__ unsigned long long g_conv_blocks[1024][2];
+#define CONV_STAMP(I) do { if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 7)) g_conv_trace[wave == 7][I] = __builtin_amdgcn_s_memtime(); } while (0)
+#define CONV_BLOCK(I) do { if (lane == 0 && wave == 0 && blockIdx.x < 1024) g_conv_blocks[blockIdx.x][I] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CONV_STAMP(I) do {} while (0)
+#define CONV_BLOCK(I) do {} while (0)
+#endif
+
 constexpr int WGC = 512;                                 // 8 waves: (32-channel half of the output) x (quarter of a tap's 64 k)
 constexpr int HALO_W = 64 + 4;                           // pixels per halo row
 constexpr int PIX_UNITS = 9;                             // 8 units of 8 bf16 channels + 1 pad: pixel records on different banks
@@ -88,6 +99,7 @@ conv5_kernel(int H, int W, const float* __restrict__ x, const u32x4* __restrict_
   const int py = row % H;
   const int px0 = (blockIdx.x - row * per_row) * 64;
   const float* img = x + (size_t)(row - py) * W * C;
+  CONV_BLOCK(0); CONV_STAMP(0);
 
   // B fragments of this wave: (tap, plane) -> one coalesced 16-byte load per lane, straight from the packed image
   // (L2-resident, identical for every workgroup), LEAD taps ahead in a register ring — no LDS, no barrier per tap
@@ -117,6 +129,7 @@ conv5_kernel(int H, int W, const float* __restrict__ x, const u32x4* __restrict_
     lo[k] = *reinterpret_cast<const float4*>(src);
     hi[k] = *reinterpret_cast<const float4*>(src + 4);
   }
+  CONV_STAMP(1);
 #pragma unroll
   for (int k = 0; k < HALO_IT; ++k) {
     const int i = threadIdx.x + k * WGC;
@@ -132,7 +145,9 @@ conv5_kernel(int H, int W, const float* __restrict__ x, const u32x4* __restrict_
     s_halo[HALO_UNITS + p * PIX_UNITS + u] = p2;
     s_halo[2 * HALO_UNITS + p * PIX_UNITS + u] = p3;
   }
+  CONV_STAMP(2);
   __syncthreads();
+  CONV_STAMP(3);
 
   // one accumulator per 32-pixel strip: consecutive MFMAs of a wave alternate between them
   f32x16 acc[2];
@@ -163,7 +178,9 @@ conv5_kernel(int H, int W, const float* __restrict__ x, const u32x4* __restrict_
   }
   // the k-quarters 1..3 hand their tiles over through LDS; quarter 0 adds and stores.
   // C/D layout: column (output channel) = lane & 31, row (pixel of the strip) = (reg & 3) + 8 (reg >> 2) + 4 kg
+  CONV_STAMP(4);
   __syncthreads();
+  CONV_STAMP(5);
   float* s_t = reinterpret_cast<float*>(s_halo);         // [wave - 2][strip][reg][lane]
   if (kq > 0) {
 #pragma unroll
@@ -172,6 +189,7 @@ conv5_kernel(int H, int W, const float* __restrict__ x, const u32x4* __restrict_
       for (int r = 0; r < 16; ++r) s_t[(((wave - 2) * 2 + st) * 16 + r) * 64 + lane] = acc[st][r];
   }
   __syncthreads();
+  CONV_STAMP(6);
   if (kq == 0) {
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
@@ -185,6 +203,7 @@ conv5_kernel(int H, int W, const float* __restrict__ x, const u32x4* __restrict_
       }
     }
   }
+  CONV_STAMP(7); CONV_BLOCK(1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -309,6 +328,13 @@ bool shape_ok(int b, int H, int W) { return b > 0 && H > 0 && W > 0 && (W % 64) 
 }  // namespace ganet
 
 using namespace ganet;
+
+#ifdef GANET_CONV_TRACE
+extern "C" int ganet_dev_conv_trace(void* tr, void* bl) {
+  if (hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_conv_trace), sizeof(g_conv_trace)) != hipSuccess) return 1;
+  return (int)hipMemcpyFromSymbol(bl, HIP_SYMBOL(g_conv_blocks), sizeof(g_conv_blocks));
+}
+#endif
 
 extern "C" {
 
