@@ -360,8 +360,8 @@ __device__ __forceinline__ void sort_tile_whole(int tile, int64_t cap, const uin
 // sorting all 586). Measured and rejected on the way: two short lists side by side in one workgroup (no gain),
 // pairing ALL lists (halves the long lists' thread count: 144 us), two size classes in two launches (144 us).
 // So a list is cut into chunks of SORT_CHUNK keys, every chunk is sorted by its own workgroup (16 KiB of LDS:
-// several per CU), and sorted runs are merged pairwise with merge path inside LDS — two passes cover 4 chunks;
-// longer lists (none in avatar scenes) take the one-workgroup path with runs merged through HBM. The order is
+// several per CU), and a list's sorted runs are merged with merge path inside LDS by one workgroup — two levels cover 4
+// chunks (tile_merge_all_kernel); longer lists (none in avatar scenes) take the one-workgroup path with runs merged through HBM. The order is
 // the same total order (depth bits, then Gaussian index), whatever the decomposition.
 constexpr int SORT_CHUNK = 2048;
 constexpr int SORT_MAX_CHUNKS = 4;
@@ -391,7 +391,6 @@ __device__ __forceinline__ TileSpan tile_span(const uint32_t* tile_order, const 
 // and stop at the first list whose class needs no work: ~590 of 4096 tiles are occupied, and one workgroup per tile and
 // chunk (32k mostly empty 1024-thread workgroups per frame over the four launches) cost more than the sort.
 constexpr int SORT_GRID = 768;
-constexpr int SORT_WG = 512;              // merge kernels
 constexpr int CHUNK_WG = SORT_CHUNK / 8;  // chunk sort: 8 keys per thread
 
 // chunk blockIdx.z of the tiles of rank blockIdx.x, + SORT_GRID, ...: merge-sorted in LDS (merge_sort_lds); a
@@ -422,66 +421,59 @@ tile_sort_chunk_kernel(int T, int ordered, int64_t max_pairs, const uint32_t* __
   }
 }
 
-// merge pass PASS (runs of W = SORT_CHUNK << PASS keys): pair blockIdx.z of tile blockIdx.x. Both runs are
-// staged in LDS, every thread takes ITEMS consecutive outputs (merge path). Pass 0 reads pair_key and writes
-// pair_tmp, pass 1 the other way round; the pass that completes a list writes point_list instead.
-template <int PASS>
-__global__ void __launch_bounds__(SORT_WG)
-tile_merge_kernel(int T, int ordered, int64_t max_pairs, const uint32_t* __restrict__ tile_order,
-                  const uint32_t* __restrict__ tile_offset, uint64_t* __restrict__ pair_key,
-                  uint64_t* __restrict__ pair_tmp, uint32_t* __restrict__ point_list, size_t ws_stride) {
-  constexpr int W = SORT_CHUNK << PASS;
-  constexpr int ITEMS = 2 * W / SORT_WG;
-  __shared__ uint64_t s_run[2 * W];
-  GSR_FRAME_PTRS();
-  const int tid = threadIdx.x;
-  const int lo = blockIdx.z * 2 * W;
-  for (int rank = blockIdx.x; rank < T; rank += gridDim.x) {
-    const TileSpan ts = tile_span(tile_order, tile_offset, max_pairs, rank);
-    if (ts.n < W && ordered) break;                         // a lower size class: every later list is one run too
-    if (ts.n <= W || ts.n > SORT_MAX_CHUNKS * SORT_CHUNK || lo >= ts.n) continue;   // one run / long-list path / no such pair
-    const int mid = min(lo + W, ts.n), hi = min(lo + 2 * W, ts.n);
-    const uint64_t* src = (PASS & 1 ? pair_tmp : pair_key) + ts.start + lo;
-    uint64_t* dst = (PASS & 1 ? pair_key : pair_tmp) + ts.start + lo;
-    const int len = hi - lo, na = mid - lo, nb = hi - mid;
-    __syncthreads();
-    for (int i = tid; i < len; i += SORT_WG) s_run[i] = src[i];
-    __syncthreads();
-    const bool last = ts.n <= 2 * W;                        // this pass leaves one run = the sorted list
-    const uint64_t* A = s_run;
-    const uint64_t* B = s_run + na;
-    const int g0 = tid * ITEMS;
-    if (g0 < len) {
-      int ia = merge_split(A, na, B, nb, g0);
-      int ib = g0 - ia;
-      const int cnt = min(ITEMS, len - g0);
-#pragma unroll
-      for (int o = 0; o < ITEMS; ++o) {
-        if (o < cnt) {
-          const bool takeA = (ib >= nb) || (ia < na && A[ia] <= B[ib]);
-          const uint64_t v = takeA ? A[ia++] : B[ib++];
-          if (last) point_list[ts.start + lo + g0 + o] = (uint32_t)v;
-          else dst[g0 + o] = v;
-        }
-      }
-    }
-  }
-}
-
-// lists beyond SORT_MAX_CHUNKS chunks: one workgroup per list (64 KiB of LDS), runs merged through HBM
-__global__ void __launch_bounds__(1024)
-tile_sort_long_kernel(int T, int ordered, int64_t max_pairs, const uint32_t* __restrict__ tile_order,
+// Every merge pass of a list of 2 .. SORT_MAX_CHUNKS sorted chunks in ONE workgroup (it used to be one launch per pass plus
+// one for the long lists: three launches of ~5-10 us, most of it launch latency, for the ~100 lists per frame that have
+// more than one chunk): the runs are staged in LDS once (2 x 64 KiB, ping-pong), every thread takes 8 consecutive outputs of
+// a level (merge path), the last level writes point_list. Lists beyond SORT_MAX_CHUNKS chunks (none in avatar scenes) take
+// the whole-list path in the same launch, runs merged through HBM.
+constexpr int MERGE_WG = 1024;
+constexpr int MERGE_KEYS = SORT_MAX_CHUNKS * SORT_CHUNK;         // 8192 = SORT_CAP
+static_assert(MERGE_KEYS == SORT_CAP && MERGE_KEYS == 8 * MERGE_WG, "one 8-key window per thread, LDS image = the long path's");
+__global__ void __launch_bounds__(MERGE_WG)
+tile_merge_all_kernel(int T, int ordered, int64_t max_pairs, const uint32_t* __restrict__ tile_order,
                       const uint32_t* __restrict__ tile_offset, uint64_t* __restrict__ pair_key,
                       uint64_t* __restrict__ pair_tmp, uint32_t* __restrict__ point_list, size_t ws_stride) {
-  __shared__ uint64_t s_key[SORT_CAP];
+  extern __shared__ uint64_t s_merge[];                      // [2][MERGE_KEYS]
   GSR_FRAME_PTRS();
+  const int tid = threadIdx.x;
   for (int rank = blockIdx.x; rank < T; rank += gridDim.x) {
     const TileSpan ts = tile_span(tile_order, tile_offset, max_pairs, rank);
-    if (ts.n < SORT_MAX_CHUNKS * SORT_CHUNK && ordered) break;         // a lower size class: no long list follows
-    if (ts.n <= SORT_MAX_CHUNKS * SORT_CHUNK) continue;
+    if (ts.n <= SORT_CHUNK) { if (ordered) break; continue; }      // one run (and, in size order, so is every later list)
+    __syncthreads();                                          // the previous list's LDS image is dead
+    if (ts.n > MERGE_KEYS) {
+      sort_tile_whole<MERGE_WG>((int)tile_order[rank], max_pairs, tile_offset, pair_key, pair_tmp, point_list, s_merge, tid);
+      continue;
+    }
+    const int n = ts.n;
+    uint64_t* src = s_merge;
+    uint64_t* dst = s_merge + MERGE_KEYS;
+    for (int i = tid; i < n; i += MERGE_WG) src[i] = pair_key[ts.start + i];
     __syncthreads();
-    sort_tile_whole<1024>((int)tile_order[rank], max_pairs, tile_offset, pair_key, pair_tmp, point_list, s_key,
-                          threadIdx.x);
+    const int g0 = tid * 8;
+    for (int W = SORT_CHUNK; W < n; W <<= 1) {
+      const bool last = 2 * W >= n;                           // this level leaves one run = the sorted list
+      if (g0 < n) {
+        const int lo = (g0 / (2 * W)) * (2 * W);
+        const int mid = min(lo + W, n), hi = min(lo + 2 * W, n);
+        const uint64_t* A = src + lo;
+        const uint64_t* B = src + mid;
+        const int na = mid - lo, nb = hi - mid;
+        int ia = merge_split(A, na, B, nb, g0 - lo);
+        int ib = g0 - lo - ia;
+        const int cnt = min(8, hi - g0);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+          if (o < cnt) {
+            const bool takeA = (ib >= nb) || (ia < na && A[ia] <= B[ib]);
+            const uint64_t v = takeA ? A[ia++] : B[ib++];
+            if (last) point_list[ts.start + g0 + o] = (uint32_t)v;
+            else dst[g0 + o] = v;
+          }
+        }
+      }
+      __syncthreads();
+      uint64_t* t = src; src = dst; dst = t;
+    }
   }
 }
 
@@ -510,14 +502,16 @@ hipError_t launch_binning(const Dims& d, const Workspace& ws, const Batch& bt, h
       hipLaunchKernelGGL(tile_sort_chunk_kernel, dim3(gx, bt.frames, SORT_MAX_CHUNKS), dim3(CHUNK_WG), 0, stream, d.T,
                          ordered, d.max_pairs, ws.tile_count, ws.tile_offset, ws.pair_key, ws.pair_tmp, ws.point_list,
                          bt.ws_stride);
-      hipLaunchKernelGGL(tile_merge_kernel<0>, dim3(gx, bt.frames, SORT_MAX_CHUNKS / 2), dim3(SORT_WG), 0, stream, d.T,
-                         ordered, d.max_pairs, ws.tile_count, ws.tile_offset, ws.pair_key, ws.pair_tmp, ws.point_list,
-                         bt.ws_stride);
-      hipLaunchKernelGGL(tile_merge_kernel<1>, dim3(gx, bt.frames, SORT_MAX_CHUNKS / 4), dim3(SORT_WG), 0, stream, d.T,
-                         ordered, d.max_pairs, ws.tile_count, ws.tile_offset, ws.pair_key, ws.pair_tmp, ws.point_list,
-                         bt.ws_stride);
-      hipLaunchKernelGGL(tile_sort_long_kernel, dim3(min(d.T, 64), bt.frames), dim3(1024), 0, stream, d.T, ordered, d.max_pairs,
-                         ws.tile_count, ws.tile_offset, ws.pair_key, ws.pair_tmp, ws.point_list, bt.ws_stride);
+      static PerDeviceFlag attr_set;
+      constexpr size_t merge_lds = (size_t)2 * MERGE_KEYS * sizeof(uint64_t);
+      if (!attr_set) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_merge_all_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)merge_lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(tile_merge_all_kernel, dim3(min(d.T, 256), bt.frames), dim3(MERGE_WG), merge_lds, stream, d.T, ordered,
+                         d.max_pairs, ws.tile_count, ws.tile_offset, ws.pair_key, ws.pair_tmp, ws.point_list, bt.ws_stride);
     }
     e = hipGetLastError();
   }
