@@ -7,9 +7,13 @@ from gaussianavatar_amd.losses import l1_loss_w, ssim
 
 torch.manual_seed(0)
 B = 2
-mp, npar, op = default_params(batch_size=B, num_points=200_000, image_width=1024, image_height=1024, num_frames=16)
+STAGE = int(os.environ.get("STAGE", 1))      # STAGE=2: the stage-2 iteration (pose-encoder UNet + per-frame decoder)
+mp, npar, op = default_params(batch_size=B, num_points=200_000, image_width=1024, image_height=1024, num_frames=16, train_stage=STAGE)
 model = AvatarModel(mp, npar, op, train=True)
 model.training_setup()
+if STAGE == 2:
+    with torch.no_grad():
+        model.net.decoder.conv8N.weight.mul_(0.01); model.net.decoder.conv8N.bias.fill_(-5.65)
 ds = model.train_dataset
 dev = torch.device("cuda")
 batches = [collate_frames([ds[(s * B + k) % len(ds)] for k in range(B)], dev) for s in range(8)]
@@ -22,9 +26,15 @@ def sync():
     torch.cuda.synchronize(); return time.perf_counter()
 for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 80):
     t0 = sync()
-    image, points, offset_loss, geo_loss, scale_loss = model.train_stage1(batches[i % 8], 7)
+    if STAGE == 2:
+        image, points, pose_loss, offset_loss = model.train_stage2(batches[i % 8], 7)
+    else:
+        image, points, offset_loss, geo_loss, scale_loss = model.train_stage1(batches[i % 8], 7)
     t1 = sync()
-    loss = 0.8 * l1_loss_w(image, gt) + 0.2 * (1 - ssim(image, gt)) + offset_loss + geo_loss + scale_loss
+    if STAGE == 2:
+        loss = 0.8 * l1_loss_w(image, gt) + 0.2 * (1 - ssim(image, gt)) + offset_loss + 10 * pose_loss
+    else:
+        loss = 0.8 * l1_loss_w(image, gt) + 0.2 * (1 - ssim(image, gt)) + offset_loss + geo_loss + scale_loss
     t2 = sync()
     model.zero_grad(1); loss.backward()
     t3 = sync()
