@@ -33,6 +33,7 @@ class Adam(torch.optim.Adam):
                          fused=False)
         self._table = (_native.GanetAdamTensor * 64)()
         self.skip_on_overflow = True      # read the rasterizer's overflow flag (see the module docstring)
+        self._layout_checked = set()      # parameters whose layout (and whose moments' layout) has been verified
 
     def zero_grad(self, set_to_none: bool = True):
         super().zero_grad(set_to_none=set_to_none)
@@ -93,14 +94,16 @@ class Adam(torch.optim.Adam):
                 st["step"] = shared
                 # the update is element-wise over memory: parameter, gradient and moments must be dense and share
                 # ONE layout (row-major or channels-last; the moments are created with the parameter's)
-                if not (p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))):
-                    raise RuntimeError("gaussianavatar_amd.optim.Adam: parameters must be dense (contiguous or channels-last)")
-                if not _same_layout(g, p):
+                if g.stride() != p.stride() and not _same_layout(g, p):      # (tuple compare first: this runs per tensor and step)
                     g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
                     p.grad = g
-                for key in ("exp_avg", "exp_avg_sq"):      # (a checkpoint written with another layout)
-                    if not _same_layout(st[key], p):
-                        st[key] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st[key])
+                if p not in self._layout_checked:          # once per parameter (and again after load_state_dict)
+                    if not (p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))):
+                        raise RuntimeError("gaussianavatar_amd.optim.Adam: parameters must be dense (contiguous or channels-last)")
+                    for key in ("exp_avg", "exp_avg_sq"):  # (a checkpoint written with another layout)
+                        if not _same_layout(st[key], p):
+                            st[key] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st[key])
+                    self._layout_checked.add(p)
                 if stream is None:
                     stream = torch.cuda.current_stream(p.device).cuda_stream
                     skip = self._skip_flag(p.device)
@@ -128,6 +131,7 @@ class Adam(torch.optim.Adam):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
+        self._layout_checked.clear()
         for group in self.param_groups:
             group.pop("_shared_step", None)
         for st in self.state.values():
