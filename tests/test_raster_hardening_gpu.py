@@ -341,3 +341,47 @@ def test_more_than_8192_tiles_long_lists_and_debug_backward(raster_oracle, sprea
         bar = 2e-3 * (np.abs(want).max() + 1e-12)
         assert np.abs(a.cpu().numpy() - want).max() <= bar, ("debug", key)
         assert np.abs(c.cpu().numpy() - want).max() <= bar, ("default", key)
+
+
+def test_list_lengths_on_every_sort_boundary(raster_oracle):
+    """Tile lists of exactly 2047 / 2048 / 2049 / 4095 / 4096 / 4097 / 6144 / 6145 / 8191 / 8192 / 8193 / 10000 entries: one
+    chunk, two .. four chunks with full and one-key last chunks (the one-launch merge, gsr_binning.hip), and the long-list path —
+    every length at which the sort changes its decomposition. Tiny Gaussians placed inside chosen tiles (each touches exactly its
+    tile), depths random with some exact ties; lists, ranges and image against the oracle as everywhere."""
+    W = H = 128
+    sizes = [2047, 2048, 2049, 4095, 4096, 4097, 6144, 6145, 8191, 8192, 8193, 10000]
+    sc = random_scene(4, W, H, seed=3, kind="avatar", scale_med=1e-4)
+    rng = np.random.default_rng(17)
+    # the pixel of a world point (row-vector convention of the scene's matrices); at fixed z the map is nearly affine in (x, y)
+    def pixels(pts):
+        hom = np.concatenate([pts, np.ones((len(pts), 1), np.float32)], 1) @ sc["projmatrix"].astype(np.float32)
+        return np.stack([((hom[:, 0] / hom[:, 3] + 1.0) * W - 1.0) * 0.5, ((hom[:, 1] / hom[:, 3] + 1.0) * H - 1.0) * 0.5], 1)
+    probe = pixels(np.array([[0, 0.3, 0], [1, 0.3, 0], [0, 1.3, 0]], np.float32)).astype(np.float64)
+    A = np.stack([probe[1] - probe[0], probe[2] - probe[0]], 1)                # d pixel / d (x, y)
+    Ainv = np.linalg.inv(A)
+    cand, picks, at = [], [], 0
+    for n, t in zip(sizes, [9, 11, 13, 18, 20, 22, 25, 27, 29, 34, 36, 38]):      # twelve tiles of the 8 x 8 grid
+        want = np.stack([(t % 8) * 16 + rng.uniform(5.5, 10.5, 2 * n), (t // 8) * 16 + rng.uniform(5.5, 10.5, 2 * n)], 1)
+        xy = (want - probe[0]) @ Ainv.T + np.array([0.0, 0.3])
+        z = rng.uniform(-0.02, 0.02, (2 * n, 1))
+        for _ in range(4):                                                     # (the map is only nearly affine: refine)
+            xy = xy + (want - pixels(np.concatenate([xy, z], 1).astype(np.float32))) @ Ainv.T
+        pts = np.concatenate([xy, z], 1).astype(np.float32)
+        pix = pixels(pts)
+        ok = ((pix[:, 0] % 16 > 4) & (pix[:, 0] % 16 < 12) & (pix[:, 1] % 16 > 4) & (pix[:, 1] % 16 < 12) &
+              (pix[:, 0] // 16 == t % 8) & (pix[:, 1] // 16 == t // 8))          # radius 2 stays inside the tile
+        assert ok.sum() >= n, (t, int(ok.sum()))
+        cand.append(pts[ok][:n])
+        picks.append(np.arange(at, at + n))
+        at += n
+    cand = np.concatenate(cand)
+    idx = rng.permutation(np.concatenate(picks))
+    P = len(idx)
+    means = cand[idx].copy()
+    means[1::97, 2] = means[0:len(means[1::97]) * 97:97, 2][:len(means[1::97])]     # some exact depth ties (same z, other xy)
+    sc.update(P=P, means3D=means, colors=rng.uniform(0, 1, (P, 3)).astype(np.float32),
+              opacities=rng.uniform(0.01, 0.05, P).astype(np.float32), scales=np.full((P, 3), 1e-4, np.float32),
+              rotations=np.tile(np.array([1, 0, 0, 0], np.float32), (P, 1)))
+    ref, got = assert_forward_parity(raster_oracle, sc)
+    lens = np.sort(ref["ranges"][:, 1].astype(np.int64) - ref["ranges"][:, 0].astype(np.int64))[-len(sizes):]
+    assert lens.tolist() == sorted(sizes), lens
