@@ -73,11 +73,17 @@ conv5_pack_kernel(PackJobs jobs, u32x4* __restrict__ packed) {
 // development (tools/conv_trace.py): s_memtime stamps of waves 0 and 7 of block 0, s_memrealtime start / end per block
 __device__ unsigned long long g_conv_trace[2][8];
 __device__ unsigned long long g_conv_blocks[1024][2];
+__device__ unsigned long long g_wg_trace[2][8];
+__device__ unsigned long long g_wg_blocks[1024][2];
+#define WG_STAMP(I) do { if (blockIdx.x == 0 && blockIdx.y == 2 && lane == 0 && (wave == 0 || wave == 7)) g_wg_trace[wave == 7][I] = __builtin_amdgcn_s_memtime(); } while (0)
+#define WG_BLOCK(I) do { if (lane == 0 && wave == 0) g_wg_blocks[blockIdx.y * gridDim.x + blockIdx.x][I] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define CONV_STAMP(I) do { if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 7)) g_conv_trace[wave == 7][I] = __builtin_amdgcn_s_memtime(); } while (0)
 #define CONV_BLOCK(I) do { if (lane == 0 && wave == 0 && blockIdx.x < 1024) g_conv_blocks[blockIdx.x][I] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define CONV_STAMP(I) do {} while (0)
 #define CONV_BLOCK(I) do {} while (0)
+#define WG_STAMP(I) do {} while (0)
+#define WG_BLOCK(I) do {} while (0)
 #endif
 
 constexpr int WGC = 512;                                 // 8 waves: (32-channel half of the output) x (quarter of a tap's 64 k)
@@ -222,6 +228,7 @@ conv5_wgrad_kernel(int H, int W, int total_runs, const float* __restrict__ x, co
   const int dy = blockIdx.y;
   const int runs_per_row = W / 16;
   const int g0 = blockIdx.x * WG_STEPS + grp, g1 = min((int)(blockIdx.x + 1) * WG_STEPS, total_runs);
+  WG_BLOCK(0); WG_STAMP(0);
 
   f32x16 acc[5];
 #pragma unroll
@@ -274,6 +281,7 @@ conv5_wgrad_kernel(int H, int W, int total_runs, const float* __restrict__ x, co
   Raw ring[3];
   load(g0, ring[0]);
   load(g0 + 2, ring[1]);
+  WG_STAMP(1);
   for (int g = g0; g < g1; g += 6) {
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
@@ -283,13 +291,16 @@ conv5_wgrad_kernel(int H, int W, int total_runs, const float* __restrict__ x, co
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  WG_STAMP(2);
   if (grp == 1) {
 #pragma unroll
     for (int d = 0; d < 5; ++d)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s_wg[((w4 * 5 + d) * 16 + r) * 64 + lane] = acc[d][r];
   }
+  WG_STAMP(3);
   __syncthreads();
+  WG_STAMP(4);
   if (grp == 0) {
     // partial[chunk][dy][dx][n][k]
     float* out = partial + (((size_t)blockIdx.x * 5 + dy) * 5) * C * C;
@@ -301,6 +312,7 @@ conv5_wgrad_kernel(int H, int W, int total_runs, const float* __restrict__ x, co
         out[((size_t)d * C + n) * C + kt * 32 + li] = acc[d][r] + s_wg[((w4 * 5 + d) * 16 + r) * 64 + lane];
       }
   }
+  WG_STAMP(5); WG_BLOCK(1);
 }
 
 // dW[n][k][dy][dx] = sum over chunks of partial[chunk][dy][dx][n][k]
@@ -330,6 +342,10 @@ bool shape_ok(int b, int H, int W) { return b > 0 && H > 0 && W > 0 && (W % 64) 
 using namespace ganet;
 
 #ifdef GANET_CONV_TRACE
+extern "C" int ganet_dev_wgrad_trace(void* tr, void* bl) {
+  if (hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_wg_trace), sizeof(g_wg_trace)) != hipSuccess) return 1;
+  return (int)hipMemcpyFromSymbol(bl, HIP_SYMBOL(g_wg_blocks), sizeof(g_wg_blocks));
+}
 extern "C" int ganet_dev_conv_trace(void* tr, void* bl) {
   if (hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_conv_trace), sizeof(g_conv_trace)) != hipSuccess) return 1;
   return (int)hipMemcpyFromSymbol(bl, HIP_SYMBOL(g_conv_blocks), sizeof(g_conv_blocks));
