@@ -240,6 +240,60 @@ def plumbing_config1(budget_s: float = 10.0) -> dict:
                              "sample": f"{n} iterations, {el:.1f} s wall, {best[0]} of {cores} host threads; CPU: {_cpu_model()}"}}
 
 
+_TRAFFIC_FAMILIES = {   # kernel-name substring -> family key (tools/traffic_json.py)
+    "layer_bwd_spec_kernel<false, true, 128>": "layer_bwd", "render_bwd_kernel": "render_bwd",
+    "layer_fwd_spec_kernel<1>": "layer_fwd", "render_fwd_kernel": "render_fwd",
+}
+
+
+def measure_traffic(args):
+    """HBM-side traffic per launch of the families the bench line prices, measured NOW: two short rocprofv3 passes of this
+    same workload (--pmc FETCH_SIZE, --pmc WRITE_SIZE: the TCC counters do not fit one pass; with --kernel-trace only),
+    mean over the second half of each kernel's launches. Returns {family: {fetch_kb, write_kb}} or None (rocprofv3 missing,
+    a pass failed or timed out: the caller then cites the committed summary)."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "6", "--warmup", "4",
+             "--points", str(args.points), "--size", str(args.size), "--height", str(args.height),
+             "--frames-per-gpu", str(args.frames_per_gpu), "--stage", str(args.stage), "--smpl-type", args.smpl_type,
+             "--uv", str(args.uv), "--iteration", str(args.iteration), "--no-cpu-baseline", "--no-kernel-events",
+             "--no-fixed-batch", "--no-secondary", "--no-measure-traffic"]
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="ga_traffic_", dir="/tmp")
+    try:
+        for counter, key in (("FETCH_SIZE", "fetch_kb"), ("WRITE_SIZE", "write_kb")):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + child
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+                env.pop(k, None)
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240,
+                               check=True, start_new_session=True)
+            except (subprocess.SubprocessError, OSError):
+                return None
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None
+            vals = {}
+            with open(files[0]) as f:
+                for r in csv.DictReader(f):
+                    if r.get("Counter_Name") != counter:
+                        continue
+                    for sub, fam in _TRAFFIC_FAMILIES.items():
+                        if sub in r["Kernel_Name"]:
+                            vals.setdefault(fam, []).append(float(r["Counter_Value"]))
+                            break
+            for fam, v in vals.items():
+                tail = v[len(v) // 2:]
+                out.setdefault(fam, {})[key] = sum(tail) / len(tail)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {k: v for k, v in out.items() if "fetch_kb" in v and "write_kb" in v} or None
+
+
 def _traffic_file():
     """The newest committed PMC-traffic summary (profiles/rNN_traffic.json; tools/pmc_traffic.sh writes them)."""
     import glob
@@ -409,6 +463,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the second short measurement of the default line: the stage-2 iteration (secondary)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-measure-traffic", action="store_true",
+                    help="do not re-measure roofline.traffic with two short rocprofv3 --pmc passes of this workload after "
+                         "the timed run (N = 1, when rocprofv3 is on PATH; ~1 min); the committed profiles/rNN_traffic.json is cited instead")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket rasterizer kernels with HIP events in the timed region")
     args = ap.parse_args()
@@ -598,6 +655,15 @@ def main():
                        "fp32 product accumulated in fp32 (csrc/ganet_split.h; error vs float64 ~4e-7 of the tensor's "
                        "max, tests/test_fused_gpu.py::test_split_mfma_is_fp32_accurate)")},
     }
+    # HBM-side traffic (PMC counters) of the priced families: re-measured right now when rocprofv3 is here, else the
+    # committed summary of the same command is cited (labelled either way)
+    fresh_traffic = None
+    if probe and world == 1 and rank == 0 and not args.no_measure_traffic:
+        torch.cuda.synchronize()
+        fresh_traffic = measure_traffic(args)
+    fresh_note = ("two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only) of this workload, run by this "
+                  "invocation right after its timed region (bench.measure_traffic: 6 steps each, mean over the second half of "
+                  "the launches); 2*FETCH+WRITE (gfx950 wide-read correction)")
     if probe:
         # one launch of every rasterizer kernel processes all B frames of the rank's batch
         alg = {k: v * B for k, v in algorithmic_bytes(N, mean_pairs, H * W).items()}
@@ -642,7 +708,13 @@ def main():
             # HBM bytes of one 128->128 launch of this family (PMC passes committed under profiles/)
             traffic, traffic_note = None, None
             tpath = _traffic_file()
-            if tpath:
+            if fresh_traffic and dom_family in fresh_traffic:
+                t = fresh_traffic[dom_family]
+                traffic = (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0
+                traffic_note = ("HBM bytes of one 128->128 launch (M = 262,144) of this family, measured in this run: " + fresh_note +
+                                "; the algorithmic traffic of that launch is 4 x 134 MB of activations + 17 MB of partial "
+                                "weight-gradient tiles")
+            elif tpath:
                 t = json.load(open(tpath)).get(dom_family)
                 if t:
                     traffic = (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0
@@ -694,7 +766,11 @@ def main():
             rb = kern["render_bwd"]
             traffic, traffic_note = None, None
             tpath = _traffic_file()
-            if tpath and (N, H, B) == (200_000, 1024, 2):
+            if fresh_traffic and "render_bwd" in fresh_traffic:
+                t = fresh_traffic["render_bwd"]
+                traffic = (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0
+                traffic_note = "measured in this run: " + fresh_note
+            elif tpath and (N, H, B) == (200_000, 1024, 2):
                 t = json.load(open(tpath)).get("render_bwd")
                 if t:
                     traffic = (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0
