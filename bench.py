@@ -255,6 +255,9 @@ def measure_traffic(args):
     exe = shutil.which("rocprofv3")
     if not exe:
         return None
+    # this process is itself being profiled (rocprofv3 -- python bench.py ...): no profiler inside a profiler
+    if any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
     child = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "6", "--warmup", "4",
              "--points", str(args.points), "--size", str(args.size), "--height", str(args.height),
              "--frames-per-gpu", str(args.frames_per_gpu), "--stage", str(args.stage), "--smpl-type", args.smpl_type,
