@@ -363,8 +363,11 @@ __device__ __forceinline__ void sort_tile_whole(int tile, int64_t cap, const uin
 // several per CU), and a list's sorted runs are merged with merge path inside LDS by one workgroup — two levels cover 4
 // chunks (tile_merge_all_kernel); longer lists (none in avatar scenes) take the one-workgroup path with runs merged through HBM. The order is
 // the same total order (depth bits, then Gaussian index), whatever the decomposition.
-constexpr int SORT_CHUNK = 2048;
-constexpr int SORT_MAX_CHUNKS = 4;
+#ifndef GSR_SORT_CHUNK
+#define GSR_SORT_CHUNK 2048      // (tools/build_gsr_variant.sh -DGSR_SORT_CHUNK=1024: measured in round 4)
+#endif
+constexpr int SORT_CHUNK = GSR_SORT_CHUNK;
+constexpr int SORT_MAX_CHUNKS = 8192 / SORT_CHUNK;      // the merge launch stages a whole list: <= 8192 keys of LDS per buffer
 
 struct TileSpan { int64_t start; int n; };
 __device__ __forceinline__ TileSpan tile_span(const uint32_t* tile_order, const uint32_t* tile_offset, int64_t cap,
@@ -438,7 +441,9 @@ tile_merge_all_kernel(int T, int ordered, int64_t max_pairs, const uint32_t* __r
   const int tid = threadIdx.x;
   for (int rank = blockIdx.x; rank < T; rank += gridDim.x) {
     const TileSpan ts = tile_span(tile_order, tile_offset, max_pairs, rank);
-    if (ts.n <= SORT_CHUNK) { if (ordered) break; continue; }      // one run (and, in size order, so is every later list)
+    // one run: nothing to merge. The order is by size CLASS (1 + floor(log2 n), tile_scan_kernel): a list of exactly
+    // SORT_CHUNK keys shares its class with lists that do need merging, so only a list BELOW that class ends the walk
+    if (ts.n <= SORT_CHUNK) { if (ordered && ts.n < SORT_CHUNK) break; continue; }
     __syncthreads();                                          // the previous list's LDS image is dead
     if (ts.n > MERGE_KEYS) {
       sort_tile_whole<MERGE_WG>((int)tile_order[rank], max_pairs, tile_offset, pair_key, pair_tmp, point_list, s_merge, tid);

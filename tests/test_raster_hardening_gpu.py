@@ -343,45 +343,61 @@ def test_more_than_8192_tiles_long_lists_and_debug_backward(raster_oracle, sprea
         assert np.abs(c.cpu().numpy() - want).max() <= bar, ("default", key)
 
 
-def test_list_lengths_on_every_sort_boundary(raster_oracle):
-    """Tile lists of exactly 2047 / 2048 / 2049 / 4095 / 4096 / 4097 / 6144 / 6145 / 8191 / 8192 / 8193 / 10000 entries: one
-    chunk, two .. four chunks with full and one-key last chunks (the one-launch merge, gsr_binning.hip), and the long-list path —
-    every length at which the sort changes its decomposition. Tiny Gaussians placed inside chosen tiles (each touches exactly its
-    tile), depths random with some exact ties; lists, ranges and image against the oracle as everywhere."""
-    W = H = 128
-    sizes = [2047, 2048, 2049, 4095, 4096, 4097, 6144, 6145, 8191, 8192, 8193, 10000]
+def _scene_with_tile_lists(W, H, tile_sizes, seed=17):
+    """A scene whose tile `t` (row-major index on the 16-pixel grid) holds exactly `tile_sizes[t]` Gaussians: tiny ones placed
+    inside the tile (radius 2 px, centres 5.5 .. 10.5 px from the tile's corner: each touches exactly its tile), depths random
+    with some exact ties."""
+    gx = (W + 15) // 16
     sc = random_scene(4, W, H, seed=3, kind="avatar", scale_med=1e-4)
-    rng = np.random.default_rng(17)
+    rng = np.random.default_rng(seed)
+
     # the pixel of a world point (row-vector convention of the scene's matrices); at fixed z the map is nearly affine in (x, y)
     def pixels(pts):
         hom = np.concatenate([pts, np.ones((len(pts), 1), np.float32)], 1) @ sc["projmatrix"].astype(np.float32)
         return np.stack([((hom[:, 0] / hom[:, 3] + 1.0) * W - 1.0) * 0.5, ((hom[:, 1] / hom[:, 3] + 1.0) * H - 1.0) * 0.5], 1)
     probe = pixels(np.array([[0, 0.3, 0], [1, 0.3, 0], [0, 1.3, 0]], np.float32)).astype(np.float64)
-    A = np.stack([probe[1] - probe[0], probe[2] - probe[0]], 1)                # d pixel / d (x, y)
-    Ainv = np.linalg.inv(A)
-    cand, picks, at = [], [], 0
-    for n, t in zip(sizes, [9, 11, 13, 18, 20, 22, 25, 27, 29, 34, 36, 38]):      # twelve tiles of the 8 x 8 grid
-        want = np.stack([(t % 8) * 16 + rng.uniform(5.5, 10.5, 2 * n), (t // 8) * 16 + rng.uniform(5.5, 10.5, 2 * n)], 1)
-        xy = (want - probe[0]) @ Ainv.T + np.array([0.0, 0.3])
-        z = rng.uniform(-0.02, 0.02, (2 * n, 1))
-        for _ in range(4):                                                     # (the map is only nearly affine: refine)
-            xy = xy + (want - pixels(np.concatenate([xy, z], 1).astype(np.float32))) @ Ainv.T
-        pts = np.concatenate([xy, z], 1).astype(np.float32)
-        pix = pixels(pts)
-        ok = ((pix[:, 0] % 16 > 4) & (pix[:, 0] % 16 < 12) & (pix[:, 1] % 16 > 4) & (pix[:, 1] % 16 < 12) &
-              (pix[:, 0] // 16 == t % 8) & (pix[:, 1] // 16 == t // 8))          # radius 2 stays inside the tile
-        assert ok.sum() >= n, (t, int(ok.sum()))
-        cand.append(pts[ok][:n])
-        picks.append(np.arange(at, at + n))
-        at += n
-    cand = np.concatenate(cand)
-    idx = rng.permutation(np.concatenate(picks))
-    P = len(idx)
-    means = cand[idx].copy()
+    Ainv = np.linalg.inv(np.stack([probe[1] - probe[0], probe[2] - probe[0]], 1))      # d (x, y) / d pixel
+    tiles = np.concatenate([np.full(n, t, np.int64) for t, n in tile_sizes.items()])
+    P = len(tiles)
+    want = np.stack([(tiles % gx) * 16 + rng.uniform(5.5, 10.5, P), (tiles // gx) * 16 + rng.uniform(5.5, 10.5, P)], 1)
+    xy = (want - probe[0]) @ Ainv.T + np.array([0.0, 0.3])
+    z = rng.uniform(-0.02, 0.02, (P, 1))
+    for _ in range(4):                                                         # (the map is only nearly affine: refine)
+        xy = xy + (want - pixels(np.concatenate([xy, z], 1).astype(np.float32))) @ Ainv.T
+    means = np.concatenate([xy, z], 1).astype(np.float32)
+    pix = pixels(means)
+    ok = ((pix[:, 0] % 16 > 4) & (pix[:, 0] % 16 < 12) & (pix[:, 1] % 16 > 4) & (pix[:, 1] % 16 < 12) &
+          (pix[:, 0] // 16 == tiles % gx) & (pix[:, 1] // 16 == tiles // gx))
+    assert ok.all(), int((~ok).sum())
+    means = means[rng.permutation(P)]
     means[1::97, 2] = means[0:len(means[1::97]) * 97:97, 2][:len(means[1::97])]     # some exact depth ties (same z, other xy)
     sc.update(P=P, means3D=means, colors=rng.uniform(0, 1, (P, 3)).astype(np.float32),
               opacities=rng.uniform(0.01, 0.05, P).astype(np.float32), scales=np.full((P, 3), 1e-4, np.float32),
               rotations=np.tile(np.array([1, 0, 0, 0], np.float32), (P, 1)))
+    return sc
+
+
+def test_list_lengths_on_every_sort_boundary(raster_oracle):
+    """Tile lists of exactly 2047 / 2048 / 2049 / 4095 / 4096 / 4097 / 6144 / 6145 / 8191 / 8192 / 8193 / 10000 entries: one
+    chunk, two .. four chunks with full and one-key last chunks (the one-launch merge, gsr_binning.hip), and the long-list path —
+    every length at which the sort changes its decomposition. Lists, ranges and image against the oracle as everywhere."""
+    sizes = [2047, 2048, 2049, 4095, 4096, 4097, 6144, 6145, 8191, 8192, 8193, 10000]
+    sc = _scene_with_tile_lists(128, 128, dict(zip([9, 11, 13, 18, 20, 22, 25, 27, 29, 34, 36, 38], sizes)))
     ref, got = assert_forward_parity(raster_oracle, sc)
     lens = np.sort(ref["ranges"][:, 1].astype(np.int64) - ref["ranges"][:, 0].astype(np.int64))[-len(sizes):]
     assert lens.tolist() == sorted(sizes), lens
+
+
+def test_a_list_of_exactly_one_chunk_does_not_end_the_merge_walk(raster_oracle):
+    """The sort and merge grids walk the tiles in order of size CLASS (1 + floor(log2 n)) and stop at the first list that needs
+    no work. A list of exactly 2048 keys needs no merge but shares its class with lists of 2049 .. 4095 keys that do: a
+    workgroup that met it first used to end its walk and leave its later lists unmerged (found in round 4 with a 1024-key
+    chunk build: a memory fault in render_fwd; with 2048-key chunks it takes more than 256 multi-chunk lists). Here: 700
+    lists of 2049 .. 2060 keys and 40 of exactly 2048, i.e. every merge workgroup walks three ranks of that class."""
+    W = H = 512
+    rng = np.random.default_rng(5)
+    interior = [ty * 32 + tx for ty in range(1, 31) for tx in range(1, 31)]          # 900 tiles away from the border
+    chosen = rng.permutation(interior)[:740]
+    tile_sizes = {int(t): (2048 if i < 40 else int(rng.integers(2049, 2061))) for i, t in enumerate(chosen)}
+    sc = _scene_with_tile_lists(W, H, tile_sizes, seed=23)
+    assert_forward_parity(raster_oracle, sc)
