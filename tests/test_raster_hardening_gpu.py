@@ -401,3 +401,14 @@ def test_a_list_of_exactly_one_chunk_does_not_end_the_merge_walk(raster_oracle):
     tile_sizes = {int(t): (2048 if i < 40 else int(rng.integers(2049, 2061))) for i, t in enumerate(chosen)}
     sc = _scene_with_tile_lists(W, H, tile_sizes, seed=23)
     assert_forward_parity(raster_oracle, sc)
+
+
+@pytest.mark.parametrize("seed,P,W,H,spread,scale", [(2, 2_000_000, 512, 384, 0.6, 0.0015), (4, 1_500_000, 512, 512, 0.25, 0.001)])
+def test_dense_scenes_with_hundreds_of_multi_chunk_lists(raster_oracle, seed, P, W, H, spread, scale):
+    """Millions of small Gaussians on a small image: 130-280 tile lists above one sort chunk (more than the merge launch has
+    workgroups), 80-110 above 8192 keys (the whole-list path), the longest 15 k / 61 k keys — the decompositions of the tile
+    sort all at once, lists bit-exact against the oracle."""
+    sc = random_scene(P, W, H, seed=seed, kind="avatar", spread=spread, scale_med=scale)
+    ref, got = assert_forward_parity(raster_oracle, sc)
+    ln = ref["ranges"][:, 1].astype(np.int64) - ref["ranges"][:, 0].astype(np.int64)
+    assert (ln > 2048).sum() > 100 and (ln > 8192).sum() > 50
