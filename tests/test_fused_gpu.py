@@ -255,7 +255,11 @@ def test_wgrad_act_matches_torch(M, N, K, act, row_order):
 
 
 @pytest.mark.parametrize("M,one_pass,native", [(20000, False, False), (4099, False, False), (20000 // 32 * 32, True, False),
-                                               (20000 // 32 * 32, True, True), (262144, True, True)])
+                                               (20000 // 32 * 32, True, True), (262144, True, True),
+                                               # the three-branch conv6 forward launch: its smallest M (80 slabs: one round),
+                                               # one slab more, a slab count that is not a multiple of its 80 workgroups per
+                                               # branch, and one slab below its minimum (the single-branch launches)
+                                               (2560, True, True), (2592, True, True), (7712, True, True), (2528, True, True)])
 def test_fused_decoder_equals_per_layer_formulation(M, one_pass, native, monkeypatch):
     """The whole-decoder function on the fused layer kernels (reference widths: 66 -> 128 x 5 -> three
     heads) against the per-layer formulation (vendor GEMM + fused BN kernels) on the same device:
