@@ -53,7 +53,7 @@ ProfScope::ProfScope(KernelId id, hipStream_t s) : slot(-1), stream(s) {
   if (!p->free_.empty()) { r = p->free_.back(); p->free_.pop_back(); }
   else { if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return; }
   r.id = id;
-  hipEventRecord(r.start, s);
+  if (hipEventRecord(r.start, s) != hipSuccess) { p->free_.push_back(r); return; }
   p->recs.push_back(r);
   slot = (int)p->recs.size() - 1;
 }
@@ -62,7 +62,7 @@ ProfScope::~ProfScope() {
   GsrProfile* p = t_prof;
   if (slot < 0 || !p) return;
   std::lock_guard<std::mutex> lk(p->mu);
-  if (slot < (int)p->recs.size()) hipEventRecord(p->recs[slot].stop, stream);
+  if (slot < (int)p->recs.size()) (void)hipEventRecord(p->recs[slot].stop, stream);
 }
 
 static inline uint64_t align_up(uint64_t v) { return (v + 255u) & ~(uint64_t)255u; }
@@ -509,7 +509,7 @@ void gsr_profile_destroy(GsrProfile* p) {
   if (!p) return;
   if (t_prof == p) { t_prof = nullptr; t_prof_mask = 0; }
   for (auto* v : {&p->recs, &p->free_})
-    for (auto& r : *v) { hipEventDestroy(r.start); hipEventDestroy(r.stop); }
+    for (auto& r : *v) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
   delete p;
 }
 
