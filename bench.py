@@ -273,9 +273,21 @@ def measure_traffic(args):
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
                 env.pop(k, None)
             try:
-                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120,
-                               check=True, start_new_session=True)
-            except (subprocess.SubprocessError, OSError):
+                proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                        start_new_session=True)
+            except OSError:
+                return None
+            try:
+                rc = proc.wait(timeout=120)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)      # the profiler AND the bench it runs (its own session / group)
+                except OSError:
+                    pass
+                proc.wait()
+                return None
+            if rc != 0:
                 return None
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if not files:
