@@ -246,12 +246,27 @@ _TRAFFIC_FAMILIES = {   # kernel-name substring -> family key (tools/traffic_jso
 }
 
 
+def _counter_means(csv_path, counter):
+    """{family: mean of `counter` over the second half of the family's launches} from a rocprofv3 counter_collection CSV."""
+    import csv
+    vals = {}
+    with open(csv_path) as f:
+        for r in csv.DictReader(f):
+            if r.get("Counter_Name") != counter:
+                continue
+            for sub, fam in _TRAFFIC_FAMILIES.items():
+                if sub in r["Kernel_Name"]:
+                    vals.setdefault(fam, []).append(float(r["Counter_Value"]))
+                    break
+    return {fam: sum(v[len(v) // 2:]) / len(v[len(v) // 2:]) for fam, v in vals.items()}
+
+
 def measure_traffic(args):
     """HBM-side traffic per launch of the families the bench line prices, measured NOW: two short rocprofv3 passes of this
     same workload (--pmc FETCH_SIZE, --pmc WRITE_SIZE: the TCC counters do not fit one pass; with --kernel-trace only),
     mean over the second half of each kernel's launches. Returns {family: {fetch_kb, write_kb}} or None (rocprofv3 missing,
     a pass failed or timed out: the caller then cites the committed summary)."""
-    import csv, glob, shutil, subprocess, tempfile
+    import glob, shutil, subprocess, tempfile
     exe = shutil.which("rocprofv3")
     if not exe:
         return None
@@ -292,18 +307,8 @@ def measure_traffic(args):
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if not files:
                 return None
-            vals = {}
-            with open(files[0]) as f:
-                for r in csv.DictReader(f):
-                    if r.get("Counter_Name") != counter:
-                        continue
-                    for sub, fam in _TRAFFIC_FAMILIES.items():
-                        if sub in r["Kernel_Name"]:
-                            vals.setdefault(fam, []).append(float(r["Counter_Value"]))
-                            break
-            for fam, v in vals.items():
-                tail = v[len(v) // 2:]
-                out.setdefault(fam, {})[key] = sum(tail) / len(tail)
+            for fam, mean in _counter_means(files[0], counter).items():
+                out.setdefault(fam, {})[key] = mean
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return {k: v for k, v in out.items() if "fetch_kb" in v and "write_kb" in v} or None
