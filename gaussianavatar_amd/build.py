@@ -49,6 +49,7 @@ LIBS = {
         ("ganet_decoder.hip", []),
         ("ganet_pack.hip", []),
         ("ganet_upsample.hip", []),
+        ("ganet_upz.hip", []),
         ("ganet_conv.hip", []),
         ("ganet_optim.hip", []),
     ],
