@@ -9,8 +9,10 @@ ONE variable, `GA_DEV="key=value,key=value"`, read once at import; without it ev
     row_sweep=0         decoder: every launch sweeps the rows first-to-last (no alternation)
     native_decoder=0    decoder: the per-layer launch sequence from Python instead of one native call each way
     one_pass_backward=0 decoder: separate weight- / data-gradient kernels for the hidden layers
-    decoder_map=0       decoder: the up-sampled input tensor x [M,72] is materialised (ganet_upsample_cat + the KIN = 72
-                        launches) instead of the input GEMMs commuted with the up-sampling (ganet_upz.hip)
+    decoder_map=1       decoder: conv1 / conv5's input half commuted with the bilinear up-sampling (ganet_upz.hip: no
+                        up-sampled input tensor x [M,72], no KIN = 72 launches). Built, parity-green and measured in round 5:
+                        65 us less kernel time per iteration, the same iterations/s (profiles/r05_decoder_map.md) — off by
+                        default until it wins
 """
 from __future__ import annotations
 
@@ -25,7 +27,7 @@ class DevKnobs:
     row_sweep: bool = True
     native_decoder: bool = True
     one_pass_backward: bool = True
-    decoder_map: bool = True
+    decoder_map: bool = False
 
 
 def _parse(text: str) -> DevKnobs:

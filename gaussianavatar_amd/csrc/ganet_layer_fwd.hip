@@ -106,7 +106,17 @@ layer_fwd_spec_kernel(int64_t M, const float* __restrict__ x, const float* __res
   const int64_t nslab = M / FSLAB;
   const int rounds = (int)((nslab + vgrid - 1) / vgrid);
   const int roundsN = (rounds + 3) & ~3;            // both roles run the same number of barriers
-  auto slab_of = [&](int r) -> int64_t { return (int64_t)r * vgrid + vblock; };
+  // ADD (nslab a multiple of 8 vgrid): XCD x (= blockIdx % 8) sweeps its own contiguous eighth of the slabs, so that the
+  // rows of P it gathers are a band of the map that stays in ITS L2 (ganet_upz.hip: upsample_z_fwd_pipe_kernel)
+  const bool banded = ADD && NB == 1 && (vgrid % 8) == 0 && (nslab % vgrid) == 0;
+  const int64_t band0 = banded ? (int64_t)(vblock % 8) * (nslab / 8) : 0;
+  auto slab_of = [&](int r) -> int64_t {
+    if (banded) return r < rounds ? band0 + (int64_t)r * (vgrid / 8) + vblock / 8 : nslab;
+    return (int64_t)r * vgrid + vblock;
+  };
+  // (ADD: letting consecutive rounds of a workgroup walk down the four texel rows that share their row taps — so that
+  // three of four gathers would find their rows of P in the L1 / L2 — measured SLOWER, 102 -> 126 us per launch: the
+  // common front over contiguous rows is what the HBM stream wants)
   auto phys = [&](int64_t slab) -> int64_t {
     const int64_t sl = slab < nslab ? slab : nslab - 1;        // past the end: re-read the last slab (never used)
     return reverse ? nslab - 1 - sl : sl;
@@ -161,7 +171,7 @@ layer_fwd_spec_kernel(int64_t M, const float* __restrict__ x, const float* __res
     };
     // ---- ADD: the gathered term of this lane's 8 columns of row prow. Taps (a round ahead), then the eight 16-byte
     // loads from P, then the combination into the slab's tile region.
-    struct Taps { int q0, q1; float b0, b1, uu, vv; int64_t base0, base1; float a0, a1; };
+    struct Taps { int q0, q1; float b0, b1, uu, vv; int base0, base1; float a0, a1; };      // (32-bit offsets into P: < 2^31 floats)
     struct Gath { f32x4 v[8]; };
     float wu[8], wv[8];
     if (ADD) {
@@ -170,26 +180,31 @@ layer_fwd_spec_kernel(int64_t M, const float* __restrict__ x, const float* __res
     }
     auto issue_taps = [&](Taps& t, int64_t ps) {
       const int S = add.g.S, R = add.g.R;
-      const int64_t SS = (int64_t)S * S;
-      const int64_t m0 = ps * FSLAB;                     // wave-uniform: the slab's first texel
-      const int f = (int)(m0 / SS);
-      const int rem = (int)(m0 - f * SS);
-      const int i = rem / S, j = rem - i * S + prow;
+      // slab ps -> (frame f, texel row i, first texel j) without a 64-bit division (~100 instructions on the producers'
+      // critical path, every round): slabs per row / per frame are small 32-bit numbers, one frame is the common case
+      const int spr = S / FSLAB;                         // slabs per texel row
+      const int psi = (int)ps;                           // (nslab < 2^31)
+      const int grow = (spr & (spr - 1)) == 0 ? psi >> __builtin_ctz(spr) : psi / spr;
+      const int jcol = psi - grow * spr;
+      const int f = add.g.frames == 1 ? 0 : grow / S;
+      const int i = grow - f * S, j = jcol * FSLAB + prow;
       const int2 ri = *reinterpret_cast<const int2*>(add.g.row_idx + 2 * i);
       const float2 rw = *reinterpret_cast<const float2*>(add.g.row_w + 2 * i);
       const int2 ci = *reinterpret_cast<const int2*>(add.g.col_idx + 2 * j);
       const float2 cw = *reinterpret_cast<const float2*>(add.g.col_w + 2 * j);
-      const float2 uvv = *reinterpret_cast<const float2*>(add.g.uv + (int64_t)f * add.g.uv_frame_stride + ((int64_t)i * S + j) * 2);
+      const float2 uvv = *reinterpret_cast<const float2*>(add.g.uv + ((int64_t)f * add.g.uv_frame_stride + (i * S + j) * 2));
       t.q0 = ci.x; t.q1 = ci.y; t.b0 = cw.x; t.b1 = cw.y; t.uu = uvv.x; t.vv = uvv.y;
-      t.base0 = (((int64_t)f * R + ri.x) * R) * add.ldp + 8 * pq;
-      t.base1 = (((int64_t)f * R + ri.y) * R) * add.ldp + 8 * pq;
+      const int ldp = (int)add.ldp;
+      t.base0 = ((f * R + ri.x) * R) * ldp + 8 * pq;
+      t.base1 = ((f * R + ri.y) * R) * ldp + 8 * pq;
       t.a0 = rw.x; t.a1 = rw.y;
     };
     auto issue_gather = [&](Gath& gq, const Taps& t) {
-      const float* p00 = add.P + t.base0 + (int64_t)t.q0 * add.ldp;
-      const float* p01 = add.P + t.base0 + (int64_t)t.q1 * add.ldp;
-      const float* p10 = add.P + t.base1 + (int64_t)t.q0 * add.ldp;
-      const float* p11 = add.P + t.base1 + (int64_t)t.q1 * add.ldp;
+      const int ldp = (int)add.ldp;
+      const float* p00 = add.P + (t.base0 + t.q0 * ldp);
+      const float* p01 = add.P + (t.base0 + t.q1 * ldp);
+      const float* p10 = add.P + (t.base1 + t.q0 * ldp);
+      const float* p11 = add.P + (t.base1 + t.q1 * ldp);
       gq.v[0] = *reinterpret_cast<const f32x4*>(p00); gq.v[1] = *reinterpret_cast<const f32x4*>(p00 + 4);
       gq.v[2] = *reinterpret_cast<const f32x4*>(p01); gq.v[3] = *reinterpret_cast<const f32x4*>(p01 + 4);
       gq.v[4] = *reinterpret_cast<const f32x4*>(p10); gq.v[5] = *reinterpret_cast<const f32x4*>(p10 + 4);
@@ -397,7 +412,7 @@ int layer_fwd_spec_add(int64_t M, const float* x, const float* in_scale, const f
                        int reverse, hipStream_t stream) {
   const UpGrid& g = add.g;
   if (M < FSLAB || (M % FSLAB) != 0 || !aligned16(z) || g.S <= 0 || (g.S % FSLAB) != 0 ||
-      M != (int64_t)g.frames * g.S * g.S || !add.P || (add.ldp % 4) != 0 || !aligned16(add.P) || !add.Wuv) return -1;
+      M != (int64_t)g.frames * g.S * g.S || M >= (int64_t)1 << 31 || (int64_t)g.frames * g.R * g.R * add.ldp >= (int64_t)1 << 31 || !add.P || (add.ldp % 4) != 0 || !aligned16(add.P) || !add.Wuv) return -1;
   FwdBranches br{};
   br.W[0] = W; br.bias[0] = bias; br.z[0] = z; br.col_part[0] = col_part; br.stat_shift[0] = stat_shift;
   return launch_layer_fwd<1, true>(FBLOCKS, M, x, in_scale, in_shift, br, reverse, stream, add);

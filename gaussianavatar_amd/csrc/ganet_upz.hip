@@ -183,22 +183,29 @@ upsample_z_fwd_kernel(UpGrid g, const float* __restrict__ P, int64_t ldp, const 
   }
 }
 
-// The same for S a multiple of 8 (the reference: 512): a wave takes EIGHT consecutive texels of one texel row per step —
-// the row taps are wave-uniform (scalar loads), the sixteen 16-byte loads from P of a step are issued together, and the
-// column taps / uv of the NEXT step are requested before this step's arithmetic. The per-pair kernel above waits out two
-// dependent L2 round trips per kilobyte it writes (measured 74 us for the 134 MB of a 512^2 map, 1.8 TB/s).
-constexpr int UPZ8_WG = 512;      // 8 waves per CU, 16 KB of loads in flight each: registers for two tap sets + 16 P rows
-__global__ void __launch_bounds__(UPZ8_WG)
-upsample_z_fwd8_kernel(UpGrid g, const float* __restrict__ P, int64_t ldp, const float* __restrict__ Wuv,
-                       const float* __restrict__ bias, const float* __restrict__ stat_shift, float* __restrict__ z,
-                       float* __restrict__ col_part) {
-  __shared__ float s_red[UPZ8_WG / 64][2][128];
+// The production form (S even): the per-pair kernel above as a software pipeline. What bounds that kernel is neither
+// the HBM writes (a fill of the same 134 MB takes 23 us) nor its arithmetic, but a wave's serial chain "taps -> four
+// gathers from the L2 / Infinity Cache -> arithmetic -> store" with ONE step in flight: 74 us. Here
+//   * a step's taps are wave-uniform — the two texels of a pair differ only in the half-wave — so they come through the
+//     SCALAR cache (row taps, the column taps and uv of both texels), requested a step ahead, and select by half-wave;
+//   * the four 16-byte gathers of step n + 1 are issued before the arithmetic of step n (two register sets);
+//   * 16 waves per CU.
+// Measured on the way (512^2 map): eight texels per step, taps prefetched, 8 waves per CU: 50 us; the same with the
+// rows of P parked in LDS per 4 x 4 patch (4x fewer gather bytes, 8 waves per CU at 190 registers): 71 us.
+constexpr int UPQ_WG = 1024;
+
+__global__ void __launch_bounds__(UPQ_WG)
+upsample_z_fwd_pipe_kernel(UpGrid g, const float* __restrict__ P, int64_t ldp, const float* __restrict__ Wuv,
+                           const float* __restrict__ bias, const float* __restrict__ stat_shift, float* __restrict__ z,
+                           float* __restrict__ col_part) {
+  __shared__ float s_red[UPQ_WG / 64][2][128];
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int u = lane >> 5, c4 = lane & 31;
   const int S = g.S, R = g.R;
-  const int gpr = S / 8;                               // groups of 8 texels per texel row
-  const int64_t ngroup = (int64_t)g.frames * S * gpr;
+  const int gpr = S / 2;                                // pairs per texel row
+  const int64_t npair = (int64_t)g.frames * S * gpr;
   float wu[4], wv[4], bs[4], sh[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -208,71 +215,113 @@ upsample_z_fwd8_kernel(UpGrid g, const float* __restrict__ P, int64_t ldp, const
     sh[e] = stat_shift ? stat_shift[4 * c4 + e] : 0.f;
   }
   float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
-  struct Taps { int2 ci[4]; float2 cw[4], uv[4]; };
-  // group t -> (frame f, texel row i, first texel j0): wave-uniform
-  auto locate = [&](int64_t t, int& f, int& i, int& j0) {
-    const int64_t row = t / gpr;
-    j0 = (int)(t - row * gpr) * 8;
-    f = (int)(row / S);
-    i = (int)(row - (int64_t)f * S);
+  // Work assignment: XCD x (= blockIdx % 8) owns a contiguous eighth of the texels, its workgroups contiguous ranges in
+  // it, the waves of a workgroup consecutive pairs: the rows of P an XCD gathers are then a band of the map (1 MB of the
+  // 8 MB at 512^2) that stays in ITS L2, each row re-used by the 16 texels under it. With the texels dealt round-robin
+  // over the workgroups every XCD gathers from the WHOLE of P with a re-use distance of four texel rows: half of the
+  // 537 MB of gathers then cross the fabric from the Infinity Cache, next to the 134 MB the kernel writes.
+  const int nb = (int)gridDim.x;
+  const int64_t lblock = (nb % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x;
+  const int64_t ppb = (npair + nb - 1) / nb;            // pairs per workgroup
+  const int64_t first = lblock * ppb, last = first + ppb < npair ? first + ppb : npair;
+  const int64_t stride = UPQ_WG / 64;
+  const int64_t slot0 = first + wave;
+  // everything a step needs that is wave-uniform (scalar registers)
+  struct Geo { int64_t zoff, pb0, pb1; float a0, a1; int q0[2], q1[2]; float b0[2], b1[2], ux[2], uy[2]; };
+  // (no division in the loop: a 64-bit divide is ~100 instructions, more than the step's own arithmetic; the wave's
+  // position advances by `stride` pairs per step)
+  int cur_f, cur_i, cur_j;                              // position of the NEXT geom() call (wave-uniform)
+  {
+    const int64_t pr0 = slot0 < last ? slot0 : (last > 0 ? last - 1 : 0);
+    const int64_t row = pr0 / gpr;
+    cur_j = (int)(pr0 - row * gpr) * 2;
+    cur_f = (int)(row / S);
+    cur_i = (int)(row - (int64_t)cur_f * S);
+  }
+  int64_t cur_pr = slot0;
+  // the row-dependent part (taps of texel row i, bases of its two rows of P) changes once per texel row: 16 steps of a
+  // wave at S = 512 — recomputed only then (the counters showed 92 scalar + 81 vector instructions per step, the SIMDs
+  // 87 % busy issuing: this kernel is issue-bound, not memory-bound)
+  int64_t row_pb0 = 0, row_pb1 = 0, row_z = 0, row_uv = 0;
+  float row_a0 = 0.f, row_a1 = 0.f;
+  auto row_setup = [&]() {
+    const int f = cur_f, i = cur_i;
+    const int p0 = g.row_idx[2 * i], p1 = g.row_idx[2 * i + 1];
+    row_a0 = g.row_w[2 * i]; row_a1 = g.row_w[2 * i + 1];
+    row_pb0 = ((int64_t)f * R + p0) * R * ldp;
+    row_pb1 = ((int64_t)f * R + p1) * R * ldp;
+    row_z = ((int64_t)f * S + i) * S * 128;
+    row_uv = (int64_t)f * g.uv_frame_stride + (int64_t)i * S * 2;
   };
-  auto load_taps = [&](Taps& tp, int64_t t) {
-    int f, i, j0;
-    locate(t < ngroup ? t : ngroup - 1, f, i, j0);
-    const float* uvr = g.uv + (int64_t)f * g.uv_frame_stride + ((int64_t)i * S + j0 + u) * 2;
+  row_setup();
+  auto geom = [&]() {
+    Geo o;
+    const int j0 = cur_j;
+    o.a0 = row_a0; o.a1 = row_a1; o.pb0 = row_pb0; o.pb1 = row_pb1;
+    o.zoff = row_z + (int64_t)j0 * 128;
+    const float* uvp = g.uv + row_uv + j0 * 2;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int j = j0 + 2 * k + u;
-      tp.ci[k] = *reinterpret_cast<const int2*>(g.col_idx + 2 * j);
-      tp.cw[k] = *reinterpret_cast<const float2*>(g.col_w + 2 * j);
-      tp.uv[k] = *reinterpret_cast<const float2*>(uvr + 4 * k);
+    for (int t = 0; t < 2; ++t) {
+      o.q0[t] = g.col_idx[2 * (j0 + t)]; o.q1[t] = g.col_idx[2 * (j0 + t) + 1];
+      o.b0[t] = g.col_w[2 * (j0 + t)]; o.b1[t] = g.col_w[2 * (j0 + t) + 1];
+      o.ux[t] = uvp[2 * t]; o.uy[t] = uvp[2 * t + 1];
     }
-  };
-  const int64_t stride = (int64_t)gridDim.x * (UPZ8_WG / 64);
-  auto step = [&](int64_t t, const Taps& cur, Taps& nxt) {
-    int f, i, j0;
-    locate(t, f, i, j0);
-    const int p0 = g.row_idx[2 * i], p1 = g.row_idx[2 * i + 1];           // scalar loads
-    const float a0 = g.row_w[2 * i], a1 = g.row_w[2 * i + 1];
-    const float* P0 = P + ((int64_t)f * R + p0) * R * ldp + 4 * c4;
-    const float* P1 = P + ((int64_t)f * R + p1) * R * ldp + 4 * c4;
-    float4 v[4][4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      v[k][0] = *reinterpret_cast<const float4*>(P0 + (int64_t)cur.ci[k].x * ldp);
-      v[k][1] = *reinterpret_cast<const float4*>(P0 + (int64_t)cur.ci[k].y * ldp);
-      v[k][2] = *reinterpret_cast<const float4*>(P1 + (int64_t)cur.ci[k].x * ldp);
-      v[k][3] = *reinterpret_cast<const float4*>(P1 + (int64_t)cur.ci[k].y * ldp);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    load_taps(nxt, t + stride);                         // the next step's taps travel while this step computes
-    __builtin_amdgcn_sched_barrier(0);
-    float* zr = z + (((int64_t)f * S + i) * S + j0 + u) * 128 + 4 * c4;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float b0 = cur.cw[k].x, b1 = cur.cw[k].y;
-      float o[4];
-      // same association as the up-sampling of the input tensor (ganet_upsample.hip): columns first, then rows
-      o[0] = a0 * (b0 * v[k][0].x + b1 * v[k][1].x) + a1 * (b0 * v[k][2].x + b1 * v[k][3].x);
-      o[1] = a0 * (b0 * v[k][0].y + b1 * v[k][1].y) + a1 * (b0 * v[k][2].y + b1 * v[k][3].y);
-      o[2] = a0 * (b0 * v[k][0].z + b1 * v[k][1].z) + a1 * (b0 * v[k][2].z + b1 * v[k][3].z);
-      o[3] = a0 * (b0 * v[k][0].w + b1 * v[k][1].w) + a1 * (b0 * v[k][2].w + b1 * v[k][3].w);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        o[e] += fmaf(wu[e], cur.uv[k].x, fmaf(wv[e], cur.uv[k].y, bs[e]));
-        const float d = o[e] - sh[e];
-        cs[e] += d;
-        cq[e] = fmaf(d, d, cq[e]);
+    // advance (past the end of the range: stay on the last pair — a prefetch that is never used)
+    if (cur_pr + stride < last) {
+      cur_pr += stride;
+      cur_j += 2 * (int)stride;
+      if (cur_j >= S) {
+        while (cur_j >= S) { cur_j -= S; if (++cur_i >= S) { cur_i = 0; ++cur_f; } }
+        row_setup();
       }
-      *reinterpret_cast<float4*>(zr + (int64_t)k * 256) = make_float4(o[0], o[1], o[2], o[3]);
     }
+    return o;
   };
-  int64_t t = (int64_t)blockIdx.x * (UPZ8_WG / 64) + wave;
-  Taps ta, tb;                                          // two sets, used alternately (no copy that waits for the loads)
-  load_taps(ta, t);
-  for (; t < ngroup; t += 2 * stride) {
-    step(t, ta, tb);
-    if (t + stride < ngroup) step(t + stride, tb, ta);
+  struct Step { f32x4 v00, v01, v10, v11; float w00, w01, w10, w11, ux, uy; int64_t zoff; };
+  auto issue = [&](Step& st, const Geo& o) {            // this lane's texel = j0 + u
+    const int q0 = u ? o.q0[1] : o.q0[0], q1 = u ? o.q1[1] : o.q1[0];
+    const float b0 = u ? o.b0[1] : o.b0[0], b1 = u ? o.b1[1] : o.b1[0];
+    st.w00 = o.a0 * b0; st.w01 = o.a0 * b1; st.w10 = o.a1 * b0; st.w11 = o.a1 * b1;
+    st.ux = u ? o.ux[1] : o.ux[0]; st.uy = u ? o.uy[1] : o.uy[0];
+    st.zoff = o.zoff;
+    const float* Pc = P + 4 * c4;
+    st.v00 = *reinterpret_cast<const f32x4*>(Pc + o.pb0 + (int64_t)q0 * ldp);
+    st.v01 = *reinterpret_cast<const f32x4*>(Pc + o.pb0 + (int64_t)q1 * ldp);
+    st.v10 = *reinterpret_cast<const f32x4*>(Pc + o.pb1 + (int64_t)q0 * ldp);
+    st.v11 = *reinterpret_cast<const f32x4*>(Pc + o.pb1 + (int64_t)q1 * ldp);
+  };
+  auto finish = [&](const Step& st) {
+    float o[4];
+    // (the four tap weights are multiplied out once per texel: one instruction per tap and channel)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[e] = fmaf(st.w00, st.v00[e], fmaf(st.w01, st.v01[e], fmaf(st.w10, st.v10[e], st.w11 * st.v11[e])));
+      o[e] += fmaf(wu[e], st.ux, fmaf(wv[e], st.uy, bs[e]));
+      const float d = o[e] - sh[e];
+      cs[e] += d;
+      cq[e] = fmaf(d, d, cq[e]);
+    }
+    *reinterpret_cast<f32x4*>(z + st.zoff + (int64_t)u * 128 + 4 * c4) = f32x4{o[0], o[1], o[2], o[3]};
+  };
+  const int64_t nstep = slot0 < last ? (last - slot0 + stride - 1) / stride : 0;
+  if (nstep > 0) {
+    Step sa, sb2;
+    Geo gn = geom();
+    issue(sa, gn);
+    gn = geom();
+    for (int64_t n = 0; n < nstep; n += 2) {
+      issue(sb2, gn);                                   // step n + 1's gathers
+      gn = geom();
+      __builtin_amdgcn_sched_barrier(0);
+      finish(sa);
+      __builtin_amdgcn_sched_barrier(0);
+      if (n + 1 >= nstep) break;
+      issue(sa, gn);                                    // step n + 2's gathers
+      gn = geom();
+      __builtin_amdgcn_sched_barrier(0);
+      finish(sb2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   if (!col_part) return;
 #pragma unroll
@@ -290,10 +339,10 @@ upsample_z_fwd8_kernel(UpGrid g, const float* __restrict__ P, int64_t ldp, const
   __syncthreads();
   if (threadIdx.x < 256) {
     const int k = threadIdx.x >> 7, n = threadIdx.x & 127;
-    float s = 0.f;
+    float sum = 0.f;
 #pragma unroll
-    for (int w = 0; w < UPZ8_WG / 64; ++w) s += s_red[w][k][n];
-    col_part[(size_t)blockIdx.x * 256 + k * 128 + n] = s;
+    for (int w = 0; w < UPQ_WG / 64; ++w) sum += s_red[w][k][n];
+    col_part[(size_t)blockIdx.x * 256 + k * 128 + n] = sum;
   }
 }
 
@@ -405,11 +454,17 @@ dz_upsample_t_kernel(UpGrid g, const int32_t* __restrict__ rptr, const int32_t* 
 // hits: the workgroup order keeps neighbouring tiles on ONE XCD (blockIdx % 8 selects the XCD: logical tile = (blockIdx
 // % 8) * (tiles / 8) + blockIdx / 8) and vertically neighbouring tiles sweep their rows in OPPOSITE directions, so that
 // both reach the rows they share at the same time.
-constexpr int DZM_WG = 512;        // 8 waves = 8 pixel columns in the reduce phase, 16 column slots x 32 float4 in the load phase
+#ifndef GANET_DZM_ABLATE
+#define GANET_DZM_ABLATE 0     // development (tools/dzm_ablate.sh): 1 no reduce phase, 2 no staging (loads only), 4 no Z loads,
+#endif                         // 8 no barriers, 16 natural tile order and sweep direction, 32 no db / dW_uv sums
+constexpr int DZM_WG = 1024;       // 16 waves: 32 column slots x 32 float4 in the load phase; (pixel column, channel half) in the reduce phase
 constexpr int DZM_Q = 8;
 constexpr int DZM_P = 8;
-constexpr int DZM_COLS = 48;       // texel columns a tile may span (3 load rounds of 16 slots); x4 grid: 36
+constexpr int DZM_COLS = 48;       // texel columns a tile may span (2 load rounds of 32 slots, the second half used); x4 grid: 36
 
+// (Ablation builds, 512 threads: as shipped 78 us; loads only 56; without the db / dW_uv sums 67; without the reduce phase 71;
+// G only 62 — i.e. NOT bandwidth-bound: with 8 waves per CU the per-row arithmetic was issue-bound. Hence 16 waves, and
+// branch-free sums.)
 __global__ void __launch_bounds__(DZM_WG)
 dz_upsample_march_kernel(UpGrid g, const int32_t* __restrict__ rptr, const int32_t* __restrict__ rsrc,
                          const int32_t* __restrict__ cptr, const int32_t* __restrict__ csrc,
@@ -420,39 +475,42 @@ dz_upsample_march_kernel(UpGrid g, const int32_t* __restrict__ rptr, const int32
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
-  const int c4 = tid & 31, slot = tid >> 5;            // load phase: channels 4 c4 .. + 3 of texel columns slot, slot + 16, ...
+  const int c4 = tid & 31, slot = tid >> 5;            // load phase: channels 4 c4 .. + 3 of texel columns slot, slot + 32
+  const int wq = wave & 7, ch = 64 * (wave >> 3) + lane;      // reduce phase: pixel column wq of the tile, channel ch
   const int S = g.S, R = g.R;
   const int64_t SS = (int64_t)S * S;
   const int nchunk = (R + DZM_P - 1) / DZM_P, nstrip = (R + DZM_Q - 1) / DZM_Q;
   const int total = (int)gridDim.x;
   // XCD-aware order (total a multiple of 8): consecutive logical tiles share an XCD
-  const int logical = (total % 8 == 0) ? (int)(blockIdx.x % 8) * (total / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const int logical = (total % 8 == 0 && !(GANET_DZM_ABLATE & 16))
+                          ? (int)(blockIdx.x % 8) * (total / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
   const int strip = logical % nstrip;
   const int chunk = (logical / nstrip) % nchunk;
   const int f = logical / (nstrip * nchunk);
   const int q0 = strip * DZM_Q, q1 = min(R, q0 + DZM_Q);
   const int pc0 = chunk * DZM_P, pc1 = min(R, pc0 + DZM_P);
-  const int q = q0 + wave;
+  const int q = q0 + wq;
 #pragma unroll
-  for (int p = 0; p < DZM_P; ++p) *reinterpret_cast<float2*>(&s_acc[p][wave][2 * lane]) = make_float2(0.f, 0.f);
+  for (int p = 0; p < DZM_P; ++p) s_acc[p][wq][ch] = 0.f;
   float sb[4] = {0.f, 0.f, 0.f, 0.f}, su[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {0.f, 0.f, 0.f, 0.f};
   const int e0 = rptr[pc0], e1 = rptr[pc1], d0 = cptr[q0], d1 = cptr[q1];
   if (e1 > e0 && d1 > d0) {                            // (uniform) the tile has taps at all
     const int i_lo = rsrc[e0], i_hi = rsrc[e1 - 1];    // (lists ascending in the texel index)
     const int j_lo = csrc[d0], j_hi = csrc[d1 - 1];    // <= j_lo + DZM_COLS - 1 (GanetUpGrid.max_col_span)
     const int nrow = i_hi - i_lo + 1;
-    const bool up = (chunk & 1) != 0;                  // odd chunks sweep bottom-up
+    const bool up = (chunk & 1) != 0 && !(GANET_DZM_ABLATE & 16);      // odd chunks sweep bottom-up
     auto row_at = [&](int k) { return up ? i_hi - min(k, nrow - 1) : i_lo + min(k, nrow - 1); };
-    // this thread's texel columns (three rounds) and whether the tile owns them (first column tap inside the strip)
-    int jc[3];
-    bool jon[3], jown[3];
+    // this thread's texel columns (two rounds) and whether the tile owns them (first column tap inside the strip)
+    int jc[2];
+    bool jon[2];
+    float jown[2];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int j = j_lo + slot + 16 * r;
-      jon[r] = j <= j_hi;
+    for (int r = 0; r < 2; ++r) {
+      const int j = j_lo + slot + 32 * r;
+      jon[r] = j <= j_hi && slot + 32 * r < DZM_COLS;
       jc[r] = jon[r] ? j : j_hi;
       const int qa = g.col_idx[2 * jc[r]];
-      jown[r] = jon[r] && qa >= q0 && qa < q1;
+      jown[r] = (jon[r] && qa >= q0 && qa < q1 && !(GANET_DZM_ABLATE & 32)) ? 1.f : 0.f;
     }
     const float4 cA = *reinterpret_cast<const float4*>(coef + 4 * c4);
     const float4 cQ = *reinterpret_cast<const float4*>(coef + 128 + 4 * c4);
@@ -471,102 +529,79 @@ dz_upsample_march_kernel(UpGrid g, const int32_t* __restrict__ rptr, const int32
       jt[t] = (on ? csrc[c0 + t] : j_lo) - j_lo;
       wt[t] = on ? cwt[c0 + t] : 0.f;
     }
-    struct Row { float4 gv[3], zv[3]; };
+    // (uv rides with the row's loads: a load issued in stage_row would have to wait for ALL loads in flight — the
+    // counter is in order — i.e. for the prefetched rows)
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    struct Row { f32x4 gv[2], zv[2]; f32x2 uv[2]; };
     auto load_row = [&](Row& r, int k) {
       const int64_t rowbase = (int64_t)row_at(k) * S;
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        r.gv[t] = *reinterpret_cast<const float4*>(Gf + (rowbase + jc[t]) * 128);
-        r.zv[t] = *reinterpret_cast<const float4*>(Zf + (rowbase + jc[t]) * 128);
+      for (int t = 0; t < 2; ++t) {
+        r.gv[t] = *reinterpret_cast<const f32x4*>(Gf + (rowbase + jc[t]) * 128);
+        if (!(GANET_DZM_ABLATE & 4)) r.zv[t] = *reinterpret_cast<const f32x4*>(Zf + (rowbase + jc[t]) * 128);
+        else r.zv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        r.uv[t] = *reinterpret_cast<const f32x2*>(uvf + (rowbase + jc[t]) * 2);
       }
     };
     auto stage_row = [&](const Row& r, int k) {        // dz of this thread's texels -> row image k & 1, + its sums
       const int i = row_at(k);
       const int pa = g.row_idx[2 * i];                 // scalar load
-      const bool own_row = pa >= pc0 && pa < pc1;
+      const float own_row = (pa >= pc0 && pa < pc1) ? 1.f : 0.f;
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        float4 d;
+      for (int t = 0; t < 2; ++t) {
+        f32x4 d;
         d.x = fmaf(cA.x, r.gv[t].x, fmaf(cQ.x, r.zv[t].x, cP.x));
         d.y = fmaf(cA.y, r.gv[t].y, fmaf(cQ.y, r.zv[t].y, cP.y));
         d.z = fmaf(cA.z, r.gv[t].z, fmaf(cQ.z, r.zv[t].z, cP.z));
         d.w = fmaf(cA.w, r.gv[t].w, fmaf(cQ.w, r.zv[t].w, cP.w));
-        if (jon[t]) *reinterpret_cast<float4*>(&s_dz[k & 1][slot + 16 * t][4 * c4]) = d;
-        if (own_row && jown[t]) {
-          const float2 uvv = *reinterpret_cast<const float2*>(uvf + ((int64_t)i * S + jc[t]) * 2);
-          sb[0] += d.x; sb[1] += d.y; sb[2] += d.z; sb[3] += d.w;
-          su[0] = fmaf(d.x, uvv.x, su[0]); su[1] = fmaf(d.y, uvv.x, su[1]); su[2] = fmaf(d.z, uvv.x, su[2]); su[3] = fmaf(d.w, uvv.x, su[3]);
-          sv[0] = fmaf(d.x, uvv.y, sv[0]); sv[1] = fmaf(d.y, uvv.y, sv[1]); sv[2] = fmaf(d.z, uvv.y, sv[2]); sv[3] = fmaf(d.w, uvv.y, sv[3]);
-        }
+        if (GANET_DZM_ABLATE & 2) { sb[0] += d.x + d.y + d.z + d.w; continue; }
+        if (jon[t]) *reinterpret_cast<f32x4*>(&s_dz[k & 1][slot + 32 * t][4 * c4]) = d;
+        // db / dW_uv, branch-free: the texel counts (m = 1) when the tile owns it
+        const float m = own_row * jown[t], mu = m * r.uv[t].x, mv = m * r.uv[t].y;
+        sb[0] = fmaf(m, d.x, sb[0]); sb[1] = fmaf(m, d.y, sb[1]); sb[2] = fmaf(m, d.z, sb[2]); sb[3] = fmaf(m, d.w, sb[3]);
+        su[0] = fmaf(mu, d.x, su[0]); su[1] = fmaf(mu, d.y, su[1]); su[2] = fmaf(mu, d.z, su[2]); su[3] = fmaf(mu, d.w, su[3]);
+        sv[0] = fmaf(mv, d.x, sv[0]); sv[1] = fmaf(mv, d.y, sv[1]); sv[2] = fmaf(mv, d.z, sv[2]); sv[3] = fmaf(mv, d.w, sv[3]);
       }
     };
-    auto reduce_row = [&](int k) {                     // wave = pixel column q: horizontal taps, then the vertical scatter
-      if (!q_on) return;
+    auto reduce_row = [&](int k) {                     // wave = (pixel column q, channel half): horizontal taps, vertical scatter
+      if (!q_on || (GANET_DZM_ABLATE & 1)) return;
       const int i = row_at(k);
       const int pa = g.row_idx[2 * i], pb = g.row_idx[2 * i + 1];        // scalar loads
       const float wa = g.row_w[2 * i], wb = g.row_w[2 * i + 1];
-      float h0 = 0.f, h1 = 0.f;
+      float h = 0.f;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const float2 d = *reinterpret_cast<const float2*>(&s_dz[k & 1][jt[t]][2 * lane]);
-        h0 = fmaf(wt[t], d.x, h0);
-        h1 = fmaf(wt[t], d.y, h1);
-      }
-      for (int cb = c0 + 8; cb < c1; ++cb) {           // more than 8 column taps: not the x4 grid
-        const float2 d = *reinterpret_cast<const float2*>(&s_dz[k & 1][csrc[cb] - j_lo][2 * lane]);
-        h0 = fmaf(cwt[cb], d.x, h0);
-        h1 = fmaf(cwt[cb], d.y, h1);
-      }
-      if (wa != 0.f && pa >= pc0 && pa < pc1) {
-        float2* a = reinterpret_cast<float2*>(&s_acc[pa - pc0][wave][2 * lane]);
-        float2 v = *a;
-        v.x = fmaf(wa, h0, v.x); v.y = fmaf(wa, h1, v.y);
-        *a = v;
-      }
-      if (wb != 0.f && pb >= pc0 && pb < pc1) {
-        float2* a = reinterpret_cast<float2*>(&s_acc[pb - pc0][wave][2 * lane]);
-        float2 v = *a;
-        v.x = fmaf(wb, h0, v.x); v.y = fmaf(wb, h1, v.y);
-        *a = v;
-      }
+      for (int t = 0; t < 8; ++t) h = fmaf(wt[t], s_dz[k & 1][jt[t]][ch], h);
+      for (int cb = c0 + 8; cb < c1; ++cb) h = fmaf(cwt[cb], s_dz[k & 1][csrc[cb] - j_lo][ch], h);   // (not the x4 grid)
+      if (wa != 0.f && pa >= pc0 && pa < pc1) s_acc[pa - pc0][wq][ch] = fmaf(wa, h, s_acc[pa - pc0][wq][ch]);
+      if (wb != 0.f && pb >= pc0 && pb < pc1) s_acc[pb - pc0][wq][ch] = fmaf(wb, h, s_acc[pb - pc0][wq][ch]);
     };
     // rows k = 0 .. nrow - 1; loads two rows ahead (three register sets used in turn)
     Row r0, r1, r2;
     load_row(r0, 0);
     load_row(r1, 1);
-    for (int k = 0; k < nrow; k += 3) {
-      load_row(r2, k + 2);
+    auto do_row = [&](Row& cur, Row& refill, int k) {
+      load_row(refill, k + 2);
       __builtin_amdgcn_sched_barrier(0);
-      stage_row(r0, k);
-      __syncthreads();
+      stage_row(cur, k);
+      if (!(GANET_DZM_ABLATE & 8)) __syncthreads();
       reduce_row(k);
-      if (k + 1 < nrow) {
-        load_row(r0, k + 3);
-        __builtin_amdgcn_sched_barrier(0);
-        stage_row(r1, k + 1);
-        __syncthreads();
-        reduce_row(k + 1);
-      }
-      if (k + 2 < nrow) {
-        load_row(r1, k + 4);
-        __builtin_amdgcn_sched_barrier(0);
-        stage_row(r2, k + 2);
-        __syncthreads();
-        reduce_row(k + 2);
-      }
+    };
+    for (int k = 0; k < nrow; k += 3) {
+      do_row(r0, r2, k);
+      if (k + 1 < nrow) do_row(r1, r0, k + 1);
+      if (k + 2 < nrow) do_row(r2, r1, k + 2);
     }
   }
   if (q < q1) {
 #pragma unroll
     for (int p = 0; p < DZM_P; ++p)
-      if (pc0 + p < pc1)
-        *reinterpret_cast<float2*>(dP + (((int64_t)f * R + pc0 + p) * R + q) * ldp + 2 * lane) =
-            *reinterpret_cast<const float2*>(&s_acc[p][wave][2 * lane]);
+      if (pc0 + p < pc1) dP[(((int64_t)f * R + pc0 + p) * R + q) * ldp + ch] = s_acc[p][wq][ch];
   }
   if (!partial) return;
-  // db / dWuv: 16 column slots x 32 channel quads -> [128 x 2 | 128] per workgroup, through the (now idle) row image
+  // db / dWuv: 32 column slots x 32 channel quads -> [128 x 2 | 128] per workgroup, through the (now idle) row image
   __syncthreads();
-  float* red = &s_dz[0][0][0];                         // [16 slots][3][128]
+  float* red = &s_dz[0][0][0];                         // [32 slots][3][128] = all of it
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     red[(slot * 3 + 0) * 128 + 4 * c4 + e] = sb[e];
@@ -578,7 +613,7 @@ dz_upsample_march_kernel(UpGrid g, const int32_t* __restrict__ rptr, const int32
     const int k = tid >> 7, n = tid & 127;
     float sum = 0.f;
 #pragma unroll
-    for (int sl = 0; sl < 16; ++sl) sum += red[(sl * 3 + k) * 128 + n];
+    for (int sl = 0; sl < 32; ++sl) sum += red[(sl * 3 + k) * 128 + n];
     float* out = partial + (size_t)blockIdx.x * DZT_PART;
     if (k == 0) out[256 + n] = sum;                    // db
     else out[n * 2 + (k - 1)] = sum;                   // dWuv[n][0] (u), dWuv[n][1] (v)
@@ -620,8 +655,8 @@ int upsample_z_fwd_launch(const UpGrid& g, const float* P, int64_t ldp, const fl
     return 1;
   }
   ProfScope prof_(K_UPZ_FWD, stream);
-  if (g.S % 8 == 0)
-    hipLaunchKernelGGL(upsample_z_fwd8_kernel, dim3(UPZ_BLOCKS), dim3(UPZ8_WG), 0, stream, g, P, ldp, Wuv, bias, stat_shift,
+  if (g.S % 2 == 0)
+    hipLaunchKernelGGL(upsample_z_fwd_pipe_kernel, dim3(UPZ_BLOCKS), dim3(UPQ_WG), 0, stream, g, P, ldp, Wuv, bias, stat_shift,
                        z, col_part);
   else
     hipLaunchKernelGGL(upsample_z_fwd_kernel, dim3(UPZ_BLOCKS), dim3(UPZ_WG), 0, stream, g, P, ldp, Wuv, bias, stat_shift, z,

@@ -47,6 +47,10 @@ def timeit(name, fn, bytes_=None, reps=21):
 
 
 chk = _native.ganet_check
+ONLY = sys.argv[2] if len(sys.argv) > 2 else ""
+if ONLY == "dz":
+    timeit("dz_upsample_t", lambda k: chk(lib.ganet_dz_upsample_t(ctypes.byref(grid), _ptr(Gs[k % NB]), _ptr(Zs[k % NB]), _ptr(coef), _ptr(dP[:, 128:]), 256, _ptr(part), st)), 8.0 * M * 128)
+    sys.exit(0)
 big = [torch.empty(M, 128, device="cuda") for _ in range(NB)]
 timeit("torch zero_ (134 MB write)", lambda k: big[k % NB].zero_(), 4.0 * M * 128)
 timeit("torch sum (134 MB read)", lambda k: Gs[k % NB].sum(), 4.0 * M * 128)
