@@ -160,7 +160,7 @@ _ganet = None
 GANET_SYMBOLS = ["ganet_linear_wgrad_workspace", "ganet_linear_wgrad", "ganet_bn_workspace",
                  "ganet_bn_act_fwd", "ganet_bn_act_bwd", "ganet_ssim_sums_floats", "ganet_ssim_fwd", "ganet_ssim_bwd",
                  "ganet_mlp_stats_floats", "ganet_mlp_fwd", "ganet_mlp_stats",
-                 "ganet_wgrad_act_workspace", "ganet_wgrad_act", "ganet_wgrad_reduce_batch", "ganet_adam_step", "ganet_mlp_bwd_data_parts",
+                 "ganet_wgrad_act_workspace", "ganet_wgrad_act", "ganet_wgrad_reduce_batch", "ganet_adam_step", "ganet_flag_clear", "ganet_mlp_bwd_data_parts",
                  "ganet_mlp_head_bwd_parts", "ganet_mlp_bwd_data", "ganet_mlp_head_bwd", "ganet_mlp_bwd_stats",
                  "ganet_mlp_bwd_fused_parts", "ganet_mlp_bwd_fused_workspace", "ganet_mlp_bwd_fused", "ganet_mlp_bwd_fused_input",
                  "ganet_decoder_saved_floats", "ganet_decoder_fwd_workspace", "ganet_decoder_fwd",
@@ -284,6 +284,8 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_wgrad_reduce_batch.argtypes = [c_int32, P, P]
         lib.ganet_adam_step.restype = c_int
         lib.ganet_adam_step.argtypes = [c_int32, P, c_float, c_float, c_float, P, P]
+        lib.ganet_flag_clear.restype = c_int
+        lib.ganet_flag_clear.argtypes = [P, P]
         lib.ganet_mean_sq_fwd.restype = c_int
         lib.ganet_mean_sq_fwd.argtypes = [c_int64, P, c_float, P, P]
         lib.ganet_mean_sq_bwd.restype = c_int

@@ -401,7 +401,7 @@ class AvatarModel:
         return self.model_parms.train_stage == 1 and epoch > self.opt_parms.pose_op_start_iter
 
     def zero_grad(self, epoch):
-        self.optimizer.zero_grad()        # (optim.Adam: also lowers the rasterizer's overflow flag for the new step)
+        self.optimizer.zero_grad()
         if self._pose_opt_active(epoch):
             self.optimizer_pose.zero_grad()
         elif self.model_parms.train_stage == 1:
@@ -419,10 +419,23 @@ class AvatarModel:
             # every rank back-propagated its slice of the UV map: the parameter gradients are partial sums
             parallel.allreduce_param_grads(list(self.net.parameters()) + [self.geo_feature], average=False)
         parallel.wait_overflow_flag()     # every rank skips the step if any rank dropped a frame's gradient
+        pose_on = self._pose_opt_active(epoch)
+        keep = None
+        if pose_on and self.device.type == "cuda":
+            # the pose optimiser drops an overflowed iteration too (its rasterizer gradients are zeros: a SparseAdam step
+            # would apply momentum alone, and real updates for the frames that did not overflow): read the flag before
+            # optim.Adam lowers it
+            from . import rasterizer
+            keep = 1.0 - rasterizer.overflow_flag(self.device).float()
         self.optimizer.step()
         self.scheduler.step()
-        if self._pose_opt_active(epoch):
+        if pose_on:
             parallel.allgather_sparse_grads([self.pose.weight, self.transl.weight])
+            if keep is not None:
+                for p in (self.pose.weight, self.transl.weight):
+                    if p.grad is not None and p.grad.is_sparse:
+                        p.grad = p.grad.coalesce()
+                        p.grad._values().mul_(keep)
             self.optimizer_pose.step()
 
     # ------------------------------------------------------------------ the hot path

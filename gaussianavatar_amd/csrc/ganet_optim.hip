@@ -117,4 +117,9 @@ int ganet_adam_step(int32_t n_tensors, const GanetAdamTensor* tensors, float bet
   return check_hip(hipGetLastError(), "adam_kernel");
 }
 
+int ganet_flag_clear(int32_t* flag, void* stream_) {
+  if (!flag) { set_error("ganet_flag_clear: flag is NULL"); return 1; }
+  return check_hip(hipMemsetAsync(flag, 0, sizeof(int32_t), static_cast<hipStream_t>(stream_)), "hipMemsetAsync");
+}
+
 }  // extern "C"

@@ -10,8 +10,9 @@ maximize, capturable and differentiable off; float32 CUDA parameters with dense 
 
 Overflow safety (no host sync): the rasterizer's backward pass raises a device-side flag when a forward pass had
 overflowed its pair buffer — that frame's gradients are zeros (rasterizer.overflow_flag). `step()` hands the flag
-to the kernel, which then changes nothing: a step computed from truncated tile lists is never applied.
-`zero_grad()` lowers the flag for the next step. (A skipped step still advances the `step` counter of the bias
+to the kernel, which then changes nothing: a step computed from truncated tile lists is never applied — and lowers the
+flag again behind its last launch (stream-ordered), so the flag describes ONE step whatever the caller's loop does in
+between (module.zero_grad(), `p.grad = None`, two steps per zero_grad: ADVICE r04). (A skipped step still advances the `step` counter of the bias
 corrections; at the reference's betas that shifts the step size of the following updates by < 1e-3 relative after
 a few hundred steps.)
 """
@@ -34,12 +35,6 @@ class Adam(torch.optim.Adam):
         self._table = (_native.GanetAdamTensor * 64)()
         self.skip_on_overflow = True      # read the rasterizer's overflow flag (see the module docstring)
         self._layout_checked = set()      # parameters whose layout (and whose moments' layout) has been verified
-
-    def zero_grad(self, set_to_none: bool = True):
-        super().zero_grad(set_to_none=set_to_none)
-        if self.skip_on_overflow:
-            from . import rasterizer
-            rasterizer.clear_overflow_flag()
 
     def _skip_flag(self, device):
         if not self.skip_on_overflow:
@@ -117,6 +112,8 @@ class Adam(torch.optim.Adam):
                     n = 0
         if n:
             _native.ganet_check(lib.ganet_adam_step(n, table, *flush_args, skip, stream))
+        if skip is not None:          # the flag belonged to this step
+            _native.ganet_check(lib.ganet_flag_clear(skip, stream))
         return loss
 
     def state_dict(self):

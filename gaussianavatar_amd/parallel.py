@@ -92,6 +92,7 @@ def rank() -> int:
 
 
 _flag_work = None
+_flag_posts = []          # (work, snapshot, flag) of the reductions in flight
 
 
 def post_overflow_flag(device) -> None:
@@ -103,15 +104,23 @@ def post_overflow_flag(device) -> None:
     if world_size() == 1 or not torch.device(device).type == "cuda":
         return
     from . import rasterizer
-    _flag_work = dist.all_reduce(rasterizer.overflow_flag(device), op=dist.ReduceOp.MAX, group=_group, async_op=True)
+    # a SNAPSHOT is reduced, not the flag itself: a later backward pass of the same iteration (per-frame fallback path)
+    # may raise the flag while this message is in flight, and the in-place result would overwrite it
+    flag = rasterizer.overflow_flag(device)
+    snap = flag.clone()
+    _flag_work = dist.all_reduce(snap, op=dist.ReduceOp.MAX, group=_group, async_op=True)
+    _flag_posts.append((_flag_work, snap, flag))
 
 
 def wait_overflow_flag() -> None:
-    """Order the optimiser step behind the flag's reduction (stream-level wait with RCCL, no host block)."""
+    """Order the optimiser step behind the flag's reductions (stream-level wait with RCCL, no host block) and fold their
+    results into the flag."""
     global _flag_work
-    if _flag_work is not None:
-        _flag_work.wait()
-        _flag_work = None
+    for work, snap, flag in _flag_posts:
+        work.wait()
+        torch.maximum(flag, snap, out=flag)
+    _flag_posts.clear()
+    _flag_work = None
 
 
 class _ExchangeGrad(torch.autograd.Function):

@@ -288,6 +288,9 @@ typedef struct GanetAdamTensor {
 } GanetAdamTensor;
 int ganet_adam_step(int32_t n_tensors, const GanetAdamTensor* tensors, float beta1, float beta2, float eps,
                     const int32_t* skip_flag, void* stream);
+/* Lower the flag again behind the step's last launch (stream-ordered 4-byte fill): the flag describes ONE optimisation
+ * step, whatever the caller's loop does between steps. */
+int ganet_flag_clear(int32_t* flag, void* stream);
 
 /* out[0] = bias + sum_{i<n} weights[i] * terms[i][0]: the scalar objective of the training loop
  * (/root/reference/train.py:70-82) in one launch. terms: HOST array of n device pointers, weights: HOST

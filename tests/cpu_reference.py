@@ -82,6 +82,7 @@ def forward(model, snap, batch, iteration, oracle, stage=1, free=False):
         enc = snap["pose_encoder"]
         enc.train()
         posef = enc(batch["inp_pos_map"].cpu().float())
+        posef.retain_grad()          # (tests that re-evaluate the encoder's backward in float64 read it)
     res, sc, shs = net(posef, geom, uv)
     res = res.permute(0, 2, 1) * 0.02
     sc = sc.permute(0, 2, 1)
@@ -100,6 +101,7 @@ def forward(model, snap, batch, iteration, oracle, stage=1, free=False):
         out["geo_loss"] = torch.mean(snap["geo"] ** 2)
     else:
         out["pose_loss"] = torch.mean(posef ** 2)
+        out["pose_featmap"] = posef
     rots = model.fix_rotation.cpu()
     opac = model.fix_opacity.cpu()
     bg = model.background.cpu().numpy()

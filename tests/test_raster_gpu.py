@@ -244,6 +244,8 @@ def test_steady_state_overflow_never_reaches_the_parameters(raster_oracle):
             opt.step()
             for a, b in zip(before, state()):
                 assert torch.equal(a, b)                    # the step changed nothing
+            # ... and lowered the flag behind itself: it describes ONE step, whatever clears the gradients
+            assert int(R.overflow_flag("cuda")) == 0
             R.check_overflow(block=True)                    # the host learns of it at the latest here: capacity raised
         # training continues: the next step renders the full lists and moves the parameters
         color = iteration()
