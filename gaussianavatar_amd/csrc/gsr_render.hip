@@ -293,9 +293,8 @@ render_fwd_kernel(int W, int H, int gx, int T, int64_t max_pairs, int seg_cap, c
       }
       pending = false;
       const bool valid = lane < take;
-      // the block's pixels that are still accumulating, one after the other (p is wave-uniform: an SGPR)
-      for (unsigned long long pm = alive; pm; pm &= pm - 1ull) {
-        const int p = __builtin_ctzll(pm);
+      // the block's pixels that are still accumulating, one after the other
+      auto pixel = [&](const int p) {
         const float Tin = read_lane(vT, p);
         const float dx = c.x - (fbx + (float)(p & (SUB - 1)));
         const float dy = c.y - (fby + (float)(p / SUB));
@@ -303,7 +302,7 @@ render_fwd_kernel(int W, int H, int gx, int T, int64_t max_pairs, int seg_cap, c
         const float alpha = fminf(ALPHA_MAX, co.w * __expf(power));
         const float a = (valid & (power <= 0.0f) & (alpha >= ALPHA_MIN)) ? alpha : 0.f;
         const unsigned long long hit = __ballot(a > 0.f);
-        if (hit == 0ull) continue;                              // nothing of this segment reaches the pixel
+        if (hit == 0ull) return;                                // nothing of this segment reaches the pixel
         const float Pincl = wave_scan_mul(1.0f - a);            // prod_{j<=l} (1 - a_j)
         const float Tincl = Tin * Pincl;
         // the first hit whose blend would push T below 1e-4 ends the pixel BEFORE it is accumulated
@@ -328,6 +327,16 @@ render_fwd_kernel(int W, int H, int gx, int T, int64_t max_pairs, int seg_cap, c
         const float Tnew = first < GSR_WAVE ? read_lane(Texcl, first) : read_lane(Tincl, GSR_WAVE - 1);
         vT = write_lane_at(vT, Tnew, p);
         if (first < GSR_WAVE) alive &= ~(1ull << p);
+      };
+      if constexpr (SUB == 4) {
+        // 4x4 blocks: the sixteen pixels unrolled — p is a compile-time constant (lane selects and v_readlane with
+        // immediate lanes, the pixel's offsets folded into constants). Round 4 had replaced this by the bit-scan loop
+        // of the 8x8 experiment for both block sizes: render_fwd 138 -> 143 us, render_bwd 141 -> 154 us (rocprofv3).
+#pragma unroll
+        for (int p = 0; p < NPIX; ++p)
+          if ((alive >> p) & 1ull) pixel(p);
+      } else {
+        for (unsigned long long pm = alive; pm; pm &= pm - 1ull) pixel(__builtin_ctzll(pm));   // (p wave-uniform: an SGPR)
       }
       // record the segment for the backward pass
       if (RECORD) {
@@ -468,17 +477,17 @@ render_bwd_kernel(int W, int H, int list_cap, const float2* __restrict__ xy,
     const int kmin = __builtin_amdgcn_readfirstlane(k);            // entries are in list order
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;
     {
-      // the block's pixels that did not saturate in front of this segment, one after the other (p: an SGPR)
-      for (unsigned long long pm = __ballot(lane < NPIX && vLast > kmin); pm; pm &= pm - 1ull) {
-        const int p = __builtin_ctzll(pm);
+      // the block's pixels that did not saturate in front of this segment, one after the other
+      auto pixel = [&](const int p) {
         const int lastp = __builtin_amdgcn_readlane(vLast, p);
+        if (SUB == 4 && lastp <= kmin) return;                      // (the static loop tests here; the bit scan below never gets such a pixel)
         const float dx = c.x - (fbx + (float)(p & (SUB - 1)));
         const float dy = c.y - (fby + (float)(p / SUB));
         const float power = eval_power(co, dx, dy);
         const float G = __expf(power);
         const float alpha = fminf(ALPHA_MAX, co.w * G);
         const float a = ((k < lastp) & (power <= 0.0f) & (alpha >= ALPHA_MIN)) ? alpha : 0.f;
-        if (__ballot(a > 0.f) == 0ull) continue;
+        if (__ballot(a > 0.f) == 0ull) return;
         const float g0 = read_lane(vg0, p), g1 = read_lane(vg1, p), g2 = read_lane(vg2, p);
         const float om = 1.0f - a;
         const float T = read_lane(vTs, p) * wave_shr1(1.0f, wave_scan_mul(om));   // in front of this entry
@@ -501,6 +510,12 @@ render_bwd_kernel(int W, int H, int list_cap, const float2* __restrict__ xy,
         v6 = fmaf(w, g0, v6);
         v7 = fmaf(w, g1, v7);
         v8 = fmaf(w, g2, v8);
+      };
+      if constexpr (SUB == 4) {        // sixteen pixels unrolled, p a compile-time constant (see render_fwd_kernel)
+#pragma unroll
+        for (int p = 0; p < NPIX; ++p) pixel(p);
+      } else {
+        for (unsigned long long pm = __ballot(lane < NPIX && vLast > kmin); pm; pm &= pm - 1ull) pixel(__builtin_ctzll(pm));
       }
     }
     // the next segment's record has arrived by now: start its second-level loads
