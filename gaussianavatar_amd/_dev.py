@@ -13,6 +13,8 @@ ONE variable, `GA_DEV="key=value,key=value"`, read once at import; without it ev
                         up-sampled input tensor x [M,72], no KIN = 72 launches). Built, parity-green and measured in round 5:
                         65 us less kernel time per iteration, the same iterations/s (profiles/r05_decoder_map.md) — off by
                         default until it wins
+    native_unet=0       stage 2: the pose encoder as im2col + vendor GEMM + torch BatchNorm / element-wise kernels instead of
+                        the hand-written kernels of csrc/ganet_unet.hip
 """
 from __future__ import annotations
 
@@ -28,6 +30,7 @@ class DevKnobs:
     native_decoder: bool = True
     one_pass_backward: bool = True
     decoder_map: bool = False
+    native_unet: bool = True
 
 
 def _parse(text: str) -> DevKnobs:

@@ -168,7 +168,8 @@ GANET_SYMBOLS = ["ganet_linear_wgrad_workspace", "ganet_linear_wgrad", "ganet_bn
                  "ganet_decode_pack_fwd", "ganet_decode_pack_bwd", "ganet_records_bwd", "ganet_mean_sq_fwd", "ganet_mean_sq_bwd", "ganet_weighted_sum_fwd", "ganet_weighted_sum_bwd", "ganet_upsample_cat_fwd", "ganet_upsample_cat_bwd",
                  "ganet_rowgemm", "ganet_upsample_z_fwd", "ganet_mlp_fwd_add", "ganet_dz_upsample_t_parts", "ganet_dz_upsample_t",
                  "ganet_decoder_map_fwd_workspace", "ganet_decoder_map_fwd", "ganet_decoder_map_bwd_workspace",
-                 "ganet_decoder_map_bwd", "ganet_profile_create", "ganet_profile_destroy", "ganet_profile_bind", "ganet_profile_count", "ganet_profile_read", "ganet_profile_kernel_name",
+                 "ganet_decoder_map_bwd", "ganet_unet_saved_floats", "ganet_unet_fwd_workspace", "ganet_unet_fwd",
+                 "ganet_unet_bwd_workspace", "ganet_unet_bwd", "ganet_profile_create", "ganet_profile_destroy", "ganet_profile_bind", "ganet_profile_count", "ganet_profile_read", "ganet_profile_kernel_name",
                  "ganet_conv5_packed_bytes", "ganet_conv5_pack", "ganet_conv5_apply",
                  "ganet_conv5_wgrad_workspace", "ganet_conv5_wgrad", "ganet_last_error", "ganet_abi_version"]
 
@@ -205,6 +206,19 @@ class GanetUpGrid(ctypes.Structure):
                 ("row_ptr", c_void_p), ("row_src", c_void_p), ("row_wt", c_void_p),
                 ("col_ptr", c_void_p), ("col_src", c_void_p), ("col_wt", c_void_p),
                 ("uv", c_void_p), ("uv_frame_stride", c_int64), ("max_col_span", c_int32)]
+
+
+class GanetUnetParams(ctypes.Structure):
+    """include/ganet.h GanetUnetParams"""
+    _fields_ = [("cin", c_int32), ("nf", c_int32), ("cout", c_int32), ("S", c_int32),
+                ("Wd", c_void_p * 5), ("Wu", c_void_p * 5), ("bias5", c_void_p),
+                ("running_mean", c_void_p * 7), ("running_var", c_void_p * 7), ("num_batches_tracked", c_void_p * 7),
+                ("eps", c_float), ("momentum", c_float)]
+
+
+class GanetUnetGrads(ctypes.Structure):
+    """include/ganet.h GanetUnetGrads"""
+    _fields_ = [("dWd", c_void_p * 5), ("dWu", c_void_p * 5), ("dbias5", c_void_p)]
 
 
 class GanetAdamTensor(ctypes.Structure):
@@ -316,6 +330,16 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_decoder_map_bwd_workspace.argtypes = [P]
         lib.ganet_decoder_map_bwd.restype = c_int
         lib.ganet_decoder_map_bwd.argtypes = [P, P, P, P, P, P, P, c_size_t, P, P]
+        lib.ganet_unet_saved_floats.restype = c_size_t
+        lib.ganet_unet_saved_floats.argtypes = [P, c_int32]
+        lib.ganet_unet_fwd_workspace.restype = c_size_t
+        lib.ganet_unet_fwd_workspace.argtypes = [P, c_int32]
+        lib.ganet_unet_fwd.restype = c_int
+        lib.ganet_unet_fwd.argtypes = [P, c_int32, P, c_int32, P, P, P, c_size_t, P]
+        lib.ganet_unet_bwd_workspace.restype = c_size_t
+        lib.ganet_unet_bwd_workspace.argtypes = [P, c_int32]
+        lib.ganet_unet_bwd.restype = c_int
+        lib.ganet_unet_bwd.argtypes = [P, c_int32, P, P, P, P, P, c_size_t, P]
         lib.ganet_profile_create.restype = c_void_p
         lib.ganet_profile_create.argtypes = []
         lib.ganet_profile_destroy.restype = None

@@ -50,6 +50,7 @@ LIBS = {
         ("ganet_pack.hip", []),
         ("ganet_upsample.hip", []),
         ("ganet_upz.hip", []),
+        ("ganet_unet.hip", []),
         ("ganet_conv.hip", []),
         ("ganet_optim.hip", []),
     ],

@@ -1174,3 +1174,89 @@ def _decoder_param_list(dec):
         c = getattr(dec, f"conv8{t}")
         params += [c.weight, c.bias]
     return params
+
+
+# ------------------------------------------------------------------------------------------------
+# The stage-2 pose encoder (network.UnetNoCond5DS) as one native call each way (csrc/ganet_unet.hip).
+_UNET_BN = ("conv2", "conv3", "conv4", "upconv1", "upconv2", "upconv3", "upconv4")
+_NATIVE_UNET = _dev.knobs.native_unet
+
+
+def unet_supported(net, x) -> bool:
+    """net: network.UnetNoCond5DS; x [B, cin, S, S]."""
+    if not (_NATIVE_UNET and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[2] == x.shape[3]):
+        return False
+    ups = [getattr(net, f"upconv{k}") for k in range(1, 6)]
+    if not all(isinstance(u.up, torch.nn.ConvTranspose2d) and not u.use_dropout for u in ups):
+        return False
+    nf, cout = net.conv1.conv.out_channels, net.upconv5.up.out_channels
+    bns = [getattr(net, n).bn for n in _UNET_BN]
+    plain = all(type(b) is torch.nn.BatchNorm2d and not b.affine and b.momentum is not None and b.track_running_stats
+                and b.training == net.training for b in bns)
+    return (plain and nf % 32 == 0 and cout % 32 == 0 and x.shape[2] % 32 == 0 and x.shape[1] <= 8
+            and net.conv1.conv.in_channels == x.shape[1] and net.upconv5.up.bias is not None
+            and (net.training or not torch.is_grad_enabled()))
+
+
+def _unet_params(net, ws, S):
+    P = _native.GanetUnetParams()
+    P.cin, P.nf, P.cout, P.S = net.conv1.conv.in_channels, net.conv1.conv.out_channels, net.upconv5.up.out_channels, S
+    for k in range(5):
+        P.Wd[k], P.Wu[k] = ws[k].data_ptr(), ws[5 + k].data_ptr()
+    P.bias5 = ws[10].data_ptr()
+    for i, name in enumerate(_UNET_BN):
+        bn = getattr(net, name).bn
+        P.running_mean[i], P.running_var[i] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+        P.num_batches_tracked[i] = bn.num_batches_tracked.data_ptr()
+    bn0 = getattr(net, _UNET_BN[0]).bn
+    P.eps, P.momentum = float(bn0.eps), float(bn0.momentum)
+    return P
+
+
+class _UnetFn(torch.autograd.Function):
+    """(x [B,cin,S,S], conv1..5 weights, upconv1..5 weights, upconv5 bias) -> pose features, a logical-NCHW view of a
+    channels-last buffer [B,S,S,cout]."""
+
+    @staticmethod
+    def forward(ctx, x, net, *ws):
+        lib = _native.ganet()
+        dev = x.device
+        B, _, S, _ = x.shape
+        xc = x.contiguous()
+        ws = tuple(w if w.is_contiguous() else w.contiguous() for w in ws)
+        P = _unet_params(net, ws, S)
+        saved = torch.empty(lib.ganet_unet_saved_floats(ctypes.byref(P), B), dtype=torch.float32, device=dev)
+        out = torch.empty((B, S, S, P.cout), dtype=torch.float32, device=dev)
+        wsb = lib.ganet_unet_fwd_workspace(ctypes.byref(P), B)
+        wk = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        _native.ganet_check(lib.ganet_unet_fwd(ctypes.byref(P), B, _ptr(xc), int(net.training), _ptr(saved), _ptr(out),
+                                               _ptr(wk), wsb, _stream(dev)))
+        ctx.net = net
+        ctx.save_for_backward(xc, saved, *ws)
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _native.ganet()
+        xc, saved, *ws = ctx.saved_tensors
+        dev = xc.device
+        B, _, S, _ = xc.shape
+        P = _unet_params(ctx.net, ws, S)
+        gh = g.permute(0, 2, 3, 1).contiguous()                        # channels-last (no copy if it already is)
+        grads = [torch.empty_like(w) for w in ws]
+        G = _native.GanetUnetGrads()
+        for k in range(5):
+            G.dWd[k], G.dWu[k] = grads[k].data_ptr(), grads[5 + k].data_ptr()
+        G.dbias5 = grads[10].data_ptr()
+        wsb = lib.ganet_unet_bwd_workspace(ctypes.byref(P), B)
+        wk = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        _native.ganet_check(lib.ganet_unet_bwd(ctypes.byref(P), B, _ptr(xc), _ptr(saved), _ptr(gh), ctypes.byref(G), _ptr(wk),
+                                               wsb, _stream(dev)))
+        return (None, None) + tuple(grads)
+
+
+def unet_forward(net, x):
+    ws = [getattr(net, f"conv{k}").conv.weight for k in range(1, 6)]
+    ws += [getattr(net, f"upconv{k}").up.weight for k in range(1, 6)]
+    ws.append(net.upconv5.up.bias)
+    return _UnetFn.apply(x, net, *ws)

@@ -221,6 +221,10 @@ class UnetNoCond5DS(nn.Module):
         self.upconv5 = _Up(2 * nf, output_nc, use_bn=False, use_bias=True, up_mode=up_mode)
 
     def forward(self, x):
+        if fused.unet_supported(self, x):
+            # HIP device, the reference's configuration: the whole encoder as one native call each way on hand-written
+            # implicit-GEMM kernels (csrc/ganet_unet.hip; channels-last, activations and BatchNorm applied on load)
+            return fused.unet_forward(self, x)
         a1 = F.leaky_relu(self.conv1(x), 0.2)          # = d1 after the in-place activation
         a2 = F.leaky_relu(self.conv2(a1), 0.2)
         a3 = F.leaky_relu(self.conv3(a2), 0.2)

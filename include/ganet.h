@@ -391,6 +391,41 @@ int ganet_decoder_map_bwd(const GanetUpGrid* grid, const float* feat, const Gane
                           const float* saved, const float* const* d_out, const GanetDecoderGrads* grads, void* workspace,
                           size_t workspace_bytes, void* stream, void* side_stream);
 
+/* ---- the stage-2 pose encoder as ONE call each way (ganet_unet.hip): UnetNoCond5DS of
+ * /root/reference/model/modules.py:185-232 (blocks :62-111) — five 4x4 / stride-2 convolutions down (nf, 2nf, 4nf, 8nf, 8nf
+ * channels; BatchNorm2d(affine=False) after conv2..4; LeakyReLU(0.2) in front of conv2..5, in place, so the skip tensors
+ * carry it too), five ReLU -> 4x4 / stride-2 transposed convolutions up with skip concatenations (BatchNorm after
+ * upconv1..4, bias on upconv5). x: [B, cin, S, S] NCHW (S a multiple of 32, cin <= 8); out: [B, S, S, cout]
+ * channels-last; nf and cout multiples of 32. Weights in torch's layouts: Wd[k] = conv{k+1}.conv.weight
+ * [co][ci][4][4], Wu[k] = upconv{k+1}.up.weight [ci][co][4][4], bias5 = upconv5.up.bias. BatchNorm index: 0..2 =
+ * conv2..4, 3..6 = upconv1..4 (running statistics updated like F.batch_norm(training=True); training = 0: the running
+ * statistics normalise). saved (ganet_unet_saved_floats floats) keeps the raw layer outputs and the statistics for
+ * the backward pass, which expects the forward pass to have run in training mode. Replaces ~40 im2col / GEMM /
+ * col2im / batch_norm / element-wise launches per pass. */
+#define GANET_UNET_BN 7
+typedef struct GanetUnetParams {
+  int32_t cin, nf, cout, S;
+  const float* Wd[5];
+  const float* Wu[5];
+  const float* bias5;
+  float* running_mean[GANET_UNET_BN];
+  float* running_var[GANET_UNET_BN];
+  int64_t* num_batches_tracked[GANET_UNET_BN];
+  float eps, momentum;
+} GanetUnetParams;
+typedef struct GanetUnetGrads {
+  float* dWd[5];
+  float* dWu[5];
+  float* dbias5;
+} GanetUnetGrads;
+size_t ganet_unet_saved_floats(const GanetUnetParams* params, int32_t B);
+size_t ganet_unet_fwd_workspace(const GanetUnetParams* params, int32_t B);
+int ganet_unet_fwd(const GanetUnetParams* params, int32_t B, const float* x, int32_t training, float* saved, float* out,
+                   void* workspace, size_t workspace_bytes, void* stream);
+size_t ganet_unet_bwd_workspace(const GanetUnetParams* params, int32_t B);
+int ganet_unet_bwd(const GanetUnetParams* params, int32_t B, const float* x, const float* saved, const float* d_out,
+                   const GanetUnetGrads* grads, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Optional per-kernel timing (bench/profiling only). The caller owns a GanetProfile object and binds it to the
  * calling thread; from then on every instrumented launch this thread makes whose kernel id is in `mask` is bracketed by
  * hipEvents recorded on the launch stream and accounted to that object (bind NULL or mask 0 to stop). ganet_profile_read
