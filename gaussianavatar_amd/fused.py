@@ -27,7 +27,7 @@ def _stream(device):
     if getattr(_profile_tls, "mask", 0) != _profile_mask and _profile is not None:
         _native.ganet_check(_native.ganet().ganet_profile_bind(_profile, _profile_mask))
         _profile_tls.mask = _profile_mask
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return ctypes.c_void_p(_native.raw_stream(device))
 
 
 _profiling = False        # per-kernel HIP events on: launches stay on ONE stream, so that a kernel's events time that kernel
@@ -530,12 +530,27 @@ def decoder_input_pad(dec, like) -> int:
     return _K1_PAD - dec.in_size if decoder_supported(dec, probe) else 0
 
 
+def _decoder_modules(dec):
+    """(conv, bn) module pairs of the decoder's 11 BatchNorm layers and its three output convolutions, looked up ONCE per
+    decoder object: nn.Module.__getattr__ walks _parameters / _buffers / _modules on every access, and the hot path asked
+    for these ~130 times per iteration (65 us in decoder_supported, 45 us in the parameter list: tools/prof_enqueue.py)."""
+    cached = dec.__dict__.get("_fused_modules")
+    if cached is None:
+        pairs = [(getattr(dec, c), getattr(dec, b)) for c, b in _decoder_bn_layers()]
+        outs = [getattr(dec, f"conv8{t}") for t in _HEAD_TAGS]
+        cached = dec.__dict__["_fused_modules"] = (pairs, outs)
+    return cached
+
+
 def decoder_supported(dec, x) -> bool:
-    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and not dec.use_relu
-            and dec.hsize == 128 and dec.in_size <= _K1_PAD and x.shape[1] in (dec.in_size, _K1_PAD)
-            and all(getattr(dec, bn).training == dec.training and getattr(dec, bn).affine
-                    and getattr(dec, bn).momentum is not None for _, bn in _decoder_bn_layers())
-            and (dec.training or not torch.is_grad_enabled()))
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and not dec.use_relu
+            and dec.hsize == 128 and dec.in_size <= _K1_PAD and x.shape[1] in (dec.in_size, _K1_PAD)):
+        return False
+    training = dec.training
+    for _, bn in _decoder_modules(dec)[0]:
+        if bn.training != training or not bn.affine or bn.momentum is None:
+            return False
+    return training or not torch.is_grad_enabled()
 
 
 def _decoder_bn_layers():
@@ -603,12 +618,27 @@ _NATIVE_DECODER = _dev.knobs.native_decoder
 def _native_decoder_ok(dec, M, sync) -> bool:
     if not (_NATIVE_DECODER and _FUSED_BWD and dec.training and not sync and M % 32 == 0):
         return False
-    tracks = [getattr(dec, bn).track_running_stats for _, bn in _decoder_bn_layers()]
+    tracks = [bn.track_running_stats for _, bn in _decoder_modules(dec)[0]]
     return all(tracks) or not any(tracks)
 
 
 def _native_decoder_params(dec, params, nl):
-    """GanetDecoderParams for the module's current tensors (and the tensors it points at, to keep them alive)."""
+    """GanetDecoderParams for the module's current tensors (and the tensors it points at, to keep them alive). The struct
+    is rebuilt only when a tensor moved: the optimiser updates parameters in place, so an iteration re-uses the previous
+    one's (75 us per build, twice per iteration)."""
+    bns = [bn for _, bn in _decoder_modules(dec)[0]]
+    key = tuple([p.data_ptr() for p in params] +
+                [bn.running_mean.data_ptr() if bn.track_running_stats else 0 for bn in bns])
+    cached = dec.__dict__.get("_fused_P")
+    if cached is not None and cached[0] == key:
+        return cached[1], cached[2]
+    P, keep = _build_decoder_params(dec, params, nl)
+    if all(p.is_contiguous() for p in params):       # (a contiguous COPY of a strided weight would go stale in the cache)
+        dec.__dict__["_fused_P"] = (key, P, keep)
+    return P, keep
+
+
+def _build_decoder_params(dec, params, nl):
     from ._native import GanetDecoderParams
     P = GanetDecoderParams()
     P.cin = dec.in_size
@@ -1166,12 +1196,11 @@ def decoder_mlp(dec, x, m_global=None):
 
 
 def _decoder_param_list(dec):
+    pairs, outs = _decoder_modules(dec)
     params = []
-    for conv, bn in _decoder_bn_layers():
-        c, b = getattr(dec, conv), getattr(dec, bn)
+    for c, b in pairs:
         params += [c.weight, c.bias, b.weight, b.bias]
-    for t in _HEAD_TAGS:
-        c = getattr(dec, f"conv8{t}")
+    for c in outs:
         params += [c.weight, c.bias]
     return params
 

@@ -20,7 +20,7 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 def _stream(device):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return ctypes.c_void_p(_native.raw_stream(device))
 
 
 def _require_cuda(t: torch.Tensor, what: str):

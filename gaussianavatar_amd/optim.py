@@ -34,7 +34,6 @@ class Adam(torch.optim.Adam):
                          fused=False)
         self._table = (_native.GanetAdamTensor * 64)()
         self.skip_on_overflow = True      # read the rasterizer's overflow flag (see the module docstring)
-        self._layout_checked = set()      # parameters whose layout (and whose moments' layout) has been verified
 
     def _skip_flag(self, device):
         if not self.skip_on_overflow:
@@ -80,32 +79,26 @@ class Adam(torch.optim.Adam):
             lr = float(group["lr"])
             for p in params:
                 g = p.grad
-                if g.is_sparse or not p.is_cuda or p.dtype != torch.float32:
-                    raise RuntimeError("gaussianavatar_amd.optim.Adam: dense float32 CUDA parameters only")
                 st = self.state[p]
-                if "exp_avg" not in st:
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                fixed = st.get("_row")          # (param ptr, moment ptrs, numel): verified once, valid while the tensors stay put
+                if (fixed is None or fixed[0] != p.data_ptr() or fixed[1] != st["exp_avg"].data_ptr()
+                        or fixed[2] != st["exp_avg_sq"].data_ptr()):
+                    fixed = self._verify(p, st)
                 st["step"] = shared
                 # the update is element-wise over memory: parameter, gradient and moments must be dense and share
                 # ONE layout (row-major or channels-last; the moments are created with the parameter's)
+                if g.is_sparse:
+                    raise RuntimeError("gaussianavatar_amd.optim.Adam: dense float32 CUDA parameters only")
                 if g.stride() != p.stride() and not _same_layout(g, p):      # (tuple compare first: this runs per tensor and step)
                     g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
                     p.grad = g
-                if p not in self._layout_checked:          # once per parameter (and again after load_state_dict)
-                    if not (p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))):
-                        raise RuntimeError("gaussianavatar_amd.optim.Adam: parameters must be dense (contiguous or channels-last)")
-                    for key in ("exp_avg", "exp_avg_sq"):  # (a checkpoint written with another layout)
-                        if not _same_layout(st[key], p):
-                            st[key] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st[key])
-                    self._layout_checked.add(p)
                 if stream is None:
-                    stream = torch.cuda.current_stream(p.device).cuda_stream
+                    stream = _native.raw_stream(p.device)
                     skip = self._skip_flag(p.device)
                 row = table[n]
-                row.param, row.grad = p.data_ptr(), g.data_ptr()
-                row.exp_avg, row.exp_avg_sq = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
-                row.n, row.lr, row.bias_correction1, row.bias_correction2 = p.numel(), lr, bc1, bc2
+                row.param, row.exp_avg, row.exp_avg_sq, row.n = fixed
+                row.grad = g.data_ptr()
+                row.lr, row.bias_correction1, row.bias_correction2 = lr, bc1, bc2
                 n += 1
                 if n == 64:
                     _native.ganet_check(lib.ganet_adam_step(n, table, *args, skip, stream))
@@ -116,19 +109,37 @@ class Adam(torch.optim.Adam):
             _native.ganet_check(lib.ganet_flag_clear(skip, stream))
         return loss
 
+    def _verify(self, p, st):
+        """First step of a parameter (or after it / its state moved): type and layout checks, moments created with the
+        parameter's layout; returns the row's fixed part."""
+        if not p.is_cuda or p.dtype != torch.float32:
+            raise RuntimeError("gaussianavatar_amd.optim.Adam: dense float32 CUDA parameters only")
+        if "exp_avg" not in st:
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        if not (p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))):
+            raise RuntimeError("gaussianavatar_amd.optim.Adam: parameters must be dense (contiguous or channels-last)")
+        for key in ("exp_avg", "exp_avg_sq"):          # (a checkpoint written with another layout)
+            if not _same_layout(st[key], p):
+                st[key] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st[key])
+        st["_row"] = (p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
+        return st["_row"]
+
     def state_dict(self):
         sd = super().state_dict()
         for g in sd["param_groups"]:
             g.pop("_shared_step", None)
         # one independent `step` tensor per parameter, as torch writes them
         for st in sd["state"].values():
+            st.pop("_row", None)
             if "step" in st:
                 st["step"] = st["step"].detach().clone()
         return sd
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
-        self._layout_checked.clear()
+        for st in self.state.values():
+            st.pop("_row", None)
         for group in self.param_groups:
             group.pop("_shared_step", None)
         for st in self.state.values():

@@ -94,6 +94,38 @@ def rank() -> int:
 _flag_work = None
 _flag_posts = []          # (work, snapshot, flag) of the reductions in flight
 
+# Optional timing of the data-path collectives (bench.py: the per-rank breakdown of a multi-GPU line): HIP events on the
+# current stream around each call, i.e. the time the stream spends in / waiting for the collective.
+_timing = None
+
+
+def timing_enable(on: bool = True) -> None:
+    global _timing
+    _timing = [] if on else None
+
+
+def timing_read(reset: bool = True) -> dict:
+    """{tag: (total ms, calls)} of the collectives since the last reset (blocks until their events completed)."""
+    out = {}
+    for s_ev, e_ev, tag in (_timing or []):
+        e_ev.synchronize()
+        ms, n = out.get(tag, (0.0, 0))
+        out[tag] = (ms + s_ev.elapsed_time(e_ev), n + 1)
+    if reset and _timing is not None:
+        _timing.clear()
+    return out
+
+
+def _collective(tag: str, fn, tensor, **kw):
+    if _timing is None or not tensor.is_cuda:
+        return fn(tensor, **kw)
+    s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s_ev.record()
+    r = fn(tensor, **kw)
+    e_ev.record()
+    _timing.append((s_ev, e_ev, tag))
+    return r
+
 
 def post_overflow_flag(device) -> None:
     """The rasterizer's backward pass raises a device-side flag on the rank whose forward pass overflowed (that
@@ -134,7 +166,7 @@ class _ExchangeGrad(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=_group)
+        _collective("allreduce_output_grads", dist.all_reduce, g, op=dist.ReduceOp.SUM, group=_group)
         post_overflow_flag(g.device)
         return g / dist.get_world_size(_group)
 
@@ -153,7 +185,7 @@ def allreduce_param_grads(params: List[torch.Tensor], average: bool = True) -> N
     if not grads:
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=_group)
+    _collective("allreduce_param_grads", dist.all_reduce, flat, op=dist.ReduceOp.SUM, group=_group)
     if _flag_work is None:          # stage 2: no output-gradient exchange has posted the flag's reduction yet
         post_overflow_flag(flat.device)
     if average:
@@ -253,9 +285,9 @@ def broadcast_(t: torch.Tensor, src: int = 0) -> torch.Tensor:
     return t
 
 
-def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
+def all_reduce_sum_(t: torch.Tensor, tag: str = "allreduce_batchnorm_sums") -> torch.Tensor:
     if world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_group)
+        _collective(tag, dist.all_reduce, t, op=dist.ReduceOp.SUM, group=_group)
     return t
 
 
@@ -309,7 +341,7 @@ class _GatherSegments(torch.autograd.Function):
             full[off_f + c * n0: off_f + c * (n0 + n_local)] = local[off_l: off_l + c * n_local]
             off_f += c * n_total
             off_l += c * n_local
-        dist.all_reduce(full, op=dist.ReduceOp.SUM, group=_group)
+        _collective("allreduce_texel_records", dist.all_reduce, full, op=dist.ReduceOp.SUM, group=_group)
         ctx.dims = (n0, n_local, n_total, seg)
         return full
 
@@ -317,7 +349,7 @@ class _GatherSegments(torch.autograd.Function):
     def backward(ctx, g):
         n0, n_local, n_total, seg = ctx.dims
         g = g.contiguous().clone()
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=_group)
+        _collective("allreduce_texel_record_grads", dist.all_reduce, g, op=dist.ReduceOp.SUM, group=_group)
         post_overflow_flag(g.device)
         g /= dist.get_world_size(_group)
         parts, off = [], 0

@@ -279,7 +279,7 @@ def _f32c(t: torch.Tensor, shape=None) -> torch.Tensor:
 
 
 def _stream_ptr(device) -> ctypes.c_void_p:
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return ctypes.c_void_p(_native.raw_stream(device))
 
 
 def _settings_struct(rs: GaussianRasterizationSettings, keep: list) -> "_native.GsrSettings":

@@ -148,6 +148,46 @@ def test_stage2_image_and_gradients_match_cpu_reference_formulas(smpl_type, rast
     assert image.shape == (2, 3, 80, 96) and torch.isfinite(loss)
 
 
+def test_stage1_on_a_uv_map_whose_texel_count_is_not_a_multiple_of_32(raster_oracle, monkeypatch):
+    """A 60 x 60 query map (3,600 decoder rows: 3,600 % 32 = 16) at the production widths (c_geom 64, hsize 128): the
+    one-call decoder and the one-pass layer backward need whole 32-row slabs, so THIS configuration runs on the
+    per-launch path with the separate weight- / data-gradient kernels (csrc/ganet_mlp_bwd.hip, ganet_wgrad_split.hip) —
+    the reason those kernels stay in the library. Image, regularisers and every gradient against the
+    all-CPU evaluation of the reference's formulas (tests/cpu_reference.py)."""
+    from gaussianavatar_amd import fused
+    from gaussianavatar_amd.avatar_model import AvatarModel, collate_frames, default_params
+    from tests import cpu_reference
+    from tests.grad_check import assert_grads_close
+    torch.manual_seed(0)
+    mp, npar, op = default_params(batch_size=2, num_points=2500, query_posmap_size=60, inp_posmap_size=64,
+                                  image_width=96, image_height=96, num_frames=4, train_stage=1)
+    m = AvatarModel(mp, npar, op, train=True)
+    m.training_setup()
+    used = {"wgrad": 0, "bwd_data": 0, "fused": 0}
+    lib = fused._native.ganet()
+    for name, key in (("ganet_wgrad_act", "wgrad"), ("ganet_mlp_bwd_data", "bwd_data"), ("ganet_mlp_bwd_fused", "fused")):
+        real = getattr(lib, name)
+        def counted(*a, _real=real, _key=key):
+            used[_key] += 1
+            return _real(*a)
+        monkeypatch.setattr(lib, name, counted)
+    batch = collate_frames([m.train_dataset[i] for i in (0, 2)], "cuda")
+    snap = cpu_reference.snapshot(m)
+    image, pts, offset_loss, geo_loss, scale_loss = m.train_stage1(batch, 300)
+    w = torch.linspace(0.5, 1.5, image.numel(), device="cuda").reshape(image.shape)
+    loss = ((1 - image) * w).mean() + 10 * offset_loss + geo_loss + 0.03 * scale_loss
+    m.zero_grad(1)
+    loss.backward()
+    assert used["wgrad"] >= 12 and used["bwd_data"] >= 10 and used["fused"] == 0, used
+    ref = cpu_reference.forward(m, snap, {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in batch.items()},
+                                300, raster_oracle, stage=1)
+    assert float((image.detach().cpu() - ref["image"].detach()).abs().mean()) <= 1e-4
+    (((1 - ref["image"]) * w.cpu()).mean() + 10 * ref["offset_loss"] + ref["geo_loss"] + 0.03 * ref["scale_loss"]).backward()
+    pairs = [("net." + k, p.grad, dict(snap["net"].named_parameters())[k].grad) for k, p in m.net.named_parameters()]
+    pairs.append(("geo", m.geo_feature.grad, snap["geo"].grad))
+    assert_grads_close(pairs, rel=5e-3, floor=2e-4, cos_tol=1e-4)
+
+
 def test_render_free_stage2_uses_the_learned_pose_embeddings():
     """/root/reference/model/avatar_model.py:555-560: stage-2 evaluation looks the pose up by `pose_idx`."""
     from gaussianavatar_amd.avatar_model import collate_frames
