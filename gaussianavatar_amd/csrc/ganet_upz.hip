@@ -457,26 +457,37 @@ dz_upsample_t_kernel(UpGrid g, const int32_t* __restrict__ rptr, const int32_t* 
 #ifndef GANET_DZM_ABLATE
 #define GANET_DZM_ABLATE 0     // development (tools/dzm_ablate.sh): 1 no reduce phase, 2 no staging (loads only), 4 no Z loads,
 #endif                         // 8 no barriers, 16 natural tile order and sweep direction, 32 no db / dW_uv sums
-constexpr int DZM_WG = 1024;       // 16 waves: 32 column slots x 32 float4 in the load phase; (pixel column, channel half) in the reduce phase
+#ifndef GANET_DZM_WG
+#define GANET_DZM_WG 1024
+#endif
+#ifndef GANET_DZM_P
+#define GANET_DZM_P 8
+#endif
+constexpr int DZM_WG = GANET_DZM_WG;   // 1024 threads x 8 pixel rows per tile. Measured on one box (512^2 map, us per launch): 1024 / 8:
+                                       // 72.4; 512 / 4 (two workgroups per CU, so that one computes while the other waits at its row
+                                       // barrier): 74.0; 512 / 8: 82.9 — the per-row arithmetic ADDS to the load time either way
+                                       // (ablation builds: loads only 56-62 us)
 constexpr int DZM_Q = 8;
-constexpr int DZM_P = 8;
-constexpr int DZM_COLS = 48;       // texel columns a tile may span (2 load rounds of 32 slots, the second half used); x4 grid: 36
+constexpr int DZM_P = GANET_DZM_P;
+constexpr int DZM_COLS = 48;           // texel columns a tile may span; x4 grid: 36
+constexpr int DZM_SLOTS = DZM_WG / 32; // column slots of the load phase (x 32 float4 of channels)
+constexpr int DZM_NR = DZM_COLS / DZM_SLOTS;      // load rounds per row
+constexpr int DZM_NW = DZM_WG / 64;
+constexpr int DZM_CPL = 128 / (64 * (DZM_NW / DZM_Q));   // channels per lane in the reduce phase (8 waves: 2, 16 waves: 1)
+static_assert(DZM_NW == 8 || DZM_NW == 16, "reduce-phase mapping");
 
-// (Ablation builds, 512 threads: as shipped 78 us; loads only 56; without the db / dW_uv sums 67; without the reduce phase 71;
-// G only 62 — i.e. NOT bandwidth-bound: with 8 waves per CU the per-row arithmetic was issue-bound. Hence 16 waves, and
-// branch-free sums.)
-__global__ void __launch_bounds__(DZM_WG)
+__global__ void __attribute__((amdgpu_flat_work_group_size(DZM_WG, DZM_WG), amdgpu_waves_per_eu(4, 4)))
 dz_upsample_march_kernel(UpGrid g, const int32_t* __restrict__ rptr, const int32_t* __restrict__ rsrc,
                          const int32_t* __restrict__ cptr, const int32_t* __restrict__ csrc,
                          const float* __restrict__ cwt, const float* __restrict__ G, const float* __restrict__ Z,
                          const float* __restrict__ coef, float* __restrict__ dP, int64_t ldp, float* __restrict__ partial) {
   __shared__ float s_dz[2][DZM_COLS][128];            // 48 KB
-  __shared__ float s_acc[DZM_P][DZM_Q][128];          // 32 KB
+  __shared__ float s_acc[DZM_P][DZM_Q][128];          // 16 KB (P = 4)
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
-  const int c4 = tid & 31, slot = tid >> 5;            // load phase: channels 4 c4 .. + 3 of texel columns slot, slot + 32
-  const int wq = wave & 7, ch = 64 * (wave >> 3) + lane;      // reduce phase: pixel column wq of the tile, channel ch
+  const int c4 = tid & 31, slot = tid >> 5;            // load phase: channels 4 c4 .. + 3 of texel columns slot, slot + SLOTS, ...
+  const int wq = wave & 7, ch = DZM_CPL * (64 * (wave >> 3) + lane);    // reduce phase: pixel column wq, channels ch .. + CPL - 1
   const int S = g.S, R = g.R;
   const int64_t SS = (int64_t)S * S;
   const int nchunk = (R + DZM_P - 1) / DZM_P, nstrip = (R + DZM_Q - 1) / DZM_Q;
@@ -491,7 +502,9 @@ dz_upsample_march_kernel(UpGrid g, const int32_t* __restrict__ rptr, const int32
   const int pc0 = chunk * DZM_P, pc1 = min(R, pc0 + DZM_P);
   const int q = q0 + wq;
 #pragma unroll
-  for (int p = 0; p < DZM_P; ++p) s_acc[p][wq][ch] = 0.f;
+  for (int p = 0; p < DZM_P; ++p)
+#pragma unroll
+    for (int e = 0; e < DZM_CPL; ++e) s_acc[p][wq][ch + e] = 0.f;
   float sb[4] = {0.f, 0.f, 0.f, 0.f}, su[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {0.f, 0.f, 0.f, 0.f};
   const int e0 = rptr[pc0], e1 = rptr[pc1], d0 = cptr[q0], d1 = cptr[q1];
   if (e1 > e0 && d1 > d0) {                            // (uniform) the tile has taps at all
@@ -500,14 +513,14 @@ dz_upsample_march_kernel(UpGrid g, const int32_t* __restrict__ rptr, const int32
     const int nrow = i_hi - i_lo + 1;
     const bool up = (chunk & 1) != 0 && !(GANET_DZM_ABLATE & 16);      // odd chunks sweep bottom-up
     auto row_at = [&](int k) { return up ? i_hi - min(k, nrow - 1) : i_lo + min(k, nrow - 1); };
-    // this thread's texel columns (two rounds) and whether the tile owns them (first column tap inside the strip)
-    int jc[2];
-    bool jon[2];
-    float jown[2];
+    // this thread's texel columns and whether the tile owns them (first column tap inside the strip)
+    int jc[DZM_NR];
+    bool jon[DZM_NR];
+    float jown[DZM_NR];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int j = j_lo + slot + 32 * r;
-      jon[r] = j <= j_hi && slot + 32 * r < DZM_COLS;
+    for (int r = 0; r < DZM_NR; ++r) {
+      const int j = j_lo + slot + DZM_SLOTS * r;
+      jon[r] = j <= j_hi;
       jc[r] = jon[r] ? j : j_hi;
       const int qa = g.col_idx[2 * jc[r]];
       jown[r] = (jon[r] && qa >= q0 && qa < q1 && !(GANET_DZM_ABLATE & 32)) ? 1.f : 0.f;
@@ -533,11 +546,11 @@ dz_upsample_march_kernel(UpGrid g, const int32_t* __restrict__ rptr, const int32
     // counter is in order — i.e. for the prefetched rows)
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    struct Row { f32x4 gv[2], zv[2]; f32x2 uv[2]; };
+    struct Row { f32x4 gv[DZM_NR], zv[DZM_NR]; f32x2 uv[DZM_NR]; };
     auto load_row = [&](Row& r, int k) {
       const int64_t rowbase = (int64_t)row_at(k) * S;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < DZM_NR; ++t) {
         r.gv[t] = *reinterpret_cast<const f32x4*>(Gf + (rowbase + jc[t]) * 128);
         if (!(GANET_DZM_ABLATE & 4)) r.zv[t] = *reinterpret_cast<const f32x4*>(Zf + (rowbase + jc[t]) * 128);
         else r.zv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -549,14 +562,14 @@ dz_upsample_march_kernel(UpGrid g, const int32_t* __restrict__ rptr, const int32
       const int pa = g.row_idx[2 * i];                 // scalar load
       const float own_row = (pa >= pc0 && pa < pc1) ? 1.f : 0.f;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < DZM_NR; ++t) {
         f32x4 d;
         d.x = fmaf(cA.x, r.gv[t].x, fmaf(cQ.x, r.zv[t].x, cP.x));
         d.y = fmaf(cA.y, r.gv[t].y, fmaf(cQ.y, r.zv[t].y, cP.y));
         d.z = fmaf(cA.z, r.gv[t].z, fmaf(cQ.z, r.zv[t].z, cP.z));
         d.w = fmaf(cA.w, r.gv[t].w, fmaf(cQ.w, r.zv[t].w, cP.w));
         if (GANET_DZM_ABLATE & 2) { sb[0] += d.x + d.y + d.z + d.w; continue; }
-        if (jon[t]) *reinterpret_cast<f32x4*>(&s_dz[k & 1][slot + 32 * t][4 * c4]) = d;
+        if (jon[t]) *reinterpret_cast<f32x4*>(&s_dz[k & 1][slot + DZM_SLOTS * t][4 * c4]) = d;
         // db / dW_uv, branch-free: the texel counts (m = 1) when the tile owns it
         const float m = own_row * jown[t], mu = m * r.uv[t].x, mv = m * r.uv[t].y;
         sb[0] = fmaf(m, d.x, sb[0]); sb[1] = fmaf(m, d.y, sb[1]); sb[2] = fmaf(m, d.z, sb[2]); sb[3] = fmaf(m, d.w, sb[3]);
@@ -564,44 +577,54 @@ dz_upsample_march_kernel(UpGrid g, const int32_t* __restrict__ rptr, const int32
         sv[0] = fmaf(mv, d.x, sv[0]); sv[1] = fmaf(mv, d.y, sv[1]); sv[2] = fmaf(mv, d.z, sv[2]); sv[3] = fmaf(mv, d.w, sv[3]);
       }
     };
-    auto reduce_row = [&](int k) {                     // wave = (pixel column q, channel half): horizontal taps, vertical scatter
+    auto reduce_row = [&](int k) {                     // wave = (pixel column q[, channel half]): horizontal taps, vertical scatter
       if (!q_on || (GANET_DZM_ABLATE & 1)) return;
       const int i = row_at(k);
       const int pa = g.row_idx[2 * i], pb = g.row_idx[2 * i + 1];        // scalar loads
       const float wa = g.row_w[2 * i], wb = g.row_w[2 * i + 1];
-      float h = 0.f;
+      float h[DZM_CPL];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) h = fmaf(wt[t], s_dz[k & 1][jt[t]][ch], h);
-      for (int cb = c0 + 8; cb < c1; ++cb) h = fmaf(cwt[cb], s_dz[k & 1][csrc[cb] - j_lo][ch], h);   // (not the x4 grid)
-      if (wa != 0.f && pa >= pc0 && pa < pc1) s_acc[pa - pc0][wq][ch] = fmaf(wa, h, s_acc[pa - pc0][wq][ch]);
-      if (wb != 0.f && pb >= pc0 && pb < pc1) s_acc[pb - pc0][wq][ch] = fmaf(wb, h, s_acc[pb - pc0][wq][ch]);
+      for (int e = 0; e < DZM_CPL; ++e) h[e] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int e = 0; e < DZM_CPL; ++e) h[e] = fmaf(wt[t], s_dz[k & 1][jt[t]][ch + e], h[e]);
+      for (int cb = c0 + 8; cb < c1; ++cb)             // (more than 8 column taps: not the x4 grid)
+#pragma unroll
+        for (int e = 0; e < DZM_CPL; ++e) h[e] = fmaf(cwt[cb], s_dz[k & 1][csrc[cb] - j_lo][ch + e], h[e]);
+      if (wa != 0.f && pa >= pc0 && pa < pc1)
+#pragma unroll
+        for (int e = 0; e < DZM_CPL; ++e) s_acc[pa - pc0][wq][ch + e] = fmaf(wa, h[e], s_acc[pa - pc0][wq][ch + e]);
+      if (wb != 0.f && pb >= pc0 && pb < pc1)
+#pragma unroll
+        for (int e = 0; e < DZM_CPL; ++e) s_acc[pb - pc0][wq][ch + e] = fmaf(wb, h[e], s_acc[pb - pc0][wq][ch + e]);
     };
-    // rows k = 0 .. nrow - 1; loads two rows ahead (three register sets used in turn)
-    Row r0, r1, r2;
+    // rows k = 0 .. nrow - 1; loads one row ahead (two register sets): the other workgroup of the CU covers the rest
+    Row r0, r1;
     load_row(r0, 0);
-    load_row(r1, 1);
     auto do_row = [&](Row& cur, Row& refill, int k) {
-      load_row(refill, k + 2);
+      load_row(refill, k + 1);
       __builtin_amdgcn_sched_barrier(0);
       stage_row(cur, k);
       if (!(GANET_DZM_ABLATE & 8)) __syncthreads();
       reduce_row(k);
     };
-    for (int k = 0; k < nrow; k += 3) {
-      do_row(r0, r2, k);
+    for (int k = 0; k < nrow; k += 2) {
+      do_row(r0, r1, k);
       if (k + 1 < nrow) do_row(r1, r0, k + 1);
-      if (k + 2 < nrow) do_row(r2, r1, k + 2);
     }
   }
   if (q < q1) {
 #pragma unroll
     for (int p = 0; p < DZM_P; ++p)
-      if (pc0 + p < pc1) dP[(((int64_t)f * R + pc0 + p) * R + q) * ldp + ch] = s_acc[p][wq][ch];
+      if (pc0 + p < pc1)
+#pragma unroll
+        for (int e = 0; e < DZM_CPL; ++e) dP[(((int64_t)f * R + pc0 + p) * R + q) * ldp + ch + e] = s_acc[p][wq][ch + e];
   }
   if (!partial) return;
-  // db / dWuv: 32 column slots x 32 channel quads -> [128 x 2 | 128] per workgroup, through the (now idle) row image
+  // db / dWuv: SLOTS column slots x 32 channel quads -> [128 x 2 | 128] per workgroup, through the (now idle) row image
   __syncthreads();
-  float* red = &s_dz[0][0][0];                         // [32 slots][3][128] = all of it
+  float* red = &s_dz[0][0][0];                         // [SLOTS][3][128] <= the image's 48 KB
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     red[(slot * 3 + 0) * 128 + 4 * c4 + e] = sb[e];
@@ -613,7 +636,7 @@ dz_upsample_march_kernel(UpGrid g, const int32_t* __restrict__ rptr, const int32
     const int k = tid >> 7, n = tid & 127;
     float sum = 0.f;
 #pragma unroll
-    for (int sl = 0; sl < 32; ++sl) sum += red[(sl * 3 + k) * 128 + n];
+    for (int sl = 0; sl < DZM_SLOTS; ++sl) sum += red[(sl * 3 + k) * 128 + n];
     float* out = partial + (size_t)blockIdx.x * DZT_PART;
     if (k == 0) out[256 + n] = sum;                    // db
     else out[n * 2 + (k - 1)] = sum;                   // dWuv[n][0] (u), dWuv[n][1] (v)
