@@ -634,6 +634,7 @@ def main():
         probe_n = fused.profile_read(reset=True)
         probe_c = parallel.timing_read()
         parallel.timing_enable(False)
+        pev[1].synchronize()
         probe_ms = pev[0].elapsed_time(pev[1]) / probe
         rasterizer.profile_enable(False)
         fused.profile_enable(False)

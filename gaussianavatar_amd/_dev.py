@@ -6,6 +6,7 @@ ONE variable, `GA_DEV="key=value,key=value"`, read once at import; without it ev
     lib_dir=<path>      load libgsr / libgalbs / libganet from <path> instead of gaussianavatar_amd/_lib
                         (A/B runs of a variant build, tools/build_variant.sh)
     wgrad_stream=0      decoder backward: the weight-gradient launches on the main stream instead of the side stream
+    unet_wgrad_stream=0 stage 2: the pose encoder's weight gradients on the main stream (ganet_unet_bwd without a side stream)
     row_sweep=0         decoder: every launch sweeps the rows first-to-last (no alternation)
     native_decoder=0    decoder: the per-layer launch sequence from Python instead of one native call each way
     one_pass_backward=0 decoder: separate weight- / data-gradient kernels for the hidden layers
@@ -26,6 +27,7 @@ from dataclasses import dataclass, fields
 class DevKnobs:
     lib_dir: str = ""
     wgrad_stream: bool = True
+    unet_wgrad_stream: bool = True
     row_sweep: bool = True
     native_decoder: bool = True
     one_pass_backward: bool = True

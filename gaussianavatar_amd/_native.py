@@ -339,7 +339,7 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_unet_bwd_workspace.restype = c_size_t
         lib.ganet_unet_bwd_workspace.argtypes = [P, c_int32]
         lib.ganet_unet_bwd.restype = c_int
-        lib.ganet_unet_bwd.argtypes = [P, c_int32, P, P, P, P, P, c_size_t, P]
+        lib.ganet_unet_bwd.argtypes = [P, c_int32, P, P, P, P, P, c_size_t, P, P]
         lib.ganet_profile_create.restype = c_void_p
         lib.ganet_profile_create.argtypes = []
         lib.ganet_profile_destroy.restype = None
@@ -363,7 +363,7 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_conv5_wgrad.argtypes = [c_int32, c_int32, c_int32, P, P, P, P, c_size_t, P]
         lib.ganet_last_error.restype = c_char_p
         lib.ganet_abi_version.restype = c_int
-        if lib.ganet_abi_version() != 7:
+        if lib.ganet_abi_version() != 8:
             raise RuntimeError("libganet_hip.so ABI version mismatch; rebuild")
         _ganet = lib
     return _ganet

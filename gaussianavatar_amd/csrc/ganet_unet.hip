@@ -751,7 +751,7 @@ size_t ganet_unet_bwd_workspace(const GanetUnetParams* p, int32_t B) {
 // d_out: [B, S, S, cout] channels-last. Gradients in the parameters' own layouts: dWd[k] like Wd[k]
 // ([co][ci][4][4]), dWu[k] like Wu[k] ([ci][co][4][4]), dbias5 [cout]. (The input x has no gradient.)
 int ganet_unet_bwd(const GanetUnetParams* p, int32_t B, const float* x, const float* saved_, const float* d_out,
-                   const GanetUnetGrads* gr, void* workspace, size_t workspace_bytes, void* stream_) {
+                   const GanetUnetGrads* gr, void* workspace, size_t workspace_bytes, void* stream_, void* side_stream_) {
   if (!unet_ok(p, B) || !x || !saved_ || !d_out || !gr || !workspace || !gr->dbias5) {
     set_error("ganet_unet_bwd: invalid arguments");
     return 1;
@@ -759,6 +759,28 @@ int ganet_unet_bwd(const GanetUnetParams* p, int32_t B, const float* x, const fl
   for (int k = 0; k < 5; ++k) if (!gr->dWd[k] || !gr->dWu[k]) { set_error("ganet_unet_bwd: missing gradient buffer"); return 1; }
   if (workspace_bytes < ganet_unet_bwd_workspace(p, B)) { set_error("ganet_unet_bwd: workspace too small"); return 2; }
   hipStream_t st = static_cast<hipStream_t>(stream_);
+  hipStream_t side = static_cast<hipStream_t>(side_stream_);
+  // The input-gradient chain (dgrad_k -> BatchNorm coefficients -> dgrad_k-1 ...) is the critical path; a layer's weight
+  // gradient hangs off it (it needs dz_k, nothing needs it): side stream, ordered by events as in ganet_decoder_bwd.
+  // Both chains are launches of a few workgroups x a few microseconds, so they overlap almost entirely. The side stream's
+  // launches share `wgpart` (serial on that stream) and only READ what the main stream produced before the fork.
+  static thread_local hipEvent_t ev_main_dev[64] = {}, ev_side_dev[64] = {};
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  hipEvent_t& ev_main = ev_main_dev[dev_ & 63];
+  hipEvent_t& ev_side = ev_side_dev[dev_ & 63];
+  if (side && !ev_main) {
+    GA_TRY(check_hip(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming), "hipEventCreate"));
+    GA_TRY(check_hip(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming), "hipEventCreate"));
+  }
+  auto fork = [&](hipStream_t* out) -> int {      // the stream for work that depends on everything enqueued on `st` so far
+    *out = st;
+    if (!side) return 0;
+    GA_TRY(check_hip(hipEventRecord(ev_main, st), "hipEventRecord"));
+    GA_TRY(check_hip(hipStreamWaitEvent(side, ev_main, 0), "hipStreamWaitEvent"));
+    *out = side;
+    return 0;
+  };
   const Net n = make_net(p, B);
   const Saved sv = carve_saved(n, const_cast<float*>(saved_));
   float* wsf = static_cast<float*>(workspace);
@@ -792,10 +814,12 @@ int ganet_unet_bwd(const GanetUnetParams* p, int32_t B, const float* x, const fl
     for (int i = 0; i < nu; ++i) w.U[i] = U[i];
     w.V = V; w.part = wgpart;
     const int M = B * Hc * Hc, nchunk = (M + 255) / 256;
-    hipLaunchKernelGGL(uwgrad_kernel, dim3(16, (I / 32) * (J / 32), nchunk), dim3(UW_WG), 0, st, w);
+    hipStream_t ws;
+    GA_TRY(fork(&ws));
+    hipLaunchKernelGGL(uwgrad_kernel, dim3(16, (I / 32) * (J / 32), nchunk), dim3(UW_WG), 0, ws, w);
     GA_TRY(check_hip(hipGetLastError(), "uwgrad_kernel"));
     const int64_t tot = (int64_t)16 * I * J;
-    hipLaunchKernelGGL(uwgrad_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, nchunk, I, J, sI, sJ,
+    hipLaunchKernelGGL(uwgrad_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ws, nchunk, I, J, sI, sJ,
                        wgpart, dW);
     return check_hip(hipGetLastError(), "uwgrad_reduce_kernel");
   };
@@ -820,8 +844,10 @@ int ganet_unet_bwd(const GanetUnetParams* p, int32_t B, const float* x, const fl
     const int ci = in[0].C + (nin > 1 ? in[1].C : 0);
     if (k == 5) {      // bias gradient: column sums of d_out
       const int M = B * n.S * n.S, nchunk = (M + 255) / 256;
-      hipLaunchKernelGGL(ucolsum_kernel, dim3((co + 63) / 64, nchunk), dim3(256), 0, st, M, co, 256, d_out, wgpart);
-      hipLaunchKernelGGL(usum_chunks_kernel, dim3((co + 255) / 256), dim3(256), 0, st, nchunk, (int64_t)co, wgpart, gr->dbias5);
+      hipStream_t ws;
+      GA_TRY(fork(&ws));
+      hipLaunchKernelGGL(ucolsum_kernel, dim3((co + 63) / 64, nchunk), dim3(256), 0, ws, M, co, 256, d_out, wgpart);
+      hipLaunchKernelGGL(usum_chunks_kernel, dim3((co + 255) / 256), dim3(256), 0, ws, nchunk, (int64_t)co, wgpart, gr->dbias5);
       GA_TRY(check_hip(hipGetLastError(), "ucolsum kernels"));
     }
     // weight gradient dWT[ci][co][t] = sum_m in[m, ci] dz[gather_S(m, t), co]
@@ -872,10 +898,16 @@ int ganet_unet_bwd(const GanetUnetParams* p, int32_t B, const float* x, const fl
   {
     const int M = B * n.Hd[1] * n.Hd[1], nchunk = (M + 255) / 256;
     const int KC = n.cin * 16 * n.C[1];
-    hipLaunchKernelGGL(uconv1_wgrad_kernel, dim3(n.cin * 16, nchunk, (n.C[1] + 31) / 32), dim3(256), 0, st, B, n.cin, n.S,
+    hipStream_t ws;
+    GA_TRY(fork(&ws));
+    hipLaunchKernelGGL(uconv1_wgrad_kernel, dim3(n.cin * 16, nchunk, (n.C[1] + 31) / 32), dim3(256), 0, ws, B, n.cin, n.S,
                        n.C[1], 256, x, Gd[1], wgpart);
-    hipLaunchKernelGGL(usum_chunks_kernel, dim3((KC + 255) / 256), dim3(256), 0, st, nchunk, (int64_t)KC, wgpart, gr->dWd[0]);
+    hipLaunchKernelGGL(usum_chunks_kernel, dim3((KC + 255) / 256), dim3(256), 0, ws, nchunk, (int64_t)KC, wgpart, gr->dWd[0]);
     GA_TRY(check_hip(hipGetLastError(), "uconv1_wgrad kernels"));
+  }
+  if (side) {      // every gradient is ready in main-stream order
+    GA_TRY(check_hip(hipEventRecord(ev_side, side), "hipEventRecord"));
+    GA_TRY(check_hip(hipStreamWaitEvent(st, ev_side, 0), "hipStreamWaitEvent"));
   }
   return 0;
 }

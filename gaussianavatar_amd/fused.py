@@ -1279,8 +1279,10 @@ class _UnetFn(torch.autograd.Function):
         G.dbias5 = grads[10].data_ptr()
         wsb = lib.ganet_unet_bwd_workspace(ctypes.byref(P), B)
         wk = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        # (weight gradients on the side stream, ordered inside the call with events both ways: see ganet_decoder_bwd)
+        side = _side_stream(dev) if (_dev.knobs.unet_wgrad_stream and not _profiling) else None
         _native.ganet_check(lib.ganet_unet_bwd(ctypes.byref(P), B, _ptr(xc), _ptr(saved), _ptr(gh), ctypes.byref(G), _ptr(wk),
-                                               wsb, _stream(dev)))
+                                               wsb, _stream(dev), None if side is None else ctypes.c_void_p(side.cuda_stream)))
         return (None, None) + tuple(grads)
 
 

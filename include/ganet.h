@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GANET_ABI_VERSION 7
+#define GANET_ABI_VERSION 8
 #define GANET_MAX_TERMS 8
 
 /* ---- dW[N,K] = sum_m g[m,n] x[m,k] ; db[N] = sum_m g[m,n] (db may be NULL).
@@ -401,7 +401,9 @@ int ganet_decoder_map_bwd(const GanetUpGrid* grid, const float* feat, const Gane
  * conv2..4, 3..6 = upconv1..4 (running statistics updated like F.batch_norm(training=True); training = 0: the running
  * statistics normalise). saved (ganet_unet_saved_floats floats) keeps the raw layer outputs and the statistics for
  * the backward pass, which expects the forward pass to have run in training mode. Replaces ~40 im2col / GEMM /
- * col2im / batch_norm / element-wise launches per pass. */
+ * col2im / batch_norm / element-wise launches per pass. ganet_unet_bwd's side_stream (may be NULL) takes the weight
+ * gradients, which hang off the input-gradient chain; it is ordered against `stream` inside the call (events both
+ * ways), so every result is ready in `stream` order. */
 #define GANET_UNET_BN 7
 typedef struct GanetUnetParams {
   int32_t cin, nf, cout, S;
@@ -424,7 +426,7 @@ int ganet_unet_fwd(const GanetUnetParams* params, int32_t B, const float* x, int
                    void* workspace, size_t workspace_bytes, void* stream);
 size_t ganet_unet_bwd_workspace(const GanetUnetParams* params, int32_t B);
 int ganet_unet_bwd(const GanetUnetParams* params, int32_t B, const float* x, const float* saved, const float* d_out,
-                   const GanetUnetGrads* grads, void* workspace, size_t workspace_bytes, void* stream);
+                   const GanetUnetGrads* grads, void* workspace, size_t workspace_bytes, void* stream, void* side_stream);
 
 /* Optional per-kernel timing (bench/profiling only). The caller owns a GanetProfile object and binds it to the
  * calling thread; from then on every instrumented launch this thread makes whose kernel id is in `mask` is bracketed by

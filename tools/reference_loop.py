@@ -71,11 +71,16 @@ def main():
                 parts[name].append(time.perf_counter() - t)
         return w
 
+    pair_windows = []                                  # mean (tile, Gaussian) pairs per 2-frame launch, 40 iterations at a time
+
     def step(self, epoch):
         t = time.perf_counter()
         r = orig_step(self, epoch)
         stamps.append(time.perf_counter())
         parts["step"].append(stamps[-1] - t)
+        if len(stamps) % 40 == 0:                      # (blocks on the status records; the script's .item() is about to anyway)
+            from gaussianavatar_amd import rasterizer
+            pair_windows.append(round(rasterizer.pair_statistics(reset=True)[1]))
         return r
 
     orig = dict(stage1=AM.AvatarModel.train_stage1, zero=AM.AvatarModel.zero_grad, bwd=torch.Tensor.backward,
@@ -119,6 +124,7 @@ def main():
            "iterations": n, "timed": len(dt), "iters_per_s_mean": len(dt) / sum(dt),
            "ms_per_iter_median": 1e3 * dts[len(dts) // 2], "ms_per_iter_p10": 1e3 * dts[len(dts) // 10],
            "ms_per_iter_p90": 1e3 * dts[9 * len(dts) // 10], "dataset_write_s": t_write,
+           "pairs_per_launch_mean_by_40_iterations": pair_windows,
            "host_ms_inside_our_entry_points_median": {k: 1e3 * sorted(v[skip:])[len(v[skip:]) // 2] for k, v in parts.items() if len(v) > skip}}
     ours = sum(res["host_ms_inside_our_entry_points_median"].values())
     res["host_ms_script_own_code_and_item_wait_median"] = res["ms_per_iter_median"] - ours
