@@ -42,10 +42,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct USrc {
   const float* x;
   const float* g;
-  const float* sc;      // mode 1: scale [C];  mode 2: coef [3][C]
-  const float* sh;
+  const float* k3;      // [3][C]: the prologue as act(k0 g + k1 x + k2) — mode 0: (0, 1, 0); mode 1: (0, scale, shift); mode 2:
+                        // (cA, cQ, cP). Every producer of a scale / shift / coefficient writes this layout, so that a consumer
+                        // stages it with three plain loads (a load under a test of the mode is a serialised round trip)
   int C, mode;
-  float slope;
+  float slope;          // of the activation (1: none)
 };
 // where a tile of output channels goes, and what the epilogue does with it
 //   out (+)= val [+ bias];   dmode 1: val *= act'(z * sc + sh) (act = leaky(slope));
@@ -69,117 +70,197 @@ struct UGemm {
   USrc src[2];
   UDst dst[2];
   const float* Wp;        // [16][N][Ctot]
+  int nwk, ks;            // waves of a workgroup that share a tile (1, 2, 4, 8); workgroups that share a tile (K split)
+  float* kpart;           // ks > 1: [tile][ks][16][64] partial tiles
+  unsigned* ticket;       //         [tile] arrival counters (zero before the launch; the last workgroup leaves zero again)
 };
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
 
-constexpr int UG_WG = 512;       // 8 waves split the taps (and, pattern T, the channel chunks): the maps are small, a wave's
-                                 // serial chain of (tap, chunk) steps is what a launch takes
+constexpr int UG_WG = 512;       // 8 waves
+constexpr int UG_MAXC = 1024;    // K channels whose prologue coefficients are staged in LDS
 
-// PATTERN 0 = S, 1 = T (blockIdx.z = parity class)
-template <int PATTERN>
+// One GEMM step = (32-channel chunk, tap): 16 MFMAs (~0.45 us) behind two or three 64-byte loads per lane that come from L2
+// or HBM (1 - 3 us). The maps are tiny — M = 32 .. 8192 pixels a launch — so what a launch takes is the serial chain of
+// steps of its slowest wave plus launch overhead, and the first version (8 waves of ONE workgroup per tile, each step's
+// loads waited for before its MFMAs) spent 16 dependent round trips on a 4 x 4 map. Now:
+//   * a tile's steps are cut nwk x ks ways: nwk waves of a workgroup (partial tiles added through LDS) and ks workgroups
+//     (partial tiles through global memory; the LAST workgroup to arrive — a ticket per tile — adds them in a fixed
+//     order and runs the epilogue: deterministic, no extra launch). The host picks them so that a launch has ~2048 waves;
+//   * with nwk < 8 a workgroup holds 8 / nwk tiles (large maps: no partial sums at all);
+//   * the loads of step s + 1 are in flight while step s computes (two register stages);
+//   * the prologue coefficients of every K channel sit in LDS, the operand modes fold into one formula
+//     act(k0 g + k1 x + k2) (HASG: the source is a dz assembled from (g, z)) — no branch between a load and its use.
+// PATTERN 0 = S, 1 = T (blockIdx.z = parity class + 4 x K-split index)
+template <int PATTERN, bool HASG>
 __global__ void __launch_bounds__(UG_WG)
 ugemm_kernel(UGemm p) {
-  __shared__ float s_part[UG_WG / 64 - 1][16][64];
+  __shared__ float s_part[UG_WG / 64][16][64];
+  __shared__ float s_coef[3][UG_MAXC];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int h = lane >> 5, r = lane & 31;
   const int Hc = p.Hc, Wc = p.Wc;                    // (powers of two)
   const int lw = 31 - __clz(Wc), lhw = lw + (31 - __clz(Hc));
   const int M = p.B * Hc * Wc;                       // output pixels (of this parity class)
-  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
-  const int cls = PATTERN ? (int)blockIdx.z : 0;
+  const int mtiles = (M + 31) >> 5;
+  constexpr int NCLS = PATTERN ? 4 : 1;
+  constexpr int NTAP = PATTERN ? 4 : 16, LTAP = PATTERN ? 2 : 4;
+  const int nwk = p.nwk, ks = p.ks;
+  const int cls = PATTERN ? (int)(blockIdx.z & 3) : 0;
+  const int ksi = PATTERN ? (int)(blockIdx.z >> 2) : (int)blockIdx.z;
   const int py = cls >> 1, px = cls & 1;
+  const int lnwk = 31 - __clz(nwk);
+  const int kw = wave & (nwk - 1);
+  const int mtile = (int)blockIdx.x * (8 >> lnwk) + (wave >> lnwk);
+  const bool tile_on = mtile < mtiles;
+  const int m0 = mtile * 32, n0 = blockIdx.y * 32;
+  // prologue coefficients of all K channels -> LDS: requested here, stored behind the first step's requests (below)
+  constexpr int NST = UG_MAXC / UG_WG;
+  float kst[2][NST][3];
+#pragma unroll
+  for (int sidx = 0; sidx < 2; ++sidx) {
+    const USrc& s = p.src[min(sidx, p.nsrc - 1)];                 // (uniform index; a missing second segment re-reads the first)
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+      const int c = min((int)threadIdx.x + j * UG_WG, s.C - 1);   // (clamped: not stored past the end)
+      kst[sidx][j][0] = s.k3[c]; kst[sidx][j][1] = s.k3[s.C + c]; kst[sidx][j][2] = s.k3[2 * s.C + c];
+    }
+  }
   // this lane's output pixel (row r of the tile) on the COARSE index space
   const int m = m0 + r;
-  const bool row_on = m < M;
+  const bool row_on = tile_on && m < M;
   const int mm = row_on ? m : 0;
   const int b = mm >> lhw, yc = (mm >> lw) & (Hc - 1), xc = mm & (Wc - 1);
   const int Hs = PATTERN ? Hc : 2 * Hc, Ws = PATTERN ? Wc : 2 * Wc;     // source grid
+  const int nch0 = p.src[0].C >> 5;
+  const int S = (p.Ctot >> 5) << LTAP;               // steps of a tile: (chunk, tap), tap fastest
+  const int way = ksi * nwk + kw, P = nwk * ks;
+  const int slo = tile_on ? (int)(((int64_t)way * S) / P) : 0;
+  const int shi = tile_on ? (int)(((int64_t)(way + 1) * S) / P) : 0;
+  const float slope0 = p.src[0].slope, slope1 = p.nsrc > 1 ? p.src[1].slope : 1.f;
   f32x16 acc;
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-  // wave -> its taps: pattern S two of the 16 (t0, t0 + 8), pattern T one of the 4 and every second channel chunk
-  constexpr int NW = UG_WG / 64;
-  const int t0 = PATTERN ? (wave & 3) : wave;
-  const int tstep = PATTERN ? 4 : NW, ntap = PATTERN ? 4 : 16;
-  const int cg = PATTERN ? (wave >> 2) : 0, ncg = PATTERN ? NW / 4 : 1;
-  int coff = 0, chunk = 0;
-  for (int sidx = 0; sidx < p.nsrc; ++sidx) {
-    const USrc& s = p.src[sidx];
-    for (int c0 = 0; c0 < s.C; c0 += 32, ++chunk) {
-      if ((chunk % ncg) != cg) continue;
-      const int cl = c0 + 16 * h;                     // this lane's 16 channels of the chunk
-      f32x4 k0[4], k1[4], k2[4];                      // per-channel coefficients (mode 1: sc, sh; mode 2: cA, cQ, cP)
-      if (s.mode == 1) {
+  struct Stage { f32x4 a[4], g[4], w[4]; bool on; };
+  auto issue = [&](int s, Stage& R) {
+    const int c = s >> LTAP, t = s & (NTAP - 1);
+    const bool seg1 = c >= nch0;
+    const USrc& src = p.src[seg1 ? 1 : 0];
+    const int cl = ((seg1 ? c - nch0 : c) << 5) + 16 * h;            // this lane's 16 channels of the chunk, in the segment
+    int sy, sx, wt;
+    if (PATTERN == 0) {
+      const int ky = t >> 2, kx = t & 3;
+      sy = 2 * yc + ky - 1; sx = 2 * xc + kx - 1; wt = t;
+    } else {
+      // output (y, x) = (2 yc + py, 2 xc + px): ky = y + 1 - 2 iy in {1 - py, 3 - py}
+      const int a = t >> 1, bb = t & 1;
+      const int ky = (1 - py) + 2 * a, kx = (1 - px) + 2 * bb;
+      sy = yc + py - a; sx = xc + px - bb; wt = ky * 4 + kx;
+    }
+    R.on = row_on && sy >= 0 && sy < Hs && sx >= 0 && sx < Ws;
+    const int64_t sp = R.on ? ((int64_t)(b * Hs + sy) * Ws + sx) * src.C + cl : cl;
+    const float* wp = p.Wp + ((int64_t)wt * p.N + n0 + r) * p.Ctot + (c << 5) + 16 * h;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          k0[u] = *reinterpret_cast<const f32x4*>(s.sc + cl + 4 * u);
-          k1[u] = *reinterpret_cast<const f32x4*>(s.sh + cl + 4 * u);
-        }
-      } else if (s.mode == 2) {
+    for (int u = 0; u < 4; ++u) R.a[u] = *reinterpret_cast<const f32x4*>(src.x + sp + 4 * u);
+    if (HASG) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          k0[u] = *reinterpret_cast<const f32x4*>(s.sc + cl + 4 * u);
-          k1[u] = *reinterpret_cast<const f32x4*>(s.sc + s.C + cl + 4 * u);
-          k2[u] = *reinterpret_cast<const f32x4*>(s.sc + 2 * s.C + cl + 4 * u);
-        }
-      }
-      for (int t = t0; t < ntap; t += tstep) {
-        // source pixel of this row for tap t, and the tap's index in the packed weights
-        int sy, sx, wt;
-        if (PATTERN == 0) {
-          const int ky = t >> 2, kx = t & 3;
-          sy = 2 * yc + ky - 1; sx = 2 * xc + kx - 1; wt = t;
-        } else {
-          // output (y, x) = (2 yc + py, 2 xc + px): ky = y + 1 - 2 iy in {1 - py, 3 - py}
-          const int a = t >> 1, bb = t & 1;
-          const int ky = (1 - py) + 2 * a, kx = (1 - px) + 2 * bb;
-          sy = yc + py - a; sx = xc + px - bb; wt = ky * 4 + kx;
-        }
-        const bool on = row_on && sy >= 0 && sy < Hs && sx >= 0 && sx < Ws;
-        const int64_t sp = on ? ((int64_t)(b * Hs + sy) * Ws + sx) * s.C + cl : cl;
-        f32x4 a[4], w[4];
+      for (int u = 0; u < 4; ++u) R.g[u] = *reinterpret_cast<const f32x4*>(src.g + sp + 4 * u);
+    }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const f32x4*>(s.x + sp + 4 * u);
-        const float* wp = p.Wp + ((int64_t)wt * p.N + n0 + r) * p.Ctot + coff + cl;
+    for (int u = 0; u < 4; ++u) R.w[u] = *reinterpret_cast<const f32x4*>(wp + 4 * u);
+  };
+  auto consume = [&](int s, Stage& R) {
+    const int c = s >> LTAP;
+    const float slope = c >= nch0 ? slope1 : slope0;
+    const int ci = (c << 5) + 16 * h;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const f32x4*>(wp + 4 * u);
-        if (s.mode == 2) {
+    for (int u = 0; u < 4; ++u) {
+      const f32x4 k1 = *reinterpret_cast<const f32x4*>(&s_coef[1][ci + 4 * u]);
+      const f32x4 k2 = *reinterpret_cast<const f32x4*>(&s_coef[2][ci + 4 * u]);
+      f32x4 k0;
+      if (HASG) k0 = *reinterpret_cast<const f32x4*>(&s_coef[0][ci + 4 * u]);
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const f32x4 gq = *reinterpret_cast<const f32x4*>(s.g + sp + 4 * u);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a[u][e] = fmaf(k0[u][e], gq[e], fmaf(k1[u][e], a[u][e], k2[u][e]));
-          }
-        } else if (s.mode == 1) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a[u][e] = leaky(fmaf(a[u][e], k0[u][e], k1[u][e]), s.slope);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int e = 0; e < 4; ++e)       // (zero padding / rows past the end: a select, not a product with 0)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(on ? a[u][e] : 0.f, w[u][e], acc, 0, 0, 0);
+      for (int e = 0; e < 4; ++e) {
+        float v = fmaf(k1[e], R.a[u][e], k2[e]);
+        if (HASG) v = fmaf(k0[e], R.g[u][e], v);
+        v = leaky(v, slope);
+        // (zero padding / rows past the end: a select, not a product with 0)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(R.on ? v : 0.f, R.w[u][e], acc, 0, 0, 0);
       }
     }
-    coff += s.C;
-  }
-  // the waves' partial tiles
-  if (wave > 0) {
+  };
+  // (The look-ahead is UNCONDITIONAL — past the last step it re-requests that step — because a load issued under a branch
+  // makes the number of loads in flight unknown at the join, and the compiler then waits for all of them: vmcnt(0) in
+  // front of every step, no overlap at all. That is what the first version of this loop compiled to.)
+  Stage R0, R1;
+  __builtin_amdgcn_sched_barrier(0);
+  issue(min(slo, S - 1), R0);                  // (a wave without steps requests a valid address and drops it)
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    int coff = 0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) s_part[wave - 1][q][lane] = acc[q];
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      if (sidx < p.nsrc) {
+#pragma unroll
+        for (int j = 0; j < NST; ++j) {
+          const int c = threadIdx.x + j * UG_WG;
+          if (c < p.src[sidx].C) {
+            s_coef[0][coff + c] = kst[sidx][j][0]; s_coef[1][coff + c] = kst[sidx][j][1]; s_coef[2][coff + c] = kst[sidx][j][2];
+          }
+        }
+        coff += p.src[sidx].C;
+      }
+    }
   }
   __syncthreads();
-  if (wave > 0) return;
+  if (slo < shi) {
+    int s = slo;
+    for (;;) {
+      issue(min(s + 1, shi - 1), R1);
+      __builtin_amdgcn_sched_barrier(0);       // (or the scheduler sinks the requests below the MFMAs: one stage again)
+      consume(s, R0);
+      if (++s >= shi) break;
+      issue(min(s + 1, shi - 1), R0);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(s, R1);
+      if (++s >= shi) break;
+    }
+  }
+  // the partial tiles of the waves that share this tile
+  if (nwk > 1) {
+    if (kw > 0) {
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    float v = acc[q];
+      for (int q = 0; q < 16; ++q) s_part[wave][q][lane] = acc[q];
+    }
+    __syncthreads();
+    if (kw > 0) return;
+    for (int w = 1; w < nwk; ++w) {
 #pragma unroll
-    for (int w = 0; w < UG_WG / 64 - 1; ++w) v += s_part[w][q][lane];
-    acc[q] = v;
+      for (int q = 0; q < 16; ++q) acc[q] += s_part[wave + w][q][lane];
+    }
+  }
+  if (!tile_on) return;
+  // ... and of the workgroups that do
+  if (ks > 1) {
+    const int tile_id = (cls * mtiles + mtile) * (int)gridDim.y + (int)blockIdx.y;
+    float* mine = p.kpart + ((int64_t)tile_id * ks + ksi) * 1024;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) mine[q * 64 + lane] = acc[q];
+    __threadfence();                                    // release: the partial tile before the ticket
+    unsigned old = 0;
+    if (lane == 0) old = atomicAdd(&p.ticket[tile_id], 1u);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != (unsigned)(ks - 1)) return;
+    __threadfence();                                    // acquire: the other workgroups' tiles after the ticket
+    if (lane == 0) p.ticket[tile_id] = 0u;
+    const float* all = p.kpart + (int64_t)tile_id * ks * 1024;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    for (int k = 0; k < ks; ++k) {                      // fixed order: the sum does not depend on who came last
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] += all[(int64_t)k * 1024 + q * 64 + lane];
+    }
   }
   // ---- epilogue: C/D layout column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
   int doff = 0, di = 0;
@@ -190,39 +271,58 @@ ugemm_kernel(UGemm p) {
   const float dsc = d.sc ? d.sc[n] : 1.f, dsh = d.sh ? d.sh[n] : 0.f;
   const float sshift = d.stat_shift ? d.stat_shift[n] : 0.f;
   float s1 = 0.f, s2 = 0.f;
+  // (every load of the tile first — with a load, its use and a store per element inside the branches, the 16 elements
+  // took 16 .. 32 memory round trips one after the other: most of what an input-gradient launch cost)
+  int64_t op[16];
+  bool ok[16];
+  float zv[16], ov[16];
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
-    const int mr = m0 + row;
-    if (mr >= M) continue;
-    int64_t op;
+    ok[q] = m0 + row < M;
+    const int mr = ok[q] ? m0 + row : m0;
     if (PATTERN == 0) {
-      op = (int64_t)mr * d.C + n;
+      op[q] = (int64_t)mr * d.C + n;
     } else {
       const int b2 = mr >> lhw, y2 = (mr >> lw) & (Hc - 1), x2 = mr & (Wc - 1);
-      op = ((int64_t)(b2 * 2 * Hc + 2 * y2 + py) * (2 * Wc) + 2 * x2 + px) * d.C + n;
+      op[q] = ((int64_t)(b2 * 2 * Hc + 2 * y2 + py) * (2 * Wc) + 2 * x2 + px) * d.C + n;
     }
+  }
+  if (d.dmode == 1) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) zv[q] = d.z[op[q]];
+  }
+  if (d.accumulate) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) ov[q] = d.out[op[q]];
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
     float val = acc[q] + bias;
     if (d.dmode == 1) {
-      const float yv = fmaf(d.z[op], dsc, dsh);
+      const float yv = fmaf(zv[q], dsc, dsh);
       val *= yv > 0.f ? 1.f : d.slope;
-      if (d.accumulate) val += d.out[op];
-      d.out[op] = val;
-      s1 += val;
-      s2 = fmaf(val, yv, s2);
+      if (d.accumulate) val += ov[q];
+      if (ok[q]) {
+        d.out[op[q]] = val;
+        s1 += val;
+        s2 = fmaf(val, yv, s2);
+      }
     } else {
-      if (d.accumulate) val += d.out[op];
-      d.out[op] = val;
-      const float dv = val - sshift;
-      s1 += dv;
-      s2 = fmaf(dv, dv, s2);
+      if (d.accumulate) val += ov[q];
+      if (ok[q]) {
+        d.out[op[q]] = val;
+        const float dv = val - sshift;
+        s1 += dv;
+        s2 = fmaf(dv, dv, s2);
+      }
     }
   }
   if (d.part) {
     s1 += __shfl_xor(s1, 32);
     s2 += __shfl_xor(s2, 32);
     if (h == 0) {
-      const int prow = cls * gridDim.x + blockIdx.x;
+      const int prow = cls * mtiles + mtile;
       d.part[((int64_t)prow * 2 + 0) * d.C + n] = s1;
       d.part[((int64_t)prow * 2 + 1) * d.C + n] = s2;
     }
@@ -239,17 +339,28 @@ struct UWgrad {
   USrc U[2];
   USrc V;
   float* part;
+  float* dW;              // != NULL (one chunk only): the tile goes straight to dW[i * sI + j * sJ + t], no reduction launch
+  long long sI, sJ;
 };
 
-__device__ __forceinline__ float usrc_read(const USrc& s, int64_t idx, float k0, float k1, float k2) {
-  const float x = s.x[idx];
-  if (s.mode == 1) return leaky(fmaf(x, k0, k1), s.slope);
-  if (s.mode == 2) return fmaf(k0, s.g[idx], fmaf(k1, x, k2));
-  return x;
+// operand element with its per-channel prologue as ONE formula, act(k0 g + k1 x + k2) (mode 0: 0, 1, 0; mode 1: 0, sc, sh
+// with the activation's slope; mode 2: cA, cQ, cP), HASG = the operand has a g tensor. The mode is a launch constant, and
+// testing it per element (as the first version did) put a branch around every load: the 32 .. 48 loads of a 32-row step
+// waited for each other one by one, ~1 us each — that, not the arithmetic, was the 35 us a launch took.
+struct UCoef { float k0, k1, k2, slope; };
+__device__ __forceinline__ UCoef ucoef_of(const USrc& s, int c) {
+  UCoef k;
+  k.k0 = s.k3[c]; k.k1 = s.k3[s.C + c]; k.k2 = s.k3[2 * s.C + c]; k.slope = s.slope;
+  return k;
+}
+__device__ __forceinline__ float ucoef_apply(const UCoef& k, float x, float g) {
+  const float v = fmaf(k.k0, g, fmaf(k.k1, x, k.k2));
+  return v > 0.f ? v : v * k.slope;
 }
 
 constexpr int UW_WG = 256;       // four waves share a (tap, tile, chunk): a quarter of the chunk's rows each
 
+template <bool UG, bool VG>
 __global__ void __launch_bounds__(UW_WG)
 uwgrad_kernel(UWgrad p) {
   __shared__ float s_part[3][16][64];
@@ -270,33 +381,40 @@ uwgrad_kernel(UWgrad p) {
   const USrc& U = p.U[ui];
   const USrc& V = p.V;
   const int ic = i0 - uo + r, jc = j0 + r;
-  float u0 = 0.f, u1 = 0.f, u2 = 0.f, v0 = 0.f, v1 = 0.f, v2 = 0.f;
-  if (U.mode == 1) { u0 = U.sc[ic]; u1 = U.sh[ic]; }
-  else if (U.mode == 2) { u0 = U.sc[ic]; u1 = U.sc[U.C + ic]; u2 = U.sc[2 * U.C + ic]; }
-  if (V.mode == 1) { v0 = V.sc[jc]; v1 = V.sh[jc]; }
-  else if (V.mode == 2) { v0 = V.sc[jc]; v1 = V.sc[V.C + jc]; v2 = V.sc[2 * V.C + jc]; }
+  const UCoef ku = ucoef_of(U, ic), kv = ucoef_of(V, jc);
+  const float* __restrict__ ux = U.x;
+  const float* __restrict__ ug = UG ? U.g : U.x;
+  const float* __restrict__ vx = V.x;
+  const float* __restrict__ vg = VG ? V.g : V.x;
+  const int UC = U.C, VC = V.C;
   const int ky = t >> 2, kx = t & 3;
   f32x16 acc;
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.f;
   for (int mb = mlo; mb < mhi; mb += 32) {
-    float uu[16], vv[16];
+    float uxr[16], ugr[16], vxr[16], vgr[16];
+    bool uon[16], von[16];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
+    for (int s = 0; s < 16; ++s) {                  // every load of the step first: one memory round trip
       const int m = mb + 2 * s + h;
-      const bool on = m < mhi;
-      const int mm = on ? m : mlo;
+      uon[s] = m < mhi;
+      const int mm = uon[s] ? m : mlo;
       const int b = mm >> lhw, yc = (mm >> lw) & (Hc - 1), xc = mm & (Wc - 1);
       const int sy = 2 * yc + ky - 1, sx = 2 * xc + kx - 1;
-      const bool von = on && sy >= 0 && sy < 2 * Hc && sx >= 0 && sx < 2 * Wc;
-      const int64_t vp = von ? ((int64_t)(b * 2 * Hc + sy) * (2 * Wc) + sx) * V.C + jc : jc;
-      const float ur = usrc_read(U, (int64_t)mm * U.C + ic, u0, u1, u2);
-      const float vr = usrc_read(V, vp, v0, v1, v2);
-      uu[s] = on ? ur : 0.f;
-      vv[s] = von ? vr : 0.f;
+      von[s] = uon[s] && sy >= 0 && sy < 2 * Hc && sx >= 0 && sx < 2 * Wc;
+      const int64_t up = (int64_t)mm * UC + ic;
+      const int64_t vp = von[s] ? ((int64_t)(b * 2 * Hc + sy) * (2 * Wc) + sx) * VC + jc : jc;
+      uxr[s] = ux[up];
+      ugr[s] = UG ? ug[up] : 0.f;
+      vxr[s] = vx[vp];
+      vgr[s] = VG ? vg[vp] : 0.f;
     }
 #pragma unroll
-    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(uu[s], vv[s], acc, 0, 0, 0);
+    for (int s = 0; s < 16; ++s) {
+      const float uu = uon[s] ? ucoef_apply(ku, uxr[s], ugr[s]) : 0.f;
+      const float vv = von[s] ? ucoef_apply(kv, vxr[s], vgr[s]) : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(uu, vv, acc, 0, 0, 0);
+    }
   }
   if (wave > 0) {
 #pragma unroll
@@ -308,7 +426,9 @@ uwgrad_kernel(UWgrad p) {
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
-    out[(int64_t)(i0 + row) * p.J + j0 + r] = (acc[q] + s_part[0][q][lane]) + (s_part[1][q][lane] + s_part[2][q][lane]);
+    const float v = (acc[q] + s_part[0][q][lane]) + (s_part[1][q][lane] + s_part[2][q][lane]);
+    if (p.dW) p.dW[(int64_t)(i0 + row) * p.sI + (int64_t)(j0 + r) * p.sJ + t] = v;
+    else out[(int64_t)(i0 + row) * p.J + j0 + r] = v;
   }
 }
 
@@ -327,20 +447,39 @@ uwgrad_reduce_kernel(int nchunk, int I, int J, int64_t sI, int64_t sJ, const flo
   dW[i * sI + j * sJ + t] = s;
 }
 
-// Wp[t][n][c] = W[n * sn + c * sc + t] for up to 9 layers in one launch (blockIdx.y = layer)
-struct UPackJobs { const float* W[9]; float* Wp[9]; int N[9], C[9]; long long sn[9], sc[9]; };
+// Wp[t][n][c] = W[n * sn + c * sc + t] for up to 9 layers in one launch (blockIdx.y = layer): a thread takes one (n, c)
+// pair — its 16 taps are contiguous in every source layout (64 bytes in, 16 stores that are coalesced across the
+// threads' c). Workgroup (0, 0) also zeroes the K-split tickets of the GEMM launches that follow.
+struct UPackJobs {
+  const float* W[9]; float* Wp[9]; int N[9], C[9]; long long sn[9], sc[9];
+  unsigned* ticket; int nticket;
+  float* ident[2]; int identC[2];          // identity prologue blocks [3][C] = (0, 1, 0) to fill (C = 0: none)
+};
 __global__ void __launch_bounds__(256)
 upack_kernel(UPackJobs jobs) {
   const int j = blockIdx.y;
+  if (blockIdx.x == 0 && j == 0) {
+    for (int i = threadIdx.x; i < jobs.nticket; i += 256) jobs.ticket[i] = 0u;
+    for (int b = 0; b < 2; ++b)
+      for (int i = threadIdx.x; i < 3 * jobs.identC[b]; i += 256)
+        jobs.ident[b][i] = (i >= jobs.identC[b] && i < 2 * jobs.identC[b]) ? 1.f : 0.f;
+  }
   const int N = jobs.N[j], C = jobs.C[j];
-  const int64_t total = (int64_t)16 * N * C;
+  const int pairs = N * C;
   const float* __restrict__ W = jobs.W[j];
   float* __restrict__ Wp = jobs.Wp[j];
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int t = (int)(e / ((int64_t)N * C));
-    const int64_t nc = e - (int64_t)t * N * C;
-    const int n = (int)(nc / C), c = (int)(nc - (int64_t)n * C);
-    Wp[e] = W[n * jobs.sn[j] + c * jobs.sc[j] + t];
+  const long long sn = jobs.sn[j], sc = jobs.sc[j];
+  for (int e = (int)blockIdx.x * 256 + (int)threadIdx.x; e < pairs; e += (int)gridDim.x * 256) {
+    const int n = e / C, c = e - n * C;
+    const f32x4* src = reinterpret_cast<const f32x4*>(W + n * sn + c * sc);
+    const f32x4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      Wp[(int64_t)(t + 0) * pairs + e] = v0[t];
+      Wp[(int64_t)(t + 4) * pairs + e] = v1[t];
+      Wp[(int64_t)(t + 8) * pairs + e] = v2[t];
+      Wp[(int64_t)(t + 12) * pairs + e] = v3[t];
+    }
   }
 }
 
@@ -349,7 +488,7 @@ upack_kernel(UPackJobs jobs) {
 __global__ void __launch_bounds__(64)
 ubn_fwd_kernel(int nparts, int C, float count, const float* __restrict__ part, const float* __restrict__ stat_shift,
                float eps, float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
-               long long* __restrict__ nbt, float* __restrict__ sc, float* __restrict__ sh) {
+               long long* __restrict__ nbt, float* __restrict__ k0, float* __restrict__ sc, float* __restrict__ sh) {
   const int n = blockIdx.x;
   const float shv = stat_shift ? stat_shift[n] : 0.f;          // (may alias running_mean: read first)
   const float rm = running_mean ? running_mean[n] : 0.f, rv = running_var ? running_var[n] : 0.f;
@@ -366,6 +505,7 @@ ubn_fwd_kernel(int nparts, int C, float count, const float* __restrict__ part, c
     double var = s2 / (double)count - dm * dm;
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    k0[n] = 0.f;                       // (k0, sc, sh) = the consumers' [3][C] prologue block (USrc.k3)
     sc[n] = rstd;
     sh[n] = -(float)mean * rstd;
     if (running_mean) {
@@ -379,10 +519,11 @@ ubn_fwd_kernel(int nparts, int C, float count, const float* __restrict__ part, c
 
 // evaluation mode: scale / shift from the running statistics
 __global__ void ubn_eval_kernel(int C, const float* __restrict__ rm, const float* __restrict__ rv, float eps,
-                                float* __restrict__ sc, float* __restrict__ sh) {
+                                float* __restrict__ k0, float* __restrict__ sc, float* __restrict__ sh) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= C) return;
   const float rstd = 1.0f / sqrtf(rv[n] + eps);
+  k0[n] = 0.f;
   sc[n] = rstd;
   sh[n] = -rm[n] * rstd;
 }
@@ -428,19 +569,21 @@ uconv1_fwd_kernel(int B, int Cin, int S, int Cout, const float* __restrict__ x, 
   const int b = (int)(pix / (Ho * Ho)), rem = (int)(pix - (int64_t)b * Ho * Ho);
   const int oy = rem / Ho, ox = rem - oy * Ho;
   float acc = 0.f;
-  for (int ci = 0; ci < Cin; ++ci)
+  for (int ci = 0; ci < Cin; ++ci) {
+    float xv[16];
 #pragma unroll
-    for (int ky = 0; ky < 4; ++ky) {
-      const int sy = 2 * oy + ky - 1;
-      if (sy < 0 || sy >= S) continue;
-#pragma unroll
-      for (int kx = 0; kx < 4; ++kx) {
-        const int sx = 2 * ox + kx - 1;
-        if (sx < 0 || sx >= S) continue;
-        const int wi = ((co * Cin + ci) * 4 + ky) * 4 + kx;
-        acc = fmaf(lds_w ? s_w[wi] : W[wi], x[(((int64_t)b * Cin + ci) * S + sy) * S + sx], acc);
-      }
+    for (int t = 0; t < 16; ++t) {                   // the 16 taps' loads together (no branch between a load and its use)
+      const int sy = 2 * oy + (t >> 2) - 1, sx = 2 * ox + (t & 3) - 1;
+      const bool on = sy >= 0 && sy < S && sx >= 0 && sx < S;
+      const float v = x[on ? (((int64_t)b * Cin + ci) * S + sy) * S + sx : 0];
+      xv[t] = on ? v : 0.f;
     }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int wi = (co * Cin + ci) * 16 + t;
+      acc = fmaf(lds_w ? s_w[wi] : W[wi], xv[t], acc);
+    }
+  }
   z[e] = acc;
 }
 
@@ -458,14 +601,25 @@ uconv1_wgrad_kernel(int B, int Cin, int S, int Cout, int chunk_rows, const float
   const int M = B * Ho * Ho;
   const int mlo = blockIdx.y * chunk_rows, mhi = min(M, mlo + chunk_rows);
   float acc = 0.f;
-  if (co < Cout)
-    for (int m = mlo + rl; m < mhi; m += 8) {
-      const int b = m / (Ho * Ho), rem = m - b * Ho * Ho;
-      const int oy = rem / Ho, ox = rem - oy * Ho;
-      const int sy = 2 * oy + ky - 1, sx = 2 * ox + kx - 1;
-      if (sy < 0 || sy >= S || sx < 0 || sx >= S) continue;
-      acc = fmaf(dz[(int64_t)m * Cout + co], x[(((int64_t)b * Cin + ci) * S + sy) * S + sx], acc);
+  if (co < Cout) {
+    const int lh = 31 - __clz(Ho);                   // (S is a power of two: unet_ok)
+    for (int m0 = mlo + rl; m0 < mhi; m0 += 64) {    // eight rows' loads in flight
+      float dv[8], xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int m = m0 + 8 * u;
+        const int mm = m < mhi ? m : mlo;
+        const int b = mm >> (2 * lh), oy = (mm >> lh) & (Ho - 1), ox = mm & (Ho - 1);
+        const int sy = 2 * oy + ky - 1, sx = 2 * ox + kx - 1;
+        const bool on = m < mhi && sy >= 0 && sy < S && sx >= 0 && sx < S;
+        dv[u] = dz[(int64_t)mm * Cout + co];
+        const float xr = x[on ? (((int64_t)b * Cin + ci) * S + sy) * S + sx : 0];
+        xv[u] = on ? xr : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = fmaf(dv[u], xv[u], acc);
     }
+  }
   s_acc[rl][threadIdx.x & 31] = acc;
   __syncthreads();
   if (rl == 0 && co < Cout) {
@@ -501,18 +655,28 @@ ucolsum_kernel(int M, int C, int chunk_rows, const float* __restrict__ g, float*
   const int rl = threadIdx.x >> 6, c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int mlo = blockIdx.y * chunk_rows, mhi = min(M, mlo + chunk_rows);
   float s = 0.f;
-  if (c < C) for (int m = mlo + rl; m < mhi; m += 4) s += g[(int64_t)m * C + c];
+  if (c < C) {
+    int m = mlo + rl;
+    for (; m + 28 < mhi; m += 32) {                  // eight independent loads in flight (the plain loop waited for each)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = g[(int64_t)(m + 4 * u) * C + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; m < mhi; m += 4) s += g[(int64_t)m * C + c];
+  }
   s_acc[rl][threadIdx.x & 63] = s;
   __syncthreads();
   if (rl == 0 && c < C)
     part[(int64_t)blockIdx.y * C + c] = (s_acc[0][threadIdx.x] + s_acc[1][threadIdx.x]) + (s_acc[2][threadIdx.x] + s_acc[3][threadIdx.x]);
 }
 
-// ones / zeros for the tensors without BatchNorm: sc[0] = sc[1] = 1, sh[0] = sh[1] = 0
-__global__ void ufill_kernel(int n0, int n1, float* sc0, float* sh0, float* sc1, float* sh1) {
+// identity prologue blocks [3][n] = (0, 1, 0) for the tensors without BatchNorm
+__global__ void ufill_kernel(int n0, int n1, float* k3a, float* k3b) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n0) { sc0[i] = 1.f; sh0[i] = 0.f; }
-  if (i < n1) { sc1[i] = 1.f; sh1[i] = 0.f; }
+  if (i < n0) { k3a[i] = 0.f; k3a[n0 + i] = 1.f; k3a[2 * n0 + i] = 0.f; }
+  if (i < n1) { k3b[i] = 0.f; k3b[n1 + i] = 1.f; k3b[2 * n1 + i] = 0.f; }
 }
 
 // ------------------------------------------------------------------------------------------------- host side
@@ -552,8 +716,9 @@ Saved carve_saved(const Net& n, float* base) {
   size_t o = 0;
   for (int k = 1; k <= 5; ++k) { s.z[k] = base + o; o += al((size_t)n.B * n.Hd[k] * n.Hd[k] * n.C[k]); }
   for (int k = 1; k <= 4; ++k) { s.zT[k] = base + o; o += al((size_t)n.B * n.HU[k] * n.HU[k] * n.CU[k]); }
-  for (int k = 1; k <= 5; ++k) { s.sc_d[k] = base + o; o += al(n.C[k]); s.sh_d[k] = base + o; o += al(n.C[k]); }
-  for (int k = 1; k <= 4; ++k) { s.sc_u[k] = base + o; o += al(n.CU[k]); s.sh_u[k] = base + o; o += al(n.CU[k]); }
+  // per tensor one [3][C] prologue block (k0 = 0 | scale | shift): USrc.k3 = sc - C
+  for (int k = 1; k <= 5; ++k) { s.sc_d[k] = base + o + n.C[k]; s.sh_d[k] = base + o + 2 * n.C[k]; o += al(3 * n.C[k]); }
+  for (int k = 1; k <= 4; ++k) { s.sc_u[k] = base + o + n.CU[k]; s.sh_u[k] = base + o + 2 * n.CU[k]; o += al(3 * n.CU[k]); }
   s.total = o;
   return s;
 }
@@ -573,11 +738,37 @@ size_t max_part_floats(const Net& n) {    // BN partials of the widest case: row
   return al(mx * 2);
 }
 
-int launch_ugemm(int pattern, const UGemm& g, hipStream_t st) {
+// K-split scratch of the GEMM launches: partial tiles + tickets (carved from the workspace after the BatchNorm partials)
+constexpr int UG_KTILES = 512;                 // tiles x ks of one launch (the heuristic below keeps it under this)
+constexpr int UG_TICKETS = 512;
+size_t ksplit_floats() { return al((size_t)UG_KTILES * 1024) + al(UG_TICKETS); }
+struct KSplit { float* kpart; unsigned* ticket; };
+KSplit carve_ksplit(float* base) { return {base, reinterpret_cast<unsigned*>(base + al((size_t)UG_KTILES * 1024))}; }
+
+int launch_ugemm(int pattern, UGemm g, const KSplit& k, hipStream_t st) {
   const int M = g.B * g.Hc * g.Wc;
-  const dim3 grid((M + 31) / 32, g.N / 32, pattern ? 4 : 1);
-  if (pattern) hipLaunchKernelGGL(ugemm_kernel<1>, grid, dim3(UG_WG), 0, st, g);
-  else hipLaunchKernelGGL(ugemm_kernel<0>, grid, dim3(UG_WG), 0, st, g);
+  const int mtiles = (M + 31) / 32, ncls = pattern ? 4 : 1;
+  const int T = mtiles * (g.N / 32) * ncls;                  // tiles
+  const int S = (g.Ctot / 32) * (pattern ? 4 : 16);          // steps of a tile
+  if (g.Ctot > UG_MAXC) { set_error("ganet_unet: more than 1024 input channels in one convolution"); return 1; }
+  // ~2048 waves a launch (two per SIMD): the waves of a workgroup first, then workgroups while a wave still has more than
+  // two steps (a K split across workgroups costs a trip through memory and a ticket)
+  int nwk = 1, ks = 1;
+  while (nwk < 8 && T * nwk * 2 <= 2048 && nwk * 2 <= S) nwk *= 2;
+  if (nwk == 8)
+    while (S / (nwk * ks) > 2 && T * nwk * ks * 2 <= 4096 && T * ks * 2 <= UG_KTILES && T <= UG_TICKETS) ks *= 2;
+  g.nwk = nwk; g.ks = ks; g.kpart = k.kpart; g.ticket = k.ticket;
+  const int tpw = 8 / nwk;
+  const dim3 grid((mtiles + tpw - 1) / tpw, g.N / 32, ncls * ks);
+  const bool hasg = g.src[0].mode == 2;
+  if (hasg && g.nsrc != 1) { set_error("ganet_unet: a dz source comes alone"); return 1; }
+  if (pattern) {
+    if (hasg) hipLaunchKernelGGL((ugemm_kernel<1, true>), grid, dim3(UG_WG), 0, st, g);
+    else hipLaunchKernelGGL((ugemm_kernel<1, false>), grid, dim3(UG_WG), 0, st, g);
+  } else {
+    if (hasg) hipLaunchKernelGGL((ugemm_kernel<0, true>), grid, dim3(UG_WG), 0, st, g);
+    else hipLaunchKernelGGL((ugemm_kernel<0, false>), grid, dim3(UG_WG), 0, st, g);
+  }
   return check_hip(hipGetLastError(), "ugemm_kernel");
 }
 struct PackList {
@@ -586,19 +777,21 @@ struct PackList {
   void add(int N, int C, int64_t sn, int64_t sc, const float* W, float* Wp) {
     jobs.W[n] = W; jobs.Wp[n] = Wp; jobs.N[n] = N; jobs.C[n] = C; jobs.sn[n] = sn; jobs.sc[n] = sc; ++n;
   }
-  int launch(hipStream_t st) {
+  int launch(const KSplit& k, hipStream_t st) {
     if (!n) return 0;
-    hipLaunchKernelGGL(upack_kernel, dim3(256, n), dim3(256), 0, st, jobs);
+    jobs.ticket = k.ticket; jobs.nticket = UG_TICKETS;
+    hipLaunchKernelGGL(upack_kernel, dim3(128, n), dim3(256), 0, st, jobs);
     return check_hip(hipGetLastError(), "upack_kernel");
   }
 };
-USrc src_raw(const float* x, int C) { USrc s{}; s.x = x; s.C = C; s.mode = 0; s.slope = 1.f; return s; }
+// act(bn(z)): sc / sh are the second and third row of the tensor's [3][C] prologue block (carve_saved)
 USrc src_act(const float* z, int C, const float* sc, const float* sh, float slope) {
-  USrc s{}; s.x = z; s.sc = sc; s.sh = sh; s.C = C; s.mode = 1; s.slope = slope; return s;
+  USrc s{}; s.x = z; s.k3 = sc - C; s.C = C; s.mode = 1; s.slope = slope; (void)sh; return s;
 }
-USrc src_dz(const float* g, const float* z, const float* coef, int C) {
-  USrc s{}; s.x = z; s.g = g; s.sc = coef; s.C = C; s.mode = coef ? 2 : 0; s.slope = 1.f;
-  if (!coef) s.x = g;                   // no BatchNorm: dz = Gy
+// dz of a layer: cA g + cQ z + cP (coef [3][C], ubn_bwd_kernel), or g itself (no BatchNorm: `ident` = an identity block)
+USrc src_dz(const float* g, const float* z, const float* coef, const float* ident, int C) {
+  USrc s{}; s.x = z; s.g = g; s.k3 = coef; s.C = C; s.mode = coef ? 2 : 0; s.slope = 1.f;
+  if (!coef) { s.x = g; s.k3 = ident; }
   return s;
 }
 
@@ -624,7 +817,7 @@ size_t ganet_unet_saved_floats(const GanetUnetParams* p, int32_t B) {
 size_t ganet_unet_fwd_workspace(const GanetUnetParams* p, int32_t B) {
   if (!unet_ok(p, B)) return 0;
   const Net n = make_net(p, B);
-  return (packed_floats(n) + max_part_floats(n)) * sizeof(float);
+  return (packed_floats(n) + max_part_floats(n) + ksplit_floats()) * sizeof(float);
 }
 
 // x: [B, cin, S, S] NCHW; out: [B, S, S, cout] channels-last. training != 0: batch statistics (and the running
@@ -641,9 +834,10 @@ int ganet_unet_fwd(const GanetUnetParams* p, int32_t B, const float* x, int32_t 
   const Saved sv = carve_saved(n, saved);
   float* wsf = static_cast<float*>(workspace);
   float* part = wsf + packed_floats(n);
+  const KSplit ksp = carve_ksplit(part + max_part_floats(n));
   // ones / zeros for the tensors without BatchNorm (z1, z5)
-  hipLaunchKernelGGL(ufill_kernel, dim3((std::max(n.C[1], n.C[5]) + 255) / 256), dim3(256), 0, st, n.C[1], n.C[5], sv.sc_d[1],
-                     sv.sh_d[1], sv.sc_d[5], sv.sh_d[5]);
+  hipLaunchKernelGGL(ufill_kernel, dim3((std::max(n.C[1], n.C[5]) + 255) / 256), dim3(256), 0, st, n.C[1], n.C[5],
+                     sv.sc_d[1] - n.C[1], sv.sc_d[5] - n.C[5]);
   // every layer's weights in the [tap][n][c] order its GEMM reads, one launch
   float* wpk_d[6]; float* wpk_u[6];
   {
@@ -658,18 +852,18 @@ int ganet_unet_fwd(const GanetUnetParams* p, int32_t B, const float* x, int32_t 
       wpk_u[k] = q; q += al((size_t)16 * n.CU[k] * cinu[k]);
       pl.add(n.CU[k], cinu[k], 16, (int64_t)n.CU[k] * 16, p->Wu[k - 1], wpk_u[k]);      // WT[ci][co][16] -> [t][co][ci]
     }
-    GA_TRY(pl.launch(st));
+    GA_TRY(pl.launch(ksp, st));
   }
   // BatchNorm of a layer's raw output from the partials its forward launch left
   auto bn = [&](int idx, int C, int nparts, float count, float* sc, float* sh) -> int {
     if (training) {
       hipLaunchKernelGGL(ubn_fwd_kernel, dim3(C), dim3(64), 0, st, nparts, C, count, part, p->running_mean[idx], p->eps,
                          p->momentum, p->running_mean[idx], p->running_var[idx],
-                         reinterpret_cast<long long*>(p->num_batches_tracked[idx]), sc, sh);
+                         reinterpret_cast<long long*>(p->num_batches_tracked[idx]), sc - C, sc, sh);
     } else {
       if (!p->running_mean[idx] || !p->running_var[idx]) { set_error("ganet_unet_fwd: evaluation needs running statistics"); return 1; }
       hipLaunchKernelGGL(ubn_eval_kernel, dim3((C + 63) / 64), dim3(64), 0, st, C, p->running_mean[idx], p->running_var[idx],
-                         p->eps, sc, sh);
+                         p->eps, sc - C, sc, sh);
     }
     return check_hip(hipGetLastError(), "ubn kernels");
   };
@@ -691,7 +885,7 @@ int ganet_unet_fwd(const GanetUnetParams* p, int32_t B, const float* x, int32_t 
     const int bi = k - 2;                  // BatchNorm index 0..2 = conv2..4
     if (has_bn && training) { d.part = part; d.stat_shift = p->running_mean[bi]; }
     g.dst[0] = d;
-    GA_TRY(launch_ugemm(0, g, st));
+    GA_TRY(launch_ugemm(0, g, ksp, st));
     if (has_bn) GA_TRY(bn(bi, co, (B * n.Hd[k] * n.Hd[k] + 31) / 32, (float)(B * n.Hd[k] * n.Hd[k]), sv.sc_d[k], sv.sh_d[k]));
   }
   // ---- upconv1..5: input relu(cat[bn(zT_{k-1}), a_{5-k+1}]) (upconv1: relu(z5))
@@ -717,7 +911,7 @@ int ganet_unet_fwd(const GanetUnetParams* p, int32_t B, const float* x, int32_t 
     if (!has_bn) d.bias = p->bias5;
     if (has_bn && training) { d.part = part; d.stat_shift = p->running_mean[bi]; }
     g.dst[0] = d;
-    GA_TRY(launch_ugemm(1, g, st));
+    GA_TRY(launch_ugemm(1, g, ksp, st));
     if (has_bn) {
       const int rows = (B * g.Hc * g.Wc + 31) / 32;
       GA_TRY(bn(bi, co, 4 * rows, (float)(B * n.HU[k] * n.HU[k]), sv.sc_u[k], sv.sh_u[k]));
@@ -729,7 +923,7 @@ int ganet_unet_fwd(const GanetUnetParams* p, int32_t B, const float* x, int32_t 
 size_t ganet_unet_bwd_workspace(const GanetUnetParams* p, int32_t B) {
   if (!unet_ok(p, B)) return 0;
   const Net n = make_net(p, B);
-  size_t o = packed_floats(n) + max_part_floats(n);
+  size_t o = packed_floats(n) + max_part_floats(n) + ksplit_floats() + al(3 * n.cout) + al(3 * n.C[5]);
   // Gy of z1..z5 and zT1..zT4, coefficients, weight-gradient partial tiles
   for (int k = 1; k <= 5; ++k) o += al((size_t)B * n.Hd[k] * n.Hd[k] * n.C[k]) + al(3 * n.C[k]);
   for (int k = 1; k <= 4; ++k) o += al((size_t)B * n.HU[k] * n.HU[k] * n.CU[k]) + al(3 * n.CU[k]);
@@ -786,7 +980,10 @@ int ganet_unet_bwd(const GanetUnetParams* p, int32_t B, const float* x, const fl
   float* wsf = static_cast<float*>(workspace);
   float* wp = wsf;
   float* part = wsf + packed_floats(n);
-  float* o = part + max_part_floats(n);
+  const KSplit ksp = carve_ksplit(part + max_part_floats(n));
+  float* o = part + max_part_floats(n) + ksplit_floats();
+  float* ident_out = o; o += al(3 * n.cout);        // identity prologue blocks (d_out and Gd[5] are dz themselves)
+  float* ident_z5 = o; o += al(3 * n.C[5]);
   float* Gd[6]; float* cf_d[6]; float* Gu[6]; float* cf_u[6];
   for (int k = 1; k <= 5; ++k) { Gd[k] = o; o += al((size_t)B * n.Hd[k] * n.Hd[k] * n.C[k]); cf_d[k] = o; o += al(3 * n.C[k]); }
   for (int k = 1; k <= 4; ++k) { Gu[k] = o; o += al((size_t)B * n.HU[k] * n.HU[k] * n.CU[k]); cf_u[k] = o; o += al(3 * n.CU[k]); }
@@ -805,7 +1002,9 @@ int ganet_unet_bwd(const GanetUnetParams* p, int32_t B, const float* x, const fl
       wpk_d[k] = q; q += al((size_t)16 * n.C[k] * n.C[k - 1]);
       pl.add(n.C[k - 1], n.C[k], 16, (int64_t)n.C[k - 1] * 16, p->Wd[k - 1], wpk_d[k]);   // W[co][ci][16] -> [t][n = ci][c = co]
     }
-    GA_TRY(pl.launch(st));
+    pl.jobs.ident[0] = ident_out; pl.jobs.identC[0] = n.cout;
+    pl.jobs.ident[1] = ident_z5; pl.jobs.identC[1] = n.C[5];
+    GA_TRY(pl.launch(ksp, st));
   }
   (void)wp;
   auto wgrad = [&](int Hc, int I, int J, int nu, const USrc* U, const USrc& V, int64_t sI, int64_t sJ, float* dW) -> int {
@@ -814,10 +1013,19 @@ int ganet_unet_bwd(const GanetUnetParams* p, int32_t B, const float* x, const fl
     for (int i = 0; i < nu; ++i) w.U[i] = U[i];
     w.V = V; w.part = wgpart;
     const int M = B * Hc * Hc, nchunk = (M + 255) / 256;
+    if (nchunk == 1) { w.dW = dW; w.sI = sI; w.sJ = sJ; }      // a single chunk's tiles ARE the gradient
     hipStream_t ws;
     GA_TRY(fork(&ws));
-    hipLaunchKernelGGL(uwgrad_kernel, dim3(16, (I / 32) * (J / 32), nchunk), dim3(UW_WG), 0, ws, w);
+    bool ug = false;
+    for (int i = 0; i < nu; ++i) ug = ug || U[i].mode == 2;
+    const bool vg = V.mode == 2;
+    const dim3 grid(16, (I / 32) * (J / 32), nchunk);
+    if (ug && vg) { set_error("ganet_unet_bwd: both weight-gradient operands assembled from (g, z)"); return 1; }
+    if (ug) hipLaunchKernelGGL((uwgrad_kernel<true, false>), grid, dim3(UW_WG), 0, ws, w);
+    else if (vg) hipLaunchKernelGGL((uwgrad_kernel<false, true>), grid, dim3(UW_WG), 0, ws, w);
+    else hipLaunchKernelGGL((uwgrad_kernel<false, false>), grid, dim3(UW_WG), 0, ws, w);
     GA_TRY(check_hip(hipGetLastError(), "uwgrad_kernel"));
+    if (nchunk == 1) return 0;
     const int64_t tot = (int64_t)16 * I * J;
     hipLaunchKernelGGL(uwgrad_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ws, nchunk, I, J, sI, sJ,
                        wgpart, dW);
@@ -830,7 +1038,7 @@ int ganet_unet_bwd(const GanetUnetParams* p, int32_t B, const float* x, const fl
   // ---- up path, k = 5 .. 1. dz of zT_k: k = 5: d_out itself; else assembled from (Gu[k], zT[k], cf_u[k])
   for (int k = 5; k >= 1; --k) {
     const int co = n.CU[k], Hc = n.HU[k] / 2;
-    const USrc dz = k == 5 ? src_dz(d_out, nullptr, nullptr, co) : src_dz(Gu[k], sv.zT[k], cf_u[k], co);
+    const USrc dz = k == 5 ? src_dz(d_out, nullptr, nullptr, ident_out, co) : src_dz(Gu[k], sv.zT[k], cf_u[k], nullptr, co);
     // the activated input (two segments)
     USrc in[2];
     int nin;
@@ -869,14 +1077,14 @@ int ganet_unet_bwd(const GanetUnetParams* p, int32_t B, const float* x, const fl
       d1.dmode = 1; d1.slope = 0.f;       // the down path adds its contribution (and takes the sums) later
       g.dst[0] = d0; g.dst[1] = d1;
     }
-    GA_TRY(launch_ugemm(0, g, st));
+    GA_TRY(launch_ugemm(0, g, ksp, st));
     if (k >= 2) GA_TRY(bn_coef(n.CU[k - 1], (B * Hc * Hc + 31) / 32, (float)(B * Hc * Hc), sv.sc_u[k - 1], sv.sh_u[k - 1],
                                cf_u[k - 1]));
   }
   // ---- down path, k = 5 .. 2: dz of z_k (k = 5: Gd[5] itself; else from (Gd[k], z[k], cf_d[k]))
   for (int k = 5; k >= 2; --k) {
     const int co = n.C[k], ci = n.C[k - 1], Hc = n.Hd[k];
-    const USrc dz = k == 5 ? src_dz(Gd[5], nullptr, nullptr, co) : src_dz(Gd[k], sv.z[k], cf_d[k], co);
+    const USrc dz = k == 5 ? src_dz(Gd[5], nullptr, nullptr, ident_z5, co) : src_dz(Gd[k], sv.z[k], cf_d[k], nullptr, co);
     const USrc in = src_act(sv.z[k - 1], ci, sv.sc_d[k - 1], sv.sh_d[k - 1], 0.2f);
     // dW[co][ci][t] = sum_m dz[m, co] in[gather_S(m, t), ci]
     GA_TRY(wgrad(Hc, co, ci, 1, &dz, in, (int64_t)ci * 16, 16, gr->dWd[k - 1]));
@@ -888,7 +1096,7 @@ int ganet_unet_bwd(const GanetUnetParams* p, int32_t B, const float* x, const fl
     const bool has_bn = (k - 1) >= 2;     // z2..z4
     if (has_bn) d.part = part;
     g.dst[0] = d;
-    GA_TRY(launch_ugemm(1, g, st));
+    GA_TRY(launch_ugemm(1, g, ksp, st));
     if (has_bn) {
       const int rows = (B * Hc * Hc + 31) / 32;
       GA_TRY(bn_coef(ci, 4 * rows, (float)(B * n.Hd[k - 1] * n.Hd[k - 1]), sv.sc_d[k - 1], sv.sh_d[k - 1], cf_d[k - 1]));
