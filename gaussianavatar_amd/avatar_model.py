@@ -533,8 +533,11 @@ class AvatarModel:
 
     def _forward(self, batch_data, iteration, pose, transl, pose_featmap, warmup):
         B = pose.shape[0]
-        live = self._body(pose, transl, batch_data.get("rest_pose"))
+        # the decoder first: its launches are long, so in a loop that drains the GPU every iteration (the reference's
+        # train.py reads loss.item()) the host-bound launches of the body model run behind them instead of in front of an
+        # idle GPU (~40-75 us per iteration there; nothing changes when the host runs ahead)
         offset_loss, scale_loss, point_res, scales, colors = self._decode(B, pose_featmap, iteration, warmup)
+        live = self._body(pose, transl, batch_data.get("rest_pose"))
         full_pred = skin(self.query_points[:B] if self.query_points.shape[0] >= B else self.query_points[:1].expand(B, -1, -1),
                          point_res, self.query_lbs[0], live.cano2live)
         image = self._render_frames(batch_data, full_pred, colors, scales)

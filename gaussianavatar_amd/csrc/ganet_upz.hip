@@ -458,20 +458,22 @@ dz_upsample_t_kernel(UpGrid g, const int32_t* __restrict__ rptr, const int32_t* 
 #define GANET_DZM_ABLATE 0     // development (tools/dzm_ablate.sh): 1 no reduce phase, 2 no staging (loads only), 4 no Z loads,
 #endif                         // 8 no barriers, 16 natural tile order and sweep direction, 32 no db / dW_uv sums
 #ifndef GANET_DZM_WG
-#define GANET_DZM_WG 1024
+#define GANET_DZM_WG 512
 #endif
 #ifndef GANET_DZM_P
-#define GANET_DZM_P 8
+#define GANET_DZM_P 4
 #endif
-constexpr int DZM_WG = GANET_DZM_WG;   // 1024 threads x 8 pixel rows per tile. Measured on one box (512^2 map, us per launch): 1024 / 8:
-                                       // 72.4; 512 / 4 (two workgroups per CU, so that one computes while the other waits at its row
-                                       // barrier): 74.0; 512 / 8: 82.9 — the per-row arithmetic ADDS to the load time either way
-                                       // (ablation builds: loads only 56-62 us)
+constexpr int DZM_WG = GANET_DZM_WG;   // 512 threads x 4 pixel rows per tile (two workgroups per CU, so that one computes while the other
+                                       // waits at its row barrier). Measured on one box (512^2 map, median us per launch): 512 / 4: 80.8;
+                                       // 1024 / 8 (16 waves, two load rounds per row, the second half empty): 92.9; 512 / 8: ~9 us
+                                       // slower than 512 / 4 — the per-row arithmetic ADDS to the load time either way (ablation
+                                       // builds: loads only 56-62 us). (A first 1024 / 8 figure of 72 us was of a build that loaded
+                                       // 32 of a row's 48 columns: wrong results, caught by tests/test_decoder_map_gpu.py.)
 constexpr int DZM_Q = 8;
 constexpr int DZM_P = GANET_DZM_P;
 constexpr int DZM_COLS = 48;           // texel columns a tile may span; x4 grid: 36
 constexpr int DZM_SLOTS = DZM_WG / 32; // column slots of the load phase (x 32 float4 of channels)
-constexpr int DZM_NR = DZM_COLS / DZM_SLOTS;      // load rounds per row
+constexpr int DZM_NR = (DZM_COLS + DZM_SLOTS - 1) / DZM_SLOTS;      // load rounds per row (the last one may be partial: jon[])
 constexpr int DZM_NW = DZM_WG / 64;
 constexpr int DZM_CPL = 128 / (64 * (DZM_NW / DZM_Q));   // channels per lane in the reduce phase (8 waves: 2, 16 waves: 1)
 static_assert(DZM_NW == 8 || DZM_NW == 16, "reduce-phase mapping");

@@ -8,6 +8,7 @@ exercise), so the two formulations are checked against each other on the GPU box
 from __future__ import annotations
 
 import ctypes
+import weakref
 import threading
 
 import torch
@@ -530,15 +531,21 @@ def decoder_input_pad(dec, like) -> int:
     return _K1_PAD - dec.in_size if decoder_supported(dec, probe) else 0
 
 
+# Per-decoder caches live beside the modules, not inside them: a module must stay deep-copyable and picklable (a ctypes
+# struct of pointers is neither), and the entries die with the module.
+_module_cache = weakref.WeakKeyDictionary()
+_params_cache = weakref.WeakKeyDictionary()
+
+
 def _decoder_modules(dec):
     """(conv, bn) module pairs of the decoder's 11 BatchNorm layers and its three output convolutions, looked up ONCE per
     decoder object: nn.Module.__getattr__ walks _parameters / _buffers / _modules on every access, and the hot path asked
     for these ~130 times per iteration (65 us in decoder_supported, 45 us in the parameter list: tools/prof_enqueue.py)."""
-    cached = dec.__dict__.get("_fused_modules")
+    cached = _module_cache.get(dec)
     if cached is None:
         pairs = [(getattr(dec, c), getattr(dec, b)) for c, b in _decoder_bn_layers()]
         outs = [getattr(dec, f"conv8{t}") for t in _HEAD_TAGS]
-        cached = dec.__dict__["_fused_modules"] = (pairs, outs)
+        cached = _module_cache[dec] = (pairs, outs)
     return cached
 
 
@@ -629,12 +636,12 @@ def _native_decoder_params(dec, params, nl):
     bns = [bn for _, bn in _decoder_modules(dec)[0]]
     key = tuple([p.data_ptr() for p in params] +
                 [bn.running_mean.data_ptr() if bn.track_running_stats else 0 for bn in bns])
-    cached = dec.__dict__.get("_fused_P")
+    cached = _params_cache.get(dec)
     if cached is not None and cached[0] == key:
         return cached[1], cached[2]
     P, keep = _build_decoder_params(dec, params, nl)
     if all(p.is_contiguous() for p in params):       # (a contiguous COPY of a strided weight would go stale in the cache)
-        dec.__dict__["_fused_P"] = (key, P, keep)
+        _params_cache[dec] = (key, P, keep)
     return P, keep
 
 
