@@ -372,6 +372,8 @@ def ganet() -> ctypes.CDLL:
 def raw_stream(device) -> int:
     """torch's current HIP stream of `device` as an integer handle. (torch.cuda.current_stream(...).cuda_stream builds a
     Stream object per call: ~7 us, 13 times per training iteration — this is the C accessor underneath.)"""
+    if not isinstance(device, torch.device):       # ("cuda" / "cuda:1" / an ordinal: str.index is a method, not None)
+        device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
     idx = device.index
     if idx is None:
         idx = torch.cuda.current_device()
