@@ -557,7 +557,8 @@ class AvatarModel:
         pose_featmap = self.pose_encoder(batch_data["inp_pos_map"])
         image, full_pred, offset_loss, _scale_loss = self._forward(
             batch_data, iteration, self.pose(idx), self.transl(idx), pose_featmap, warmup=False)
-        pose_loss = torch.mean(pose_featmap ** 2)
+        # (one launch each way instead of pow / mean / their three backward kernels over the 8 MB feature map)
+        pose_loss = fused.mean_sq(pose_featmap) if pose_featmap.is_cuda else torch.mean(pose_featmap ** 2)
         return image, full_pred, pose_loss, offset_loss,
 
     def render_free_stage1(self, batch_data, iteration):

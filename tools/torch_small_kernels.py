@@ -11,17 +11,25 @@ from gaussianavatar_amd.losses import l1_loss_w, ssim, weighted_sum
 dev = torch.device("cuda")
 torch.manual_seed(0)
 B, N, S = 2, 200_000, 1024
-mp, npar, op = default_params(batch_size=B, num_points=N, image_width=S, image_height=S, num_frames=16, train_stage=1,
+STAGE = int(os.environ.get("STAGE", "1"))
+mp, npar, op = default_params(batch_size=B, num_points=N, image_width=S, image_height=S, num_frames=16, train_stage=STAGE,
                               smpl_type="smpl", query_posmap_size=512)
 model = AvatarModel(mp, npar, op, train=True, device=dev); model.training_setup(); model.net.train()
+if STAGE == 2:
+    with torch.no_grad():                       # bench.py's stand-in for the stage-1 checkpoint
+        model.net.decoder.conv8N.weight.mul_(0.01); model.net.decoder.conv8N.bias.fill_(-5.65)
 ds = model.train_dataset
 gt = torch.ones(B, 3, S, S, device=dev)
 batches = [collate_frames([ds[(s * B + k) % len(ds)] for k in range(B)], dev) for s in range(2)]
 l = op.lambda_dssim
 def step(i):
-    image, points, offset_loss, geo_loss, scale_loss = model.train_stage1(batches[i % 2], 1)
-    loss = weighted_sum([scale_loss, offset_loss, l1_loss_w(image, gt), ssim(image, gt), geo_loss],
-                        [op.lambda_scale, op.lambda_rgl, 1.0 - l, -l, 1.0], bias=l)
+    if STAGE == 2:
+        image, points, pose_loss, offset_loss = model.train_stage2(batches[i % 2], 1)
+        loss = weighted_sum([offset_loss, l1_loss_w(image, gt), ssim(image, gt), pose_loss], [op.lambda_rgl, 1.0 - l, -l, 10.0], bias=l)
+    else:
+        image, points, offset_loss, geo_loss, scale_loss = model.train_stage1(batches[i % 2], 1)
+        loss = weighted_sum([scale_loss, offset_loss, l1_loss_w(image, gt), ssim(image, gt), geo_loss],
+                            [op.lambda_scale, op.lambda_rgl, 1.0 - l, -l, 1.0], bias=l)
     model.zero_grad(1); loss.backward(); model.step(1)
 for i in range(5): step(i)
 torch.cuda.synchronize()
