@@ -7,6 +7,8 @@ ONE variable, `GA_DEV="key=value,key=value"`, read once at import; without it ev
                         (A/B runs of a variant build, tools/build_variant.sh)
     wgrad_stream=0      decoder backward: the weight-gradient launches on the main stream instead of the side stream
     unet_wgrad_stream=0 stage 2: the pose encoder's weight gradients on the main stream (ganet_unet_bwd without a side stream)
+    encoder_stream=0    stage 2: the pose encoder on the main stream (default: a side stream of its own, beside the geometry net and the
+                        body model forward, and — autograd runs a node's backward on its forward's stream — beside their backward)
     row_sweep=0         decoder: every launch sweeps the rows first-to-last (no alternation)
     native_decoder=0    decoder: the per-layer launch sequence from Python instead of one native call each way
     one_pass_backward=0 decoder: separate weight- / data-gradient kernels for the hidden layers
@@ -28,6 +30,7 @@ class DevKnobs:
     lib_dir: str = ""
     wgrad_stream: bool = True
     unet_wgrad_stream: bool = True
+    encoder_stream: bool = True
     row_sweep: bool = True
     native_decoder: bool = True
     one_pass_backward: bool = True

@@ -33,7 +33,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import fused, parallel
+from . import _dev, fused, parallel
 from .lbs import SMPLBody, skin
 from .network import POP_no_unet, UnetNoCond5DS
 from .renderer import render_batch, render_frames  # noqa: F401
@@ -552,9 +552,29 @@ class AvatarModel:
             geo_loss = parallel.replicated_term(geo_loss)       # every rank computes it; gradients are summed
         return image, full_pred, offset_loss, geo_loss, scale_loss
 
+    def _pose_features(self, inp):
+        """The pose encoder's feature map. On a HIP device the encoder runs on a stream of its own: its ~30 launches are a
+        serial chain of kernels that fill a fraction of the chip (csrc/ganet_unet.hip), and nothing else of the forward
+        pass needs its result before the feature maps are added (network.forward_points waits for the event left on the
+        tensor) — the geometry net's convolutions and the body model run beside it, and so do their backward passes
+        beside the encoder's (autograd runs a node's backward on the stream of its forward and orders the streams)."""
+        if not (inp.is_cuda and _dev.knobs.encoder_stream and torch.is_grad_enabled()):
+            return self.pose_encoder(inp)
+        cur = torch.cuda.current_stream(inp.device)
+        side = fused.encoder_stream(inp.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            feat = self.pose_encoder(inp)
+            ready = fused.encoder_event(inp.device)
+            ready.record(side)
+        inp.record_stream(side)
+        feat.record_stream(cur)
+        feat._ga_ready = ready
+        return feat
+
     def train_stage2(self, batch_data, iteration):
         idx = batch_data["pose_idx"]
-        pose_featmap = self.pose_encoder(batch_data["inp_pos_map"])
+        pose_featmap = self._pose_features(batch_data["inp_pos_map"])
         image, full_pred, offset_loss, _scale_loss = self._forward(
             batch_data, iteration, self.pose(idx), self.transl(idx), pose_featmap, warmup=False)
         # (one launch each way instead of pow / mean / their three backward kernels over the 8 MB feature map)

@@ -581,6 +581,24 @@ _FUSED_BWD = _dev.knobs.one_pass_backward
 # loops. Measured: +1.3 % iterations/s.
 _WGRAD_STREAM = _dev.knobs.wgrad_stream
 _side_streams = {}
+_encoder_streams = {}
+
+
+def encoder_stream(device):
+    """the pose encoder's own stream (one per device; distinct from the weight-gradient side stream, which the encoder's
+    backward uses itself)"""
+    key = torch.device(device).index or 0
+    st = _encoder_streams.get(key)
+    if st is None:
+        st = _encoder_streams[key] = (torch.cuda.Stream(device=device), torch.cuda.Event())
+    return st[0]
+
+
+def encoder_event(device):
+    encoder_stream(device)
+    return _encoder_streams[torch.device(device).index or 0][1]
+
+
 
 
 def _side_stream(device):

@@ -312,6 +312,10 @@ class POP_no_unet(nn.Module):
             geom_featmap, uv_loc = geom_featmap[0].unsqueeze(0), uv_loc[0].unsqueeze(0)
         if self.geom_layer_type is not None:
             geom_featmap = self.geom_proc_layers(geom_featmap)
+        if pose_featmap is not None:
+            ready = getattr(pose_featmap, "_ga_ready", None)      # produced on a side stream (AvatarModel._pose_features)
+            if ready is not None:
+                torch.cuda.current_stream(pose_featmap.device).wait_event(ready)
         pix = geom_featmap if pose_featmap is None else pose_featmap + geom_featmap
         feat_res = geom_featmap.shape[2]
         uv_res = int(uv_loc.shape[1] ** 0.5)
