@@ -26,6 +26,7 @@ reference's assets ship with it.
 from __future__ import annotations
 
 import os
+import weakref
 from types import SimpleNamespace
 from typing import Optional
 
@@ -134,8 +135,14 @@ class _DeviceLoader:
     /root/reference/train.py:63, /root/reference/scene/dataset_mono.py:204-233: ~1-2 ms of waiting per 4 ms
     iteration, 20 ms at every epoch start). `budget_gb` bounds the resident set; a larger dataset keeps streaming."""
 
-    def __init__(self, loader, device, budget_gb: float = 64.0):
+    def __init__(self, loader, device, budget_gb: Optional[float] = None):
         self.loader, self.device = loader, torch.device(device)
+        if budget_gb is None:
+            # a quarter of what is free on THIS device when training starts, at most 64 GB: a 288 GB part keeps the old
+            # figure, a smaller or a busy one keeps streaming instead of running out of memory (ADVICE r04)
+            budget_gb = 64.0
+            if self.device.type == "cuda":
+                budget_gb = min(64.0, 0.25 * torch.cuda.mem_get_info(self.device)[0] / float(1 << 30))
         self.budget = int(budget_gb * (1 << 30))
         self.samples = {}           # dataset index -> {key: per-sample value on the device}
         self.bytes = 0
@@ -303,9 +310,27 @@ class AvatarModel:
             # lives as long as the model: take it out of the cyclic collector's scans. A full collection over it is a
             # 70-95 ms host stall every ~100 iterations of a young process (tools/step_times.py: stage 2, steps 24 and
             # 152), during which nothing is enqueued — 4-5 ms per iteration in a 20-step measurement that catches one.
+            # (gc.freeze is process-wide: thaw what an earlier model froze first, so that only the CURRENT model's objects are
+            # exempt and an earlier model's cyclic garbage — which may hold device tensors — is collected now; `close()`
+            # thaws for good. ADVICE r04.)
             import gc
+            gc.unfreeze()
             gc.collect()
             gc.freeze()
+            self._gc_frozen = True
+
+    def close(self):
+        """Undo the process-wide side effects of training_setup (the cyclic collector's frozen generation) and drop the
+        resident training samples."""
+        if getattr(self, "_gc_frozen", False):
+            import gc
+            gc.unfreeze()
+            self._gc_frozen = False
+        ref = getattr(self, "_device_loader", None)
+        loader = ref() if ref is not None else None
+        if loader is not None:
+            loader.samples.clear()
+            loader.bytes = 0
 
     # ------------------------------------------------------------------ checkpoints
     def _ckpt_dir(self, iteration):
@@ -368,7 +393,9 @@ class AvatarModel:
                 self.train_dataset, batch_size=self.batch_size, shuffle=sampler is None, sampler=sampler,
                 num_workers=workers, drop_last=True, collate_fn=_host_collate,
                 pin_memory=self.device.type == "cuda", persistent_workers=workers > 0)
-            return _DeviceLoader(loader, self.device)
+            dl = _DeviceLoader(loader, self.device, getattr(self.model_parms, "device_cache_gb", None))
+            self._device_loader = weakref.ref(dl)
+            return dl
         return torch.utils.data.DataLoader(self.train_dataset, batch_size=self.batch_size, shuffle=sampler is None,
                                            sampler=sampler, num_workers=0, drop_last=True,
                                            collate_fn=lambda items: collate_frames(items, self.device))
