@@ -585,7 +585,8 @@ class AvatarModel:
         pass needs its result before the feature maps are added (network.forward_points waits for the event left on the
         tensor) — the geometry net's convolutions and the body model run beside it, and so do their backward passes
         beside the encoder's (autograd runs a node's backward on the stream of its forward and orders the streams)."""
-        if not (inp.is_cuda and _dev.knobs.encoder_stream and torch.is_grad_enabled()):
+        # (one rank only: with several, the encoder's SyncBatchNorm issues collectives, which stay on the main stream)
+        if not (inp.is_cuda and _dev.knobs.encoder_stream and torch.is_grad_enabled() and parallel.world_size() == 1):
             return self.pose_encoder(inp)
         cur = torch.cuda.current_stream(inp.device)
         side = fused.encoder_stream(inp.device)
