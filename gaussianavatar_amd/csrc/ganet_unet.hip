@@ -6,22 +6,25 @@
 //   (the reference's LeakyReLU(0.2, inplace) in front of conv2..5 also acts on the skip tensors: a_k = leaky(bn(conv_k)))
 //
 // Everything is channels-last ([B,H,W,C]) and NOTHING normalised or activated is ever stored: a layer writes its raw
-// convolution output z (+ the BatchNorm column sums of z out of the epilogue), and every consumer applies
-// act(z * scale + shift) while it loads its operand — the decoder's scheme (ganet.h). The concatenations are virtual: a
-// consumer's K dimension runs over two source tensors ("segments"). Backward likewise: a layer keeps
-// Gy = dL/d(BatchNorm output) (written, x act', by the dgrad kernel of its consumer(s), with the sums of Gy and Gy.y^
-// in that epilogue) and dz = cA Gy + cQ z + cP is assembled on load by the layer's own dgrad / wgrad kernels.
+// convolution output z (+ the BatchNorm column sums of z out of the epilogue), and every consumer applies its operand's
+// prologue while it loads — ONE formula, act(k0 g + k1 x + k2), with a [3][C] coefficient block per tensor written by
+// whoever produces it (raw: (0, 1, 0); act(bn(z)): (0, scale, shift); dz = cA Gy + cQ z + cP: the BatchNorm backward
+// folded) — the decoder's scheme (ganet.h). The concatenations are virtual: a consumer's K dimension runs over two source
+// tensors ("segments"). Backward likewise: a layer keeps Gy = dL/d(BatchNorm output) (written, x act', by the dgrad
+// kernel of its consumer(s), with the sums of Gy and Gy.y^ in that epilogue) and dz is assembled on load by the layer's
+// own dgrad / wgrad kernels.
 //
 // Two gather patterns cover all four convolution flavours (c = coarse grid [B,Hc,Wc], f = fine grid [B,2Hc,2Wc]):
 //   S  out on c, 16 taps (ky,kx) from f at (2y + ky - 1, 2x + kx - 1)      conv forward, transposed-conv input gradient
 //   T  out on f, per parity class of (y,x) 2 x 2 taps from c               transposed-conv forward, conv input gradient
-// as one GEMM per output tile: a wave owns 32 pixels x 32 channels, the four waves of a workgroup split the taps and add
-// their tiles through LDS; fp32 matrix instruction (v_mfma_f32_32x32x2_f32: exact fp32 products); lane (half, row)
-// loads 16 consecutive channels of its pixel per 32-channel chunk (the reduction order over k is free). The weight
-// gradient reduces over the coarse pixels with the pixel index as the MFMA's k: one dword per lane and operand per
-// step, per-lane channel coefficients, deterministic partial tiles per 256-pixel chunk.
-// The maps are tiny (64^2 .. 4^2 pixels x <= 512 channels): 1.2 GFLOP forward per frame, launch- and latency-bound —
-// the point of this file is the ~40 torch / rocBLAS launches per pass it replaces.
+// as one GEMM per output tile of 32 pixels x 32 channels on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32: exact
+// fp32 products); lane (half, row) loads 16 consecutive channels of its pixel per 32-channel chunk (the reduction order
+// over k is free). A tile's (chunk, tap) steps are cut over the waves of a workgroup (partial tiles through LDS) and over
+// workgroups (partial tiles through global memory, a ticket per tile: ugemm_kernel). The weight gradient reduces over the
+// coarse pixels with the pixel index as the MFMA's k: one dword per lane and operand per step, per-lane channel
+// coefficients, deterministic partial tiles per 256-pixel chunk (uwgrad_kernel); ganet_unet_bwd issues it on a side stream.
+// The maps are tiny (64^2 .. 4^2 pixels x <= 512 channels): 1.2 GFLOP forward per frame, launch- and latency-bound — what a
+// launch costs here, and the load-scheduling mistakes that cost most, are written up in profiles/r05_pose_encoder.md.
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
