@@ -71,7 +71,7 @@ def main():
                 parts[name].append(time.perf_counter() - t)
         return w
 
-    pair_windows = []                                  # mean (tile, Gaussian) pairs per 2-frame launch, 40 iterations at a time
+    pair_windows = []                                  # mean (tile, Gaussian) pairs per frame (rasterizer.pair_statistics), 40 iterations at a time
 
     def step(self, epoch):
         t = time.perf_counter()
@@ -124,7 +124,7 @@ def main():
            "iterations": n, "timed": len(dt), "iters_per_s_mean": len(dt) / sum(dt),
            "ms_per_iter_median": 1e3 * dts[len(dts) // 2], "ms_per_iter_p10": 1e3 * dts[len(dts) // 10],
            "ms_per_iter_p90": 1e3 * dts[9 * len(dts) // 10], "dataset_write_s": t_write,
-           "pairs_per_launch_mean_by_40_iterations": pair_windows,
+           "pairs_per_frame_mean_by_40_iterations": pair_windows,
            "host_ms_inside_our_entry_points_median": {k: 1e3 * sorted(v[skip:])[len(v[skip:]) // 2] for k, v in parts.items() if len(v) > skip}}
     ours = sum(res["host_ms_inside_our_entry_points_median"].values())
     res["host_ms_script_own_code_and_item_wait_median"] = res["ms_per_iter_median"] - ours
