@@ -14,7 +14,6 @@ namespace gsr {
 namespace {
 
 constexpr int SCAN_THREADS = 1024;
-constexpr int SORT_CAP = 8192;        // keys sorted in LDS at once by the large class (64 KiB; avatar tiles reach ~4600)
 constexpr int MERGE_ITEMS = 8;        // outputs per thread per merge step
 
 // ------------------------------------------------------------------ K2
@@ -169,62 +168,6 @@ scatter_kernel(int P, int gx, int64_t max_pairs, const int4* __restrict__ rect,
 }
 
 // ------------------------------------------------------------------ K4
-// Bitonic sort of n2 (power of two) keys held in LDS by SORT_THREADS threads.
-// The plain network (one compare-exchange per thread and stage: two 8-byte reads + two writes) is
-// LDS-BANDWIDTH bound: a 4096-key list moves 64 KiB per stage, 78 stages = 5 MB, at 128 B/clk per CU
-// shared by the two resident workgroups = 920 cycles per stage (measured). So stages are taken three
-// at a time: a thread loads the 8 keys that three consecutive distances (j, j/2, j/4 — a closed
-// sub-network) connect, runs the 12 compare-exchanges in registers and writes the 8 keys back: one LDS
-// round trip per three stages (30 instead of 78 for 4096 keys). All 8 keys of a thread share the
-// direction bit (i & k), because k lies above every distance of its level.
-template <int S>
-__device__ __forceinline__ void bitonic_chunk(uint64_t* s, int t, int jl, int k) {
-  constexpr int NK = 1 << S;
-  const int base = ((t & ~(jl - 1)) << S) | (t & (jl - 1));      // S zero bits inserted at log2(jl)
-  const bool up = (base & k) == 0;
-  uint64_t key[NK];
-#pragma unroll
-  for (int m = 0; m < NK; ++m) key[m] = s[base + m * jl];
-#pragma unroll
-  for (int d = S - 1; d >= 0; --d)
-#pragma unroll
-    for (int m = 0; m < NK; ++m)
-      if (!(m & (1 << d))) {
-        const uint64_t a = key[m], b = key[m | (1 << d)];
-        const bool sw = (a > b) == up;
-        key[m] = sw ? b : a;
-        key[m | (1 << d)] = sw ? a : b;
-      }
-#pragma unroll
-  for (int m = 0; m < NK; ++m) s[base + m * jl] = key[m];
-}
-
-template <int SORT_THREADS>
-__device__ __forceinline__ void bitonic_sort_lds(uint64_t* s, int n2, int tid) {
-  for (int k = 2; k <= n2; k <<= 1) {
-    int j = k >> 1;                       // distances of this level: j, j/2, ..., 1
-    while (j >= 1) {
-      const int left = 32 - __clz(j);     // stages left in the level
-      // three stages per round trip whatever the list length (measured on the bench scene, one frame: 1 stage
-      // per trip 48.9 us, 2: 35.7, 3: 34.3, "as many as keep every thread busy": 39.6)
-      const int st = left >= 3 ? 3 : left;
-      const int jl = j >> (st - 1);       // smallest distance of the chunk
-      const int nthr = n2 >> st;
-      if (st == 3) { for (int t = tid; t < nthr; t += SORT_THREADS) bitonic_chunk<3>(s, t, jl, k); }
-      else if (st == 2) { for (int t = tid; t < nthr; t += SORT_THREADS) bitonic_chunk<2>(s, t, jl, k); }
-      else { for (int t = tid; t < nthr; t += SORT_THREADS) bitonic_chunk<1>(s, t, jl, k); }
-      __syncthreads();
-      j >>= st;
-    }
-  }
-}
-
-__device__ __forceinline__ int next_pow2(int n) {
-  int p = 2;
-  while (p < n) p <<= 1;
-  return p;
-}
-
 // Merge-path split: number of elements taken from A among the first `diag` outputs of
 // merge(A[0..na), B[0..nb)); ties go to A (stable, although keys are unique here).
 __device__ __forceinline__ int merge_split(const uint64_t* A, int na, const uint64_t* B, int nb,
@@ -297,62 +240,6 @@ __device__ __forceinline__ uint64_t* merge_sort_lds(uint64_t* a, uint64_t* b, in
   return src;
 }
 
-// One tile's list, sorted by all SORT_THREADS threads of the workgroup (s_key: SORT_CAP keys of LDS).
-template <int SORT_THREADS>
-__device__ __forceinline__ void sort_tile_whole(int tile, int64_t cap, const uint32_t* __restrict__ tile_offset,
-                                                uint64_t* __restrict__ pair_key, uint64_t* __restrict__ pair_tmp,
-                                                uint32_t* __restrict__ point_list, uint64_t* s_key, int tid) {
-  const int64_t start = min((int64_t)tile_offset[tile], cap);
-  const int64_t end = min((int64_t)tile_offset[tile + 1], cap);
-  const int n = (int)(end - start);
-  if (n <= 0) return;
-  uint64_t* keys = pair_key + start;
-  uint32_t* out = point_list + start;
-  if (n <= SORT_CAP) {
-    const int n2 = next_pow2(n);
-    for (int i = tid; i < n2; i += SORT_THREADS) s_key[i] = (i < n) ? keys[i] : ~0ull;
-    __syncthreads();
-    bitonic_sort_lds<SORT_THREADS>(s_key, n2, tid);
-    for (int i = tid; i < n; i += SORT_THREADS) out[i] = (uint32_t)s_key[i];
-    return;
-  }
-  // Oversized list: sort SORT_CAP-sized runs in LDS, then merge runs through HBM.
-  for (int c0 = 0; c0 < n; c0 += SORT_CAP) {
-    const int m = min(SORT_CAP, n - c0);
-    const int m2 = next_pow2(m);
-    for (int i = tid; i < m2; i += SORT_THREADS) s_key[i] = (i < m) ? keys[c0 + i] : ~0ull;
-    __syncthreads();
-    bitonic_sort_lds<SORT_THREADS>(s_key, m2, tid);
-    for (int i = tid; i < m; i += SORT_THREADS) keys[c0 + i] = s_key[i];
-    __syncthreads();
-  }
-  uint64_t* src = keys;
-  uint64_t* dst = pair_tmp + start;
-  for (int64_t width = SORT_CAP; width < n; width <<= 1) {
-    const int nseg = (n + MERGE_ITEMS - 1) / MERGE_ITEMS;
-    for (int seg = tid; seg < nseg; seg += SORT_THREADS) {
-      const int64_t g0 = (int64_t)seg * MERGE_ITEMS;
-      const int64_t lo = (g0 / (2 * width)) * (2 * width);
-      const int64_t mid = min(lo + width, (int64_t)n);
-      const int64_t hi = min(lo + 2 * width, (int64_t)n);
-      const uint64_t* A = src + lo;
-      const uint64_t* B = src + mid;
-      const int na = (int)(mid - lo), nb = (int)(hi - mid);
-      const int diag = (int)(g0 - lo);
-      int ia = merge_split(A, na, B, nb, diag);
-      int ib = diag - ia;
-      const int cnt = (int)min((int64_t)MERGE_ITEMS, hi - g0);
-      for (int o = 0; o < cnt; ++o) {
-        const bool takeA = (ib >= nb) || (ia < na && A[ia] <= B[ib]);
-        dst[g0 + o] = takeA ? A[ia++] : B[ib++];
-      }
-    }
-    __syncthreads();   // workgroup-scope visibility of dst (one CU, shared L1)
-    uint64_t* t = src; src = dst; dst = t;
-  }
-  for (int i = tid; i < n; i += SORT_THREADS) out[i] = (uint32_t)src[i];
-}
-
 // ---- K4 as launched: chunk sorts + merges.
 // One workgroup sorting a whole list makes the launch as long as its longest list: a 4096-key list is 30
 // dependent LDS round trips (~1 us each), the training scene's densest tiles (~4600 entries) pad to 8192 keys
@@ -361,7 +248,8 @@ __device__ __forceinline__ void sort_tile_whole(int tile, int64_t cap, const uin
 // pairing ALL lists (halves the long lists' thread count: 144 us), two size classes in two launches (144 us).
 // So a list is cut into chunks of SORT_CHUNK keys, every chunk is sorted by its own workgroup (16 KiB of LDS:
 // several per CU), and a list's sorted runs are merged with merge path inside LDS by one workgroup — two levels cover 4
-// chunks (tile_merge_all_kernel); longer lists (none in avatar scenes) take the one-workgroup path with runs merged through HBM. The order is
+// chunks (tile_merge_all_kernel); longer lists (none in avatar scenes; centimetre-sized Gaussians early in a from-scratch
+// training do produce them) are merged per 8192-key block in LDS and then block against block through HBM by one workgroup. The order is
 // the same total order (depth bits, then Gaussian index), whatever the decomposition.
 #ifndef GSR_SORT_CHUNK
 #define GSR_SORT_CHUNK 2048      // (tools/build_gsr_variant.sh -DGSR_SORT_CHUNK=1024: measured in round 4)
@@ -405,21 +293,23 @@ tile_sort_chunk_kernel(int T, int ordered, int64_t max_pairs, const uint32_t* __
   __shared__ uint64_t s_key[2][SORT_CHUNK];
   GSR_FRAME_PTRS();
   const int tid = threadIdx.x;
-  const int c0 = blockIdx.z * SORT_CHUNK;
   for (int rank = blockIdx.x; rank < T; rank += gridDim.x) {
     const TileSpan ts = tile_span(tile_order, tile_offset, max_pairs, rank);
     if (ts.n <= 0) { if (ordered) break; continue; }        // every later list is empty too
-    if (c0 >= ts.n || ts.n > SORT_MAX_CHUNKS * SORT_CHUNK) continue;
-    const int m = min(SORT_CHUNK, ts.n - c0);
-    uint64_t* keys = pair_key + ts.start + c0;
-    __syncthreads();                                        // the previous list's LDS image is dead
-    for (int i = tid; i < m; i += CHUNK_WG) s_key[0][i] = keys[i];
-    __syncthreads();
-    const uint64_t* sorted = merge_sort_lds<CHUNK_WG>(s_key[0], s_key[1], m, tid);
-    if (ts.n <= SORT_CHUNK) {
-      for (int i = tid; i < m; i += CHUNK_WG) point_list[ts.start + i] = (uint32_t)sorted[i];
-    } else {
-      for (int i = tid; i < m; i += CHUNK_WG) keys[i] = sorted[i];
+    // chunks blockIdx.z, + SORT_MAX_CHUNKS, ...: one pass for the lists the merge launch stages whole (<= MERGE_KEYS keys),
+    // every chunk of a longer list too (it used to be sorted from scratch by its merge workgroup)
+    for (int c0 = blockIdx.z * SORT_CHUNK; c0 < ts.n; c0 += SORT_MAX_CHUNKS * SORT_CHUNK) {
+      const int m = min(SORT_CHUNK, ts.n - c0);
+      uint64_t* keys = pair_key + ts.start + c0;
+      __syncthreads();                                      // the previous chunk's LDS image is dead
+      for (int i = tid; i < m; i += CHUNK_WG) s_key[0][i] = keys[i];
+      __syncthreads();
+      const uint64_t* sorted = merge_sort_lds<CHUNK_WG>(s_key[0], s_key[1], m, tid);
+      if (ts.n <= SORT_CHUNK) {
+        for (int i = tid; i < m; i += CHUNK_WG) point_list[ts.start + i] = (uint32_t)sorted[i];
+      } else {
+        for (int i = tid; i < m; i += CHUNK_WG) keys[i] = sorted[i];
+      }
     }
   }
 }
@@ -430,8 +320,81 @@ tile_sort_chunk_kernel(int T, int ordered, int64_t max_pairs, const uint32_t* __
 // a level (merge path), the last level writes point_list. Lists beyond SORT_MAX_CHUNKS chunks (none in avatar scenes) take
 // the whole-list path in the same launch, runs merged through HBM.
 constexpr int MERGE_WG = 1024;
-constexpr int MERGE_KEYS = SORT_MAX_CHUNKS * SORT_CHUNK;         // 8192 = SORT_CAP
-static_assert(MERGE_KEYS == SORT_CAP && MERGE_KEYS == 8 * MERGE_WG, "one 8-key window per thread, LDS image = the long path's");
+constexpr int MERGE_KEYS = SORT_MAX_CHUNKS * SORT_CHUNK;         // 8192 keys staged in LDS at once (64 KiB per buffer; avatar tiles reach ~4600)
+static_assert(MERGE_KEYS == 8 * MERGE_WG, "one 8-key window per thread");
+// The merge levels W = SORT_CHUNK, 2 SORT_CHUNK, ... of n <= MERGE_KEYS keys held in LDS as sorted chunks (src / dst ping-pong,
+// MERGE_WG threads, 8 consecutive outputs per thread and level: merge path). The last level goes to out32 (the low words:
+// the Gaussian indices) if given, else to LDS; returns the LDS buffer that holds the result in the second case.
+__device__ __forceinline__ uint64_t* lds_merge_levels(uint64_t* src, uint64_t* dst, int n, int tid, uint32_t* out32) {
+  const int g0 = tid * 8;
+  for (int W = SORT_CHUNK; W < n; W <<= 1) {
+    const bool last = 2 * W >= n;                             // this level leaves one run = the sorted list
+    if (g0 < n) {
+      const int lo = (g0 / (2 * W)) * (2 * W);
+      const int mid = min(lo + W, n), hi = min(lo + 2 * W, n);
+      const uint64_t* A = src + lo;
+      const uint64_t* B = src + mid;
+      const int na = mid - lo, nb = hi - mid;
+      int ia = merge_split(A, na, B, nb, g0 - lo);
+      int ib = g0 - lo - ia;
+      const int cnt = min(8, hi - g0);
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        if (o < cnt) {
+          const bool takeA = (ib >= nb) || (ia < na && A[ia] <= B[ib]);
+          const uint64_t v = takeA ? A[ia++] : B[ib++];
+          if (last && out32) out32[g0 + o] = (uint32_t)v;
+          else dst[g0 + o] = v;
+        }
+      }
+    }
+    __syncthreads();
+    uint64_t* t = src; src = dst; dst = t;
+  }
+  return src;
+}
+
+// A list beyond MERGE_KEYS keys, its SORT_CHUNK-key chunks sorted (tile_sort_chunk_kernel): every MERGE_KEYS-key block is
+// merged in LDS like a short list, then the blocks are merged through HBM (keys <-> pair_tmp ping-pong), all by this one
+// workgroup — a thread takes MERGE_ITEMS consecutive outputs of a level: a binary search and MERGE_ITEMS dependent steps on
+// global memory, which is why this path is slow (~50 us per 16 k keys) and why avatar-sized Gaussians never take it.
+__device__ __forceinline__ void merge_long_list(uint64_t* keys, uint64_t* tmp, uint32_t* out, int n, uint64_t* s_merge, int tid) {
+  for (int b0 = 0; b0 < n; b0 += MERGE_KEYS) {
+    const int m = min(MERGE_KEYS, n - b0);
+    __syncthreads();                                          // the previous block's LDS image is dead
+    for (int i = tid; i < m; i += MERGE_WG) s_merge[i] = keys[b0 + i];
+    __syncthreads();
+    const uint64_t* r = lds_merge_levels(s_merge, s_merge + MERGE_KEYS, m, tid, nullptr);
+    for (int i = tid; i < m; i += MERGE_WG) keys[b0 + i] = r[i];
+  }
+  __syncthreads();                                            // workgroup-scope visibility of the blocks (one CU, shared L1)
+  uint64_t* src = keys;
+  uint64_t* dst = tmp;
+  for (int64_t width = MERGE_KEYS; width < n; width <<= 1) {
+    const int nseg = (n + MERGE_ITEMS - 1) / MERGE_ITEMS;
+    for (int seg = tid; seg < nseg; seg += MERGE_WG) {
+      const int64_t g0 = (int64_t)seg * MERGE_ITEMS;
+      const int64_t lo = (g0 / (2 * width)) * (2 * width);
+      const int64_t mid = min(lo + width, (int64_t)n);
+      const int64_t hi = min(lo + 2 * width, (int64_t)n);
+      const uint64_t* A = src + lo;
+      const uint64_t* B = src + mid;
+      const int na = (int)(mid - lo), nb = (int)(hi - mid);
+      const int diag = (int)(g0 - lo);
+      int ia = merge_split(A, na, B, nb, diag);
+      int ib = diag - ia;
+      const int cnt = (int)min((int64_t)MERGE_ITEMS, hi - g0);
+      for (int o = 0; o < cnt; ++o) {
+        const bool takeA = (ib >= nb) || (ia < na && A[ia] <= B[ib]);
+        dst[g0 + o] = takeA ? A[ia++] : B[ib++];
+      }
+    }
+    __syncthreads();   // workgroup-scope visibility of dst (one CU, shared L1)
+    uint64_t* t = src; src = dst; dst = t;
+  }
+  for (int i = tid; i < n; i += MERGE_WG) out[i] = (uint32_t)src[i];
+}
+
 __global__ void __launch_bounds__(MERGE_WG)
 tile_merge_all_kernel(int T, int ordered, int64_t max_pairs, const uint32_t* __restrict__ tile_order,
                       const uint32_t* __restrict__ tile_offset, uint64_t* __restrict__ pair_key,
@@ -446,39 +409,13 @@ tile_merge_all_kernel(int T, int ordered, int64_t max_pairs, const uint32_t* __r
     if (ts.n <= SORT_CHUNK) { if (ordered && ts.n < SORT_CHUNK) break; continue; }
     __syncthreads();                                          // the previous list's LDS image is dead
     if (ts.n > MERGE_KEYS) {
-      sort_tile_whole<MERGE_WG>((int)tile_order[rank], max_pairs, tile_offset, pair_key, pair_tmp, point_list, s_merge, tid);
+      merge_long_list(pair_key + ts.start, pair_tmp + ts.start, point_list + ts.start, ts.n, s_merge, tid);
       continue;
     }
     const int n = ts.n;
-    uint64_t* src = s_merge;
-    uint64_t* dst = s_merge + MERGE_KEYS;
-    for (int i = tid; i < n; i += MERGE_WG) src[i] = pair_key[ts.start + i];
+    for (int i = tid; i < n; i += MERGE_WG) s_merge[i] = pair_key[ts.start + i];
     __syncthreads();
-    const int g0 = tid * 8;
-    for (int W = SORT_CHUNK; W < n; W <<= 1) {
-      const bool last = 2 * W >= n;                           // this level leaves one run = the sorted list
-      if (g0 < n) {
-        const int lo = (g0 / (2 * W)) * (2 * W);
-        const int mid = min(lo + W, n), hi = min(lo + 2 * W, n);
-        const uint64_t* A = src + lo;
-        const uint64_t* B = src + mid;
-        const int na = mid - lo, nb = hi - mid;
-        int ia = merge_split(A, na, B, nb, g0 - lo);
-        int ib = g0 - lo - ia;
-        const int cnt = min(8, hi - g0);
-#pragma unroll
-        for (int o = 0; o < 8; ++o) {
-          if (o < cnt) {
-            const bool takeA = (ib >= nb) || (ia < na && A[ia] <= B[ib]);
-            const uint64_t v = takeA ? A[ia++] : B[ib++];
-            if (last) point_list[ts.start + g0 + o] = (uint32_t)v;
-            else dst[g0 + o] = v;
-          }
-        }
-      }
-      __syncthreads();
-      uint64_t* t = src; src = dst; dst = t;
-    }
+    lds_merge_levels(s_merge, s_merge + MERGE_KEYS, n, tid, point_list + ts.start);
   }
 }
 
