@@ -496,6 +496,14 @@ class AvatarModel:
             mg = None
             if pose_featmap is not None and parallel.world_size() > 1:
                 mg = pose_featmap.shape[0] * self.uv_coord_map.shape[0] * parallel.world_size()
+            pending = getattr(self, "_pose_pending", None)
+            if pending is not None:
+                # the encoder's result comes from its own stream (_pose_features); network.forward_points waits for the event
+                # the TENSOR carries, as late as it can. A tensor that lost the attribute on the way here (a view, a copy)
+                # is waited for now instead: correctness first, the overlap is what is lost
+                if pose_featmap is not None and getattr(pose_featmap, "_ga_ready", None) is None:
+                    torch.cuda.current_stream(self.device).wait_event(pending)
+                self._pose_pending = None
             res, s_logit, c_logit = self.net.forward_points(pose_featmap, self.geo_feature, uv, raw_heads=True,
                                                             m_global=mg)
             b = res.shape[0]
@@ -598,6 +606,7 @@ class AvatarModel:
         inp.record_stream(side)
         feat.record_stream(cur)
         feat._ga_ready = ready
+        self._pose_pending = ready          # (the fallback wait of _decode, should the attribute get lost on the way)
         return feat
 
     def train_stage2(self, batch_data, iteration):
