@@ -45,7 +45,7 @@ _LAYOUT_FIELDS = ["total_bytes", "depth", "xy", "conic_opacity", "rgb", "cov3d",
                   "tiles_touched", "clamped", "tile_count", "tile_offset", "tile_cursor",
                   "pair_key", "point_list", "pair_tmp", "final_T", "n_contrib", "grad_acc", "status", "seg_heads",
                   "seg_count", "xyext", "seg_entries", "seg_ckpt", "seg_info", "pix_accum", "pair_grad", "seg_list",
-                  "eval_bytes", "train_bytes"]
+                  "eval_bytes", "train_bytes", "sort_work"]
 
 GSR_WS_EVAL, GSR_WS_TRAIN, GSR_WS_DEBUG = 0, 1, 2
 
@@ -70,7 +70,7 @@ _galbs = None
 
 GSR_SYMBOLS = ["gsr_workspace_bytes", "gsr_workspace_bytes_for", "gsr_workspace_layout", "gsr_forward", "gsr_backward",
                "gsr_forward_eval", "gsr_forward_eval_batch",
-               "gsr_mark_visible", "gsr_batch_status", "gsr_read_status", "gsr_last_error", "gsr_abi_version",
+               "gsr_mark_visible", "gsr_batch_status", "gsr_read_status", "gsr_last_error", "gsr_abi_version", "gsr_set_trace",
                "gsr_profile_create", "gsr_profile_destroy", "gsr_profile_bind", "gsr_profile_read",
                "gsr_profile_kernel_name", "gsr_render_block_edge",
                "gsr_forward_batch", "gsr_backward_batch"]
@@ -126,7 +126,7 @@ def gsr() -> ctypes.CDLL:
         lib.gsr_render_block_edge.restype = c_int
         lib.gsr_profile_kernel_name.restype = c_char_p
         lib.gsr_profile_kernel_name.argtypes = [c_int]
-        if lib.gsr_abi_version() != 5:
+        if lib.gsr_abi_version() != 6:
             raise RuntimeError("libgsr_hip.so ABI version mismatch; rebuild")
         _gsr = lib
     return _gsr

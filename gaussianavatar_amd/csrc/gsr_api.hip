@@ -96,6 +96,7 @@ int compute_layout(int P, int W, int H, int64_t max_pairs, GsrLayout* out) {
   out->seg_heads = take(8 * 64 * 4);            // directly behind status: one clear
   out->seg_count = take((uint64_t)d.T * GSR_SEG_BLOCKS * 4);
   out->xyext = take(Pn * 16);
+  out->sort_work = take((uint64_t)sort_work_capacity(max_pairs) * 4);
   out->eval_bytes = off;
   // ---- what the forward pass leaves for the backward pass (GSR_WS_TRAIN)
   out->grad_acc = take(Pn * GSR_GRAD_STRIDE * 4);
@@ -145,6 +146,7 @@ Workspace resolve(void* base, const GsrLayout& L) {
   w.pix_accum = reinterpret_cast<float4*>(b + L.pix_accum);
   w.pair_grad = reinterpret_cast<float*>(b + L.pair_grad);
   w.seg_list = reinterpret_cast<uint32_t*>(b + L.seg_list);
+  w.sort_work = reinterpret_cast<uint32_t*>(b + L.sort_work);
   return w;
 }
 
@@ -154,7 +156,23 @@ static int check_hip(hipError_t e, const char* what) {
   return GSR_ERR_LAUNCH;
 }
 
+// gsr_set_trace(1): every stage of every call is announced on stderr and waited for (development: which kernel faulted)
+static std::atomic<int> g_trace{0};
+
+void trace_sync(hipStream_t stream, const char* what) {
+  if (!g_trace.load(std::memory_order_relaxed)) return;
+  fprintf(stderr, "[gsr] %s ...", what); fflush(stderr);
+  const hipError_t e = hipStreamSynchronize(stream);
+  fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e)); fflush(stderr);
+}
+
 static int debug_sync(const GsrSettings* s, hipStream_t stream, const char* what) {
+  if (g_trace.load(std::memory_order_relaxed)) {
+    fprintf(stderr, "[gsr] %s ...", what); fflush(stderr);
+    const hipError_t e = hipStreamSynchronize(stream);
+    fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e)); fflush(stderr);
+    return check_hip(e, what);
+  }
   if (!s->debug) return GSR_OK;
   return check_hip(hipStreamSynchronize(stream), what);
 }
@@ -547,6 +565,8 @@ const char* gsr_profile_kernel_name(int id) {
 }
 
 int gsr_render_block_edge(void) { return GSR_SUB; }
+
+void gsr_set_trace(int on) { g_trace.store(on ? 1 : 0, std::memory_order_relaxed); }
 
 const char* gsr_last_error(void) { return g_err; }
 

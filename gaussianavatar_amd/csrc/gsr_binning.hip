@@ -15,14 +15,22 @@ namespace {
 
 constexpr int SCAN_THREADS = 1024;
 constexpr int MERGE_ITEMS = 8;        // outputs per thread per merge step
+#ifndef GSR_SORT_CHUNK
+#define GSR_SORT_CHUNK 2048      // (tools/build_gsr_variant.sh -DGSR_SORT_CHUNK=1024: measured in round 4, see DESIGN 4.1)
+#endif
+constexpr int SORT_CHUNK = GSR_SORT_CHUNK;
+// lists beyond GSR_SORT_LDS_KEYS keys: sorted chunks -> output buckets (psrs_bucket); a wave's lane owns a chunk there
+constexpr int PSRS_MAX_RUNS = 64;
+constexpr int PSRS_MAX_KEYS = PSRS_MAX_RUNS * SORT_CHUNK;
 
 // ------------------------------------------------------------------ K2
 __global__ void __launch_bounds__(SCAN_THREADS)
 tile_scan_kernel(int T, int64_t max_pairs, uint32_t* __restrict__ tile_count,
                  uint32_t* __restrict__ tile_offset, uint32_t* __restrict__ tile_cursor,
-                 int32_t* __restrict__ status, size_t ws_stride) {
+                 int32_t* __restrict__ status, uint32_t* __restrict__ sort_work, int work_cap, size_t ws_stride) {
   {
     const size_t off = (size_t)blockIdx.y * ws_stride;   // batched launch: this frame's workspace
+    sort_work = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(sort_work) + off);
     tile_count = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(tile_count) + off);
     tile_offset = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(tile_offset) + off);
     tile_cursor = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(tile_cursor) + off);
@@ -30,7 +38,9 @@ tile_scan_kernel(int T, int64_t max_pairs, uint32_t* __restrict__ tile_count,
   }
   __shared__ uint32_t s_wave[SCAN_THREADS / GSR_WAVE];
   __shared__ uint32_t s_max[SCAN_THREADS / GSR_WAVE];
+  __shared__ uint32_t s_nwork;
   const int tid = threadIdx.x;
+  if (tid == 0) s_nwork = 0u;
   const int per = (T + SCAN_THREADS - 1) / SCAN_THREADS;
   const int lo = tid * per;
   const int hi = min(lo + per, T);
@@ -62,9 +72,19 @@ tile_scan_kernel(int T, int64_t max_pairs, uint32_t* __restrict__ tile_count,
   }
   uint32_t run = base + incl - sum;   // exclusive prefix of this thread's chunk
   for (int t = lo; t < hi; ++t) {
+    const uint32_t c = tile_count[t];
     tile_offset[t] = run;
     tile_cursor[t] = run;
-    run += tile_count[t];
+    // a list beyond the merge launch's LDS capacity is sorted bucket by bucket (tile_merge_all_kernel: psrs_bucket):
+    // one work item per output bucket
+    const int64_t n = min((int64_t)run + c, max_pairs) - min((int64_t)run, max_pairs);
+    if (n > GSR_SORT_LDS_KEYS && n <= PSRS_MAX_KEYS) {
+      const uint32_t nb = (uint32_t)((n + GSR_SORT_BUCKET - 1) / GSR_SORT_BUCKET);
+      const uint32_t w0 = atomicAdd(&s_nwork, nb);
+      for (uint32_t b = 0; b < nb; ++b)
+        if (w0 + b < (uint32_t)work_cap) sort_work[w0 + b] = ((uint32_t)t << 8) | b;
+    }
+    run += c;
   }
   if (tid == 0) {
     tile_offset[T] = total;
@@ -84,6 +104,14 @@ tile_scan_kernel(int T, int64_t max_pairs, uint32_t* __restrict__ tile_count,
   if (tid < NCLS) s_cls[tid] = 0;
   __syncthreads();
   auto cls_of = [](uint32_t c) { return c ? 32 - __clz(c) : 0; };   // 0 for empty, else 1..32
+  // the class is that of the list AS THE LATER KERNELS SEE IT — cut off at the pair buffer's capacity: they walk this
+  // order and stop at the first list too short to need them, so a tile whose pairs fell beyond an overflowed buffer
+  // (length 0 for them, whatever its count) must sort behind every list that is still there. (Rounds 1-5 ordered by
+  // the raw counts: after a heavy overflow the walks ended early and left point_list unwritten — a device fault in
+  // render_fwd, found in round 6.)
+  auto capped = [max_pairs](uint32_t start, uint32_t c) {
+    return (uint32_t)(min((int64_t)start + c, max_pairs) - min((int64_t)start, max_pairs));
+  };
   // most tiles are empty (class 0): those are counted / placed once per wave (ballot), the rest per tile
   auto place = [&](int c, bool on) -> uint32_t {
     const unsigned long long empt = __ballot(on && c == 0);
@@ -93,36 +121,53 @@ tile_scan_kernel(int T, int64_t max_pairs, uint32_t* __restrict__ tile_count,
     if (on && c == 0) return base + (uint32_t)__popcll(empt & ((1ull << lane) - 1ull));
     return on ? atomicAdd(&s_cls[c], 1u) : 0u;
   };
-  if (ordered)
+  const uint32_t run0 = base + incl - sum;
+  if (ordered) {
+    uint32_t r = run0;
     for (int k = 0; k < per; ++k) {                      // uniform trip count: the ballots need every lane
       const int t = lo + k;
-      place(t < hi ? cls_of(tile_count[t]) : -1, t < hi);
+      const uint32_t c = t < hi ? tile_count[t] : 0u;
+      place(t < hi ? cls_of(capped(r, c)) : -1, t < hi);
+      r += c;
     }
+  }
   __syncthreads();
   if (tid == 0) {
+    status[5] = (int32_t)min(s_nwork, (uint32_t)work_cap);
     uint32_t run2 = 0;
     for (int c = NCLS - 1; c >= 0; --c) { const uint32_t v = s_cls[c]; s_cls[c] = run2; run2 += v; }
   }
   __syncthreads();
-  if (ordered)
+  if (ordered) {
+    uint32_t r = run0;
     for (int k = 0; k < per; ++k) {
       const int t = lo + k;
-      pos[k] = place(t < hi ? cls_of(tile_count[t]) : -1, t < hi);
+      const uint32_t c = t < hi ? tile_count[t] : 0u;
+      pos[k] = place(t < hi ? cls_of(capped(r, c)) : -1, t < hi);
+      r += c;
     }
+  }
   __syncthreads();                    // every count has been read: the buffer may be overwritten
   for (int t = lo, k = 0; t < hi; ++t, ++k) tile_count[ordered ? pos[k] : t] = (uint32_t)t;
 }
 
 // ------------------------------------------------------------------ K3
-// Append (depth_bits << 32 | index) to every tile a Gaussian touches. The workgroup's pairs are counted
-// per tile in LDS (gsr_common.h: TileAgg), ONE returning global atomic per (workgroup, tile) reserves
-// their slots — all of a workgroup's atomics fly in one round instead of one memory round trip per
-// distinct tile and rect step — and the pairs take their positions from LDS cursors.
+// Append (depth_bits << 32 | index) to every tile a Gaussian touches. The workgroup's pairs are counted per cell of its
+// tile window in LDS (gsr_common.h: TileWin — the same difference array + prefix sum as K1's histogram), ONE returning
+// global atomic per (workgroup, tile) reserves their slots — all of a workgroup's atomics fly in one round — and the
+// pairs take their positions from the cells, which have become cursors. The pairs of a wave's 64 Gaussians are DEALT to
+// its lanes (pair p of the wave -> lane p % 64: a 6-step search in the wave's prefix of rectangle sizes finds its
+// Gaussian) instead of every lane walking its own rectangle: the wave's time is its pair count / 64, not its largest
+// rectangle (scatter 26 -> 1,313 us between 4 and 20 tiles per Gaussian before, profiles/r05_dsweep.txt).
 __global__ void __launch_bounds__(256)
 scatter_kernel(int P, int gx, int64_t max_pairs, const int4* __restrict__ rect,
                const float* __restrict__ depth, uint32_t* __restrict__ tile_cursor,
-               uint64_t* __restrict__ pair_key, size_t ws_stride) {
-  __shared__ TileAgg s_agg;
+               uint64_t* __restrict__ pair_key, size_t ws_stride, int win_cells) {
+  extern __shared__ int s_dyn[];
+  __shared__ int s_box[4];
+  __shared__ int4 s_rect[256];
+  __shared__ uint64_t s_key[256];
+  __shared__ int s_incl[4][GSR_WAVE];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   {
     const size_t off = (size_t)blockIdx.y * ws_stride;
@@ -131,9 +176,54 @@ scatter_kernel(int P, int gx, int64_t max_pairs, const int4* __restrict__ rect,
     tile_cursor = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(tile_cursor) + off);
     pair_key = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(pair_key) + off);
   }
-  agg_clear(s_agg);
   const int4 rc = i < P ? rect[i] : make_int4(0, 0, 0, 0);
   const uint64_t key = i < P ? (((uint64_t)__float_as_uint(depth[i]) << 32) | (uint32_t)i) : 0ull;
+  const int ntile = (rc.z - rc.x) * (rc.w - rc.y);
+  const TileWin wn = wg_tile_window(rc, ntile > 0, s_box, win_cells);
+  if (wn.w == 0) return;
+  if (wn.w > 0) {
+    const int ncell = wn.w * wn.h;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e = threadIdx.x; e < ncell; e += blockDim.x) s_dyn[e] = 0;
+    s_rect[threadIdx.x] = rc;
+    s_key[threadIdx.x] = key;
+    // inclusive prefix of the rectangle sizes over the wave
+    int incl = ntile > 0 ? ntile : 0;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off);
+      if (lane >= off) incl += t;
+    }
+    s_incl[wave][lane] = incl;
+    const int total = __shfl(incl, 63);
+    __syncthreads();
+    if (ntile > 0) win_mark(s_dyn, wn, rc);
+    __syncthreads();
+    win_prefix(s_dyn, wn);
+    for (int e = threadIdx.x; e < ncell; e += blockDim.x) {
+      const int c = s_dyn[e];
+      if (c > 0) s_dyn[e] = (int)atomicAdd(&tile_cursor[(wn.y0 + e / wn.w) * gx + wn.x0 + e % wn.w], (uint32_t)c);
+    }
+    __syncthreads();
+    const int* incl_w = s_incl[wave];
+    for (int p = lane; p < total; p += GSR_WAVE) {
+      int j = 0;                                              // first Gaussian of the wave whose inclusive prefix exceeds p
+#pragma unroll
+      for (int step = 32; step > 0; step >>= 1)
+        if (incl_w[j + step - 1] <= p) j += step;
+      const int4 r = s_rect[wave * GSR_WAVE + j];
+      const int rw = r.z - r.x;
+      const int k = p - (incl_w[j] - rw * (r.w - r.y));       // index of the pair inside the rectangle, row-major
+      const int ry = k / rw;
+      const int cell = (r.y + ry - wn.y0) * wn.w + (r.x + (k - ry * rw) - wn.x0);
+      const uint32_t pos = (uint32_t)atomicAdd(&s_dyn[cell], 1);
+      if ((int64_t)pos < max_pairs) pair_key[pos] = s_key[wave * GSR_WAVE + j];
+    }
+    return;
+  }
+  // the window does not fit (more than GSR_WIN_CELLS tiles in the frame): rounds 1-5's hash-table path
+  TileAgg& s_agg = *reinterpret_cast<TileAgg*>(s_dyn);
+  agg_clear(s_agg);
   const bool big = rect_is_big(rc);                     // walked by the whole wave below (gsr_common.h)
   __syncthreads();
   if (!big)
@@ -251,10 +341,6 @@ __device__ __forceinline__ uint64_t* merge_sort_lds(uint64_t* a, uint64_t* b, in
 // chunks (tile_merge_all_kernel); longer lists (none in avatar scenes; centimetre-sized Gaussians early in a from-scratch
 // training do produce them) are merged per 8192-key block in LDS and then block against block through HBM by one workgroup. The order is
 // the same total order (depth bits, then Gaussian index), whatever the decomposition.
-#ifndef GSR_SORT_CHUNK
-#define GSR_SORT_CHUNK 2048      // (tools/build_gsr_variant.sh -DGSR_SORT_CHUNK=1024: measured in round 4, see DESIGN 4.1)
-#endif
-constexpr int SORT_CHUNK = GSR_SORT_CHUNK;
 constexpr int SORT_MAX_CHUNKS = 8192 / SORT_CHUNK;      // the merge launch stages a whole list: <= 8192 keys of LDS per buffer
 
 struct TileSpan { int64_t start; int n; };
@@ -395,23 +481,161 @@ __device__ __forceinline__ void merge_long_list(uint64_t* keys, uint64_t* tmp, u
   for (int i = tid; i < n; i += MERGE_WG) out[i] = (uint32_t)src[i];
 }
 
+// ---- lists beyond MERGE_KEYS keys (round 6): sorted chunks -> independent output buckets.
+// Centimetre-sized Gaussians (the first few hundred iterations of a from-scratch training: the reference's scale warm-up)
+// put 10-60 k keys on a tile. Rounds 1-5 merged such a list level by level through HBM in ONE workgroup (2.5 ms of tile
+// sort at 4 M pairs per frame, profiles/r05_dsweep.txt). Now every ~4096-key piece of the OUTPUT is its own work item
+// (tile_scan_kernel lists them): parallel sorting by regular sampling over the list's sorted chunks ("runs").
+//   1. samples: the last key of every group of g consecutive keys of every run (g = psrs_group(runs): runs are
+//      SORT_CHUNK-aligned and g divides SORT_CHUNK, so sample q is list position (q + 1) g - 1), S = n / g of them, sorted
+//      in LDS; splitter q of p = ceil(n / GSR_SORT_BUCKET) buckets = the sample of rank floor(q S / p)
+//   2. a run's keys below a splitter: between g t and g (t + 1) where t = its samples below the splitter, so the rank of
+//      splitter q lies in [g r_q, g r_q + runs g) and a bucket holds < n / p + (runs + 1) g + 1 <= MERGE_KEYS keys:
+//      it always fits the LDS buffer — by construction, not by luck (psrs_group)
+//   3. the bucket's piece of every run by a wave-wide two-round search (64 probes, then 32 per splitter), gathered into
+//      LDS back to back, merged pairwise in log2(runs) levels (lds_merge_runs), written to its place in point_list
+// Every workgroup recomputes the splitters it needs from the samples (<= 4096 keys, usually a few hundred): no
+// dependency between work items, no extra launch, no grid-wide barrier. Same total order as every other path.
+static_assert(SORT_CHUNK <= 2048 && (SORT_CHUNK & (SORT_CHUNK - 1)) == 0, "psrs_bucket: a run is searched as <= 64 groups of 32");
+__host__ __device__ inline int psrs_group(int runs) {
+  const int lim = GSR_SORT_BUCKET / (runs + 2);      // (runs + 1) g < GSR_SORT_BUCKET
+  int g = 512;
+  while (g > lim) g >>= 1;
+  return g;
+}
+
+// pairwise merge, level by level, of the nruns sorted runs [bnd[r], bnd[r + 1]) of src (LDS; runs may be empty) until one
+// is left; MERGE_WG threads, 8 consecutive outputs per thread and level (merge path); the last level writes the low
+// words to out32. nruns >= 2.
+__device__ __forceinline__ void lds_merge_runs(uint64_t* src, uint64_t* dst, const int* bnd, int nruns, int m, int tid,
+                                               uint32_t* out32) {
+  const int g0 = tid * 8;
+  for (int stride = 1; stride < nruns; stride <<= 1) {
+    const bool last = 2 * stride >= nruns;
+    if (g0 < m) {
+      // the pair of runs this thread's first output lies in: the largest u with bnd[2 u stride] <= g0
+      const int npairs = (nruns + 2 * stride - 1) / (2 * stride);
+      int u = 0;
+      for (int lo = 0, hi = npairs - 1; ; ) {
+        if (lo >= hi) { u = lo; break; }
+        const int mid = (lo + hi + 1) >> 1;
+        if (bnd[2 * mid * stride] <= g0) lo = mid; else hi = mid - 1;
+      }
+      int o = 0;
+      while (o < 8 && g0 + o < m) {
+        const int l0 = bnd[2 * u * stride], l1 = bnd[min(nruns, 2 * u * stride + stride)],
+                  l2 = bnd[min(nruns, 2 * (u + 1) * stride)];
+        const uint64_t* A = src + l0;
+        const uint64_t* B = src + l1;
+        const int na = l1 - l0, nb = l2 - l1, diag = g0 + o - l0;
+        int ia = merge_split(A, na, B, nb, diag);
+        int ib = diag - ia;
+        const int cnt = min(8 - o, l2 - (g0 + o));
+        for (int c = 0; c < cnt; ++c) {
+          const bool takeA = (ib >= nb) || (ia < na && A[ia] <= B[ib]);
+          const uint64_t v = takeA ? A[ia++] : B[ib++];
+          if (last) out32[g0 + o + c] = (uint32_t)v;
+          else dst[g0 + o + c] = v;
+        }
+        o += cnt;
+        ++u;                                                  // the next pair starts where this one ends
+      }
+    }
+    __syncthreads();
+    uint64_t* t = src; src = dst; dst = t;
+  }
+}
+
+// bucket b of the list keys[0, n) (its SORT_CHUNK-key chunks sorted), MERGE_KEYS < n <= PSRS_MAX_KEYS -> out[...]
+__device__ __forceinline__ void psrs_bucket(const uint64_t* keys, uint32_t* out, int n, int b, uint64_t* s_a, uint64_t* s_b,
+                                            int tid) {
+  __shared__ int s_lo[PSRS_MAX_RUNS], s_hi[PSRS_MAX_RUNS], s_bnd[PSRS_MAX_RUNS + 1], s_first;
+  const int lane = tid & (GSR_WAVE - 1), wave = tid / GSR_WAVE;
+  const int runs = (n + SORT_CHUNK - 1) / SORT_CHUNK;
+  const int g = psrs_group(runs), S = n / g, p = (n + GSR_SORT_BUCKET - 1) / GSR_SORT_BUCKET;
+  __syncthreads();                                            // the previous item's LDS image is dead
+  for (int i = tid; i < S; i += MERGE_WG) s_a[i] = keys[(int64_t)(i + 1) * g - 1];
+  __syncthreads();
+  const uint64_t* ss = merge_sort_lds<MERGE_WG>(s_a, s_b, S, tid);
+  const uint64_t klo = b > 0 ? ss[(int64_t)b * S / p] : 0ull;
+  const uint64_t khi = b + 1 < p ? ss[(int64_t)(b + 1) * S / p] : ~0ull;
+  __syncthreads();                                            // every thread holds the splitters: the buffers are free
+  // keys of run j below each splitter: round 1 probes the last key of every group of 32 (the groups entirely below the
+  // splitter), round 2 the 32 keys of the group the splitter falls in — lanes 0..31 for klo, 32..63 for khi
+  for (int j = wave; j < runs; j += MERGE_WG / GSR_WAVE) {
+    const uint64_t* run = keys + (int64_t)j * SORT_CHUNK;
+    const int L = min(SORT_CHUNK, n - j * SORT_CHUNK);
+    const uint64_t v = lane * 32 < L ? run[min(lane * 32 + 31, L - 1)] : ~0ull;
+    const int c_lo = __popcll(__ballot(v < klo)), c_hi = __popcll(__ballot(v < khi));
+    const int pos = (lane < 32 ? c_lo : c_hi) * 32 + (lane & 31);
+    const uint64_t v2 = pos < L ? run[pos] : ~0ull;
+    const unsigned long long m2 = __ballot(v2 < (lane < 32 ? klo : khi));
+    if (lane == 0) {
+      s_lo[j] = min(L, c_lo * 32 + __popc((unsigned)m2));
+      s_hi[j] = min(L, c_hi * 32 + __popc((unsigned)(m2 >> 32)));
+    }
+  }
+  __syncthreads();
+  if (tid < GSR_WAVE) {                                       // runs <= 64: one lane per run
+    int len = tid < runs ? s_hi[tid] - s_lo[tid] : 0, first = tid < runs ? s_lo[tid] : 0;
+#pragma unroll
+    for (int off = 1; off < GSR_WAVE; off <<= 1) {
+      const int t = __shfl_up(len, off);
+      if (lane >= off) len += t;
+    }
+#pragma unroll
+    for (int off = GSR_WAVE / 2; off > 0; off >>= 1) first += __shfl_xor(first, off);
+    if (tid < runs) s_bnd[tid + 1] = len;
+    if (tid == 0) { s_bnd[0] = 0; s_first = first; }
+  }
+  __syncthreads();
+  const int m = s_bnd[runs];
+  if (m > MERGE_KEYS) __builtin_trap();                       // (excluded by psrs_group's bound)
+  for (int i = tid; i < m; i += MERGE_WG) {
+    int r = 0;                                                // the run position i of the bucket comes from
+#pragma unroll
+    for (int step = PSRS_MAX_RUNS / 2; step > 0; step >>= 1)
+      if (r + step <= runs && s_bnd[r + step] <= i) r += step;
+    s_a[i] = keys[(int64_t)r * SORT_CHUNK + s_lo[r] + (i - s_bnd[r])];
+  }
+  __syncthreads();
+  lds_merge_runs(s_a, s_b, s_bnd, runs, m, tid, out + s_first);
+}
+
 __global__ void __launch_bounds__(MERGE_WG)
 tile_merge_all_kernel(int T, int ordered, int64_t max_pairs, const uint32_t* __restrict__ tile_order,
                       const uint32_t* __restrict__ tile_offset, uint64_t* __restrict__ pair_key,
-                      uint64_t* __restrict__ pair_tmp, uint32_t* __restrict__ point_list, size_t ws_stride) {
+                      uint64_t* __restrict__ pair_tmp, uint32_t* __restrict__ point_list,
+                      const uint32_t* __restrict__ sort_work, const int32_t* __restrict__ status, size_t ws_stride) {
   extern __shared__ uint64_t s_merge[];                      // [2][MERGE_KEYS]
   GSR_FRAME_PTRS();
+  {
+    const size_t off = (size_t)blockIdx.y * ws_stride;
+    sort_work = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(sort_work) + off);
+    status = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(status) + off);
+  }
   const int tid = threadIdx.x;
+  // the long lists' output buckets first (tile_scan_kernel's work list): the launch's longest units
+  const int nwork = status[5];
+  for (int it = blockIdx.x; it < nwork; it += gridDim.x) {
+    const uint32_t w = sort_work[it];
+    const int tile = (int)(w >> 8);
+    const int64_t start = min((int64_t)tile_offset[tile], max_pairs);
+    const int n = (int)(min((int64_t)tile_offset[tile + 1], max_pairs) - start);
+    psrs_bucket(pair_key + start, point_list + start, n, (int)(w & 255u), s_merge, s_merge + MERGE_KEYS, tid);
+  }
   for (int rank = blockIdx.x; rank < T; rank += gridDim.x) {
     const TileSpan ts = tile_span(tile_order, tile_offset, max_pairs, rank);
     // one run: nothing to merge. The order is by size CLASS (1 + floor(log2 n), tile_scan_kernel): a list of exactly
     // SORT_CHUNK keys shares its class with lists that do need merging, so only a list BELOW that class ends the walk
     if (ts.n <= SORT_CHUNK) { if (ordered && ts.n < SORT_CHUNK) break; continue; }
-    __syncthreads();                                          // the previous list's LDS image is dead
     if (ts.n > MERGE_KEYS) {
+      if (ts.n <= PSRS_MAX_KEYS) continue;                    // done bucket by bucket above
+      __syncthreads();
       merge_long_list(pair_key + ts.start, pair_tmp + ts.start, point_list + ts.start, ts.n, s_merge, tid);
       continue;
     }
+    __syncthreads();                                          // the previous list's LDS image is dead
     const int n = ts.n;
     for (int i = tid; i < n; i += MERGE_WG) s_merge[i] = pair_key[ts.start + i];
     __syncthreads();
@@ -425,18 +649,22 @@ hipError_t launch_binning(const Dims& d, const Workspace& ws, const Batch& bt, h
   {
     ProfScope prof_(K_SCAN, stream);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1, bt.frames), dim3(SCAN_THREADS), 0, stream, d.T, d.max_pairs,
-                     ws.tile_count, ws.tile_offset, ws.tile_cursor, ws.status, bt.ws_stride);
+                     ws.tile_count, ws.tile_offset, ws.tile_cursor, ws.status, ws.sort_work,
+                     (int)sort_work_capacity(d.max_pairs), bt.ws_stride);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
+  trace_sync(stream, "tile_scan");
   if (d.P > 0) {
     {
       ProfScope prof_(K_SCATTER, stream);
-      hipLaunchKernelGGL(scatter_kernel, dim3((d.P + 255) / 256, bt.frames), dim3(256), 0, stream, d.P, d.gx,
-                       d.max_pairs, ws.rect, ws.depth, ws.tile_cursor, ws.pair_key, bt.ws_stride);
+      hipLaunchKernelGGL(scatter_kernel, dim3((d.P + 255) / 256, bt.frames), dim3(256), win_lds_bytes(d.T), stream, d.P, d.gx,
+                       d.max_pairs, ws.rect, ws.depth, ws.tile_cursor, ws.pair_key, bt.ws_stride,
+                       d.T < GSR_WIN_CELLS ? d.T : GSR_WIN_CELLS);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
+    trace_sync(stream, "scatter");
     {
       ProfScope prof_(K_SORT, stream);
       const int gx = min(d.T, SORT_GRID);
@@ -444,6 +672,7 @@ hipError_t launch_binning(const Dims& d, const Workspace& ws, const Batch& bt, h
       hipLaunchKernelGGL(tile_sort_chunk_kernel, dim3(gx, bt.frames, SORT_MAX_CHUNKS), dim3(CHUNK_WG), 0, stream, d.T,
                          ordered, d.max_pairs, ws.tile_count, ws.tile_offset, ws.pair_key, ws.pair_tmp, ws.point_list,
                          bt.ws_stride);
+      trace_sync(stream, "tile_sort_chunk");
       static PerDeviceFlag attr_set;
       constexpr size_t merge_lds = (size_t)2 * MERGE_KEYS * sizeof(uint64_t);
       if (!attr_set) {
@@ -453,7 +682,8 @@ hipError_t launch_binning(const Dims& d, const Workspace& ws, const Batch& bt, h
         attr_set = true;
       }
       hipLaunchKernelGGL(tile_merge_all_kernel, dim3(min(d.T, 256), bt.frames), dim3(MERGE_WG), merge_lds, stream, d.T, ordered,
-                         d.max_pairs, ws.tile_count, ws.tile_offset, ws.pair_key, ws.pair_tmp, ws.point_list, bt.ws_stride);
+                         d.max_pairs, ws.tile_count, ws.tile_offset, ws.pair_key, ws.pair_tmp, ws.point_list, ws.sort_work,
+                         ws.status, bt.ws_stride);
     }
     e = hipGetLastError();
   }

@@ -69,6 +69,13 @@ inline int seg_capacity(int T, int64_t max_pairs) {
 __host__ __device__ inline int seg_block_capacity(int64_t start, int64_t end) { return (int)((end >> 6) - (start >> 6)) + 1; }
 __host__ __device__ inline int64_t seg_first_slot(int64_t start, int tile) { return GSR_SEG_BLOCKS * ((start >> 6) + tile); }
 
+// Work items of the tile sort's long-list pass (gsr_binning.hip: lists beyond GSR_SORT_LDS_KEYS keys are cut into output
+// buckets of ~GSR_SORT_BUCKET keys): sum over such lists of ceil(n / GSR_SORT_BUCKET) <= max_pairs / GSR_SORT_BUCKET +
+// (number of such lists <= max_pairs / GSR_SORT_LDS_KEYS).
+#define GSR_SORT_LDS_KEYS 8192
+#define GSR_SORT_BUCKET 4096
+inline int64_t sort_work_capacity(int64_t max_pairs) { return 3 * (max_pairs / GSR_SORT_LDS_KEYS) + 16; }
+
 // tile_scan_kernel (gsr_binning.hip) leaves the tiles in size order (largest list class first) when a thread of its
 // one workgroup owns at most 8 tiles, i.e. T <= 8192; above that `tile_count` holds the identity order and every walk
 // over it must skip empty tiles instead of stopping at the first one.
@@ -114,6 +121,7 @@ struct Workspace {
   float4* pix_accum;
   float* pair_grad;
   uint32_t* seg_list;
+  uint32_t* sort_work;
 };
 
 // Batched launches: blockIdx.y = frame. Element strides between frames (0 = shared by all
@@ -129,7 +137,7 @@ __host__ __device__ inline Workspace frame_ws(Workspace w, size_t bytes) {
   mv(w.depth); mv(w.xy); mv(w.xyext); mv(w.conic_opacity); mv(w.rgb); mv(w.cov3d); mv(w.rect); mv(w.tiles_touched);
   mv(w.clamped); mv(w.tile_count); mv(w.tile_offset); mv(w.tile_cursor); mv(w.pair_key);
   mv(w.point_list); mv(w.pair_tmp); mv(w.final_T); mv(w.n_contrib); mv(w.grad_acc); mv(w.status); mv(w.seg_heads); mv(w.seg_count);
-  mv(w.seg_entries); mv(w.seg_ckpt); mv(w.seg_info); mv(w.pix_accum); mv(w.pair_grad); mv(w.seg_list);
+  mv(w.seg_entries); mv(w.seg_ckpt); mv(w.seg_info); mv(w.pix_accum); mv(w.pair_grad); mv(w.seg_list); mv(w.sort_work);
   return w;
 }
 
@@ -148,7 +156,91 @@ __device__ __forceinline__ float2 alpha_extent(float4 co) {
   return make_float2(hx, hy);
 }
 
-// ---- per-workgroup aggregation of (tile, Gaussian) pairs in LDS (K1 histogram, K3 scatter).
+// ---- per-workgroup aggregation of (tile, Gaussian) pairs in LDS (K1 histogram, K3 scatter), round 6.
+// The 256 Gaussians of a workgroup are UV neighbours: their tile rectangles lie in a WINDOW of the tile grid — the
+// bounding box of the rectangles — that is a few hundred cells for an avatar and at most the whole grid. The pairs of the
+// workgroup are counted per cell of that window in LDS, DIRECTLY INDEXED, as a 2-D difference array: a rectangle
+// [x0,x1) x [y0,y1) is four marks (+1 at (x0,y0), -1 at (x1,y0), -1 at (x0,y1), +1 at (x1,y1)), a 2-D prefix sum over
+// the window turns the marks into the count of rectangles covering each cell — the cost no longer depends on how many
+// tiles a Gaussian touches (rounds 1-5 walked every rectangle lane by lane through a hash table keyed by tile id:
+// 30 us at 4 tiles per Gaussian, 1.2 ms at 20: profiles/r05_dsweep.txt). Then ONE global atomic per (workgroup, cell).
+// A window larger than the LDS array (only possible with more than GSR_WIN_CELLS tiles in the frame) falls back to the
+// hash table (TileAgg below).
+#define GSR_WIN_CELLS 8192                       // 32 KiB of LDS: the whole grid of a 1920x1080 frame (120 x 68)
+struct TileWin { int x0, y0, w, h; };            // w == 0: no rectangle in the workgroup; w < 0: does not fit
+// LDS bytes of the K1 / K3 launches for a frame of T tiles (the hash table needs 12 KiB whatever T is)
+inline size_t win_lds_bytes(int T) {
+  const int cells = T < GSR_WIN_CELLS ? T : GSR_WIN_CELLS;
+  return (size_t)(cells < 3072 ? 3072 : cells) * 4;
+}
+// Bounding window of the rectangles of the workgroup's threads (`use` = this thread has one). All threads call;
+// s_box = 4 ints of LDS; ends with a workgroup barrier.
+__device__ __forceinline__ TileWin wg_tile_window(const int4& rc, bool use, int* s_box, int cells) {
+  if (threadIdx.x == 0) { s_box[0] = 0x7fffffff; s_box[1] = 0x7fffffff; s_box[2] = -1; s_box[3] = -1; }
+  int x0 = use ? rc.x : 0x7fffffff, y0 = use ? rc.y : 0x7fffffff, x1 = use ? rc.z : -1, y1 = use ? rc.w : -1;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    x0 = min(x0, __shfl_xor(x0, off)); y0 = min(y0, __shfl_xor(y0, off));
+    x1 = max(x1, __shfl_xor(x1, off)); y1 = max(y1, __shfl_xor(y1, off));
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0 && x1 >= 0) {
+    atomicMin(&s_box[0], x0); atomicMin(&s_box[1], y0); atomicMax(&s_box[2], x1); atomicMax(&s_box[3], y1);
+  }
+  __syncthreads();
+  TileWin wn;
+  wn.x0 = s_box[0]; wn.y0 = s_box[1]; wn.w = s_box[2] - s_box[0]; wn.h = s_box[3] - s_box[1];
+  if (s_box[2] < 0) { wn.x0 = wn.y0 = wn.w = wn.h = 0; }
+  else if ((int64_t)wn.w * wn.h > cells) wn.w = -1;
+  return wn;
+}
+// the four marks of one rectangle (marks on the window's right / bottom edge would only reach cells outside it)
+__device__ __forceinline__ void win_mark(int* cell, const TileWin& wn, const int4& rc) {
+  const int ax = rc.x - wn.x0, ay = rc.y - wn.y0, bx = rc.z - wn.x0, by = rc.w - wn.y0;
+  atomicAdd(&cell[ay * wn.w + ax], 1);
+  if (bx < wn.w) atomicAdd(&cell[ay * wn.w + bx], -1);
+  if (by < wn.h) {
+    atomicAdd(&cell[by * wn.w + ax], -1);
+    if (bx < wn.w) atomicAdd(&cell[by * wn.w + bx], 1);
+  }
+}
+// 2-D inclusive prefix sum over the window (marks -> rectangles covering each cell). All threads call; the marks must be
+// visible (barrier before); ends with a barrier. Rows: one wave per row, 64 columns per step (consecutive addresses);
+// columns: one thread per column (consecutive threads = consecutive banks), four rows in flight.
+__device__ __forceinline__ void win_prefix(int* cell, const TileWin& wn) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int r = wave; r < wn.h; r += nw) {
+    int carry = 0;
+    for (int c0 = 0; c0 < wn.w; c0 += 64) {
+      const int c = c0 + lane;
+      int v = c < wn.w ? cell[r * wn.w + c] : 0;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+      }
+      v += carry;
+      if (c < wn.w) cell[r * wn.w + c] = v;
+      carry = __shfl(v, 63);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < wn.w; c += blockDim.x) {
+    int run = 0, r = 0;
+    for (; r + 4 <= wn.h; r += 4) {
+      const int a0 = cell[r * wn.w + c], a1 = cell[(r + 1) * wn.w + c], a2 = cell[(r + 2) * wn.w + c],
+                a3 = cell[(r + 3) * wn.w + c];
+      run += a0; cell[r * wn.w + c] = run;
+      run += a1; cell[(r + 1) * wn.w + c] = run;
+      run += a2; cell[(r + 2) * wn.w + c] = run;
+      run += a3; cell[(r + 3) * wn.w + c] = run;
+    }
+    for (; r < wn.h; ++r) { run += cell[r * wn.w + c]; cell[r * wn.w + c] = run; }
+  }
+  __syncthreads();
+}
+
+// ---- the fallback for windows beyond GSR_WIN_CELLS cells (rounds 1-5's path): a hash table keyed by tile id.
 // The 256 Gaussians of a workgroup are UV neighbours and hit a few dozen distinct tiles. A serial chain
 // of wave-aggregated global atomics paid one memory round trip per distinct tile and rect step
 // (scatter: 24-30 us per 200k-Gaussian frame, 146 us at 300k / 1080p); here the pairs are first counted
@@ -214,6 +306,7 @@ __device__ __forceinline__ void for_big_rects(const int4& rc, int gx, G bcast, F
 int compute_layout(int P, int W, int H, int64_t max_pairs, GsrLayout* out);
 Workspace resolve(void* base, const GsrLayout& L);
 void set_error(const char* fmt, ...);
+void trace_sync(hipStream_t stream, const char* what);      // gsr_set_trace: announce + wait (development)
 
 // Kernel launchers (each returns a hipError_t from the launch).
 hipError_t launch_preprocess(const GsrSettings& s, const Dims& d, const float* means3D,

@@ -76,11 +76,11 @@ preprocess_kernel(int P, int W, int H, int gx, int gy, float tanfovx, float tanf
                   const float* __restrict__ colors, const float* __restrict__ opacities,
                   const float* __restrict__ scales, const float* __restrict__ rotations,
                   const float* __restrict__ cov3D_precomp, Workspace ws,
-                  int32_t* __restrict__ radii, Batch bt) {
-  __shared__ TileAgg s_agg;
+                  int32_t* __restrict__ radii, Batch bt, int win_cells) {
+  extern __shared__ int s_dyn[];    // the workgroup's tile window (gsr_common.h), or the fallback's hash table
+  __shared__ int s_box[4];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool in_range = i < P;      // (every thread stays for the workgroup's histogram)
-  agg_clear(s_agg);
   {   // batched launch: select this frame's inputs, workspace and outputs
     const int64_t f = blockIdx.y;
     view += f * bt.view; proj += f * bt.proj; means3D += f * bt.means;
@@ -181,8 +181,28 @@ preprocess_kernel(int P, int W, int H, int gx, int gy, float tanfovx, float tanf
     ws.rect[i] = rc;
     ws.tiles_touched[i] = ntiles;
   }
-  // per-tile histogram of pairs (consumed by K2/K3): counted in the workgroup's LDS table first
-  // (gsr_common.h: TileAgg), then one global atomic per (workgroup, tile)
+  // per-tile histogram of pairs (consumed by K2/K3): the workgroup's rectangles as a 2-D difference array over their
+  // bounding window in LDS, one prefix sum, then one global atomic per (workgroup, tile) (gsr_common.h: TileWin)
+  const bool has_rect = (rc.z - rc.x) * (rc.w - rc.y) > 0;
+  const TileWin wn = wg_tile_window(rc, has_rect, s_box, win_cells);
+  if (wn.w == 0) return;                                    // nothing of this workgroup is rendered
+  if (wn.w > 0) {
+    const int ncell = wn.w * wn.h;
+    for (int e = threadIdx.x; e < ncell; e += blockDim.x) s_dyn[e] = 0;
+    __syncthreads();
+    if (has_rect) win_mark(s_dyn, wn, rc);
+    __syncthreads();
+    win_prefix(s_dyn, wn);
+    for (int e = threadIdx.x; e < ncell; e += blockDim.x) {
+      const int c = s_dyn[e];
+      if (c > 0) atomicAdd(&ws.tile_count[(wn.y0 + e / wn.w) * gx + wn.x0 + e % wn.w], (uint32_t)c);
+    }
+    return;
+  }
+  // the window does not fit (more than GSR_WIN_CELLS tiles in the frame): hash table keyed by tile id, a lane walks
+  // its own rectangle (rectangles above GSR_BIG_RECT tiles: the whole wave, direct atomics)
+  TileAgg& s_agg = *reinterpret_cast<TileAgg*>(s_dyn);
+  agg_clear(s_agg);
   __syncthreads();
   if (!rect_is_big(rc))
     for (int cy = rc.y; cy < rc.w; ++cy)
@@ -396,10 +416,10 @@ hipError_t launch_preprocess(const GsrSettings& s, const Dims& d, const float* m
   const int grid = (d.P + block - 1) / block;
   {
     ProfScope prof_(K_PREPROCESS, stream);
-    hipLaunchKernelGGL(preprocess_kernel, dim3(grid, bt.frames), dim3(block), 0, stream, d.P, d.W, d.H, d.gx,
-                     d.gy, s.tanfovx, s.tanfovy, s.scale_modifier, s.viewmatrix, s.projmatrix,
+    hipLaunchKernelGGL(preprocess_kernel, dim3(grid, bt.frames), dim3(block), win_lds_bytes(d.T), stream, d.P, d.W, d.H,
+                     d.gx, d.gy, s.tanfovx, s.tanfovy, s.scale_modifier, s.viewmatrix, s.projmatrix,
                      means3D, colors_precomp, opacities, scales, rotations, cov3D_precomp, ws,
-                     radii, bt);
+                     radii, bt, d.T < GSR_WIN_CELLS ? d.T : GSR_WIN_CELLS);
   }
   return hipGetLastError();
 }

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 5
+#define GSR_ABI_VERSION 6
 #define GSR_TILE 16              /* tile edge in pixels (BLOCK_X = BLOCK_Y = 16)       */
 #define GSR_NUM_CHANNELS 3
 
@@ -97,7 +97,8 @@ typedef struct GsrLayout {
   uint64_t grad_acc;       /* float   [P,16] (dxy2, dconic3, dopac1, drgb3, pad7): one 64-byte line each */
   /* status words */
   uint64_t status;         /* int32   [8]  [0]=pairs needed (D) [1]=overflow flag (pair buffer)
-                                           [2]=unused  [3]=max pairs in one tile              */
+                                           [2]=unused  [3]=max pairs in one tile
+                                           [5]=long-list sort buckets (sort_work items)       */
   uint64_t seg_heads;      /* int32   [8,64] word 0 of row x = recorded segments of XCD class x (entries of
                                            seg_list[x]); one 256-byte line per counter         */
   uint64_t seg_count;      /* uint32  [T,B]  segments the forward pass recorded per (tile, render block); B = 16 blocks of 4x4 pixels */
@@ -121,6 +122,10 @@ typedef struct GsrLayout {
    *   [0, total_bytes)   + pair_grad, the per-pair records of the deterministic backward (settings.debug) */
   uint64_t eval_bytes;
   uint64_t train_bytes;
+  /* ABI 6: work list of the tile sort for lists beyond 8192 keys — one item (tile << 8 | bucket) per ~4096-key output
+   * bucket of such a list, written by the tile scan, consumed by the merge launch; 3 max_pairs / 8192 + 16 entries
+   * (inside the eval region). status[5] = items of the frame. */
+  uint64_t sort_work;      /* uint32  [3 cap / 8192 + 16] */
 } GsrLayout;
 
 /* workspace modes (gsr_workspace_bytes_for): per (tile, Gaussian) pair of capacity a forward-only workspace holds
@@ -301,6 +306,10 @@ int gsr_render_block_edge(void);
 
 /* Text of the last error raised on the calling thread ("" if none). */
 const char* gsr_last_error(void);
+
+/* Development aid (ABI 6): with on != 0 every stage of every call announces itself on stderr and is waited for, so that
+ * a device fault can be attributed to a kernel. Process-wide; off by default. */
+void gsr_set_trace(int on);
 
 /* ABI version of the loaded library (== GSR_ABI_VERSION of the header it was built from). */
 int gsr_abi_version(void);

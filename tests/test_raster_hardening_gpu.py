@@ -412,3 +412,76 @@ def test_dense_scenes_with_hundreds_of_multi_chunk_lists(raster_oracle, seed, P,
     ref, got = assert_forward_parity(raster_oracle, sc)
     ln = ref["ranges"][:, 1].astype(np.int64) - ref["ranges"][:, 0].astype(np.int64)
     assert (ln > 2048).sum() > 100 and (ln > 8192).sum() > 50
+
+
+def test_list_lengths_around_the_bucket_sort(raster_oracle):
+    """Round 6: lists beyond 8192 keys are sorted as independent ~4096-key output buckets (gsr_binning.hip: psrs_bucket — regular
+    samples of the list's sorted 2048-key chunks, splitters, per-chunk searches, multi-run LDS merge), lists beyond 64 chunks
+    (131072 keys) keep the one-workgroup merge through HBM. Every length at which that path changes its decomposition — the
+    number of chunks (5, 6, 8, 9, 20, 32, 33, 63, 64), the sample spacing (512 .. 32), a one-key last chunk, the hand-over
+    to the fallback at 131073 — with lists, ranges and image against the oracle as everywhere."""
+    sizes = [8193, 10241, 12288, 16384, 16385, 40000, 65536, 65537, 129000, 131072, 131073, 150000]
+    sc = _scene_with_tile_lists(128, 128, dict(zip([9, 11, 13, 18, 20, 22, 25, 27, 29, 34, 36, 38], sizes)), seed=29)
+    ref, got = assert_forward_parity(raster_oracle, sc)
+    lens = np.sort(ref["ranges"][:, 1].astype(np.int64) - ref["ranges"][:, 0].astype(np.int64))[-len(sizes):]
+    assert lens.tolist() == sorted(sizes), lens
+    assert got["status"][5] == sum((n + 4095) // 4096 for n in sizes if 8192 < n <= 131072)     # the work list's items
+
+
+@pytest.mark.parametrize("P,W,H,scale,frac", [(3000, 128, 128, 0.03, 0.5), (20000, 256, 256, 0.08, 0.05),
+                                              (200000, 512, 512, 0.1, 0.01), (400000, 256, 256, 0.05, 0.03)])
+def test_heavy_overflow_leaves_valid_sorted_lists(raster_oracle, P, W, H, scale, frac):
+    """A forward pass whose pair buffer holds only a fraction of the pairs (a stale capacity history when the scene suddenly
+    grows: the first iterations of a from-scratch training after a smaller run, found in round 6 as a device fault in
+    render_fwd) must still leave every list it kept sorted and made of valid indices: the tiles in front of the cut-off
+    bit-identical to the oracle's lists, the tile the cut-off falls in a sorted subset of the oracle's list, every tile behind
+    it empty for the later kernels — and forward + backward must run through (zero gradients, flag raised)."""
+    import torch
+    from gaussianavatar_amd import rasterizer as R
+    from gaussianavatar_amd.rasterizer import GaussianRasterizer
+    from tests.hip_helpers import hip_forward_state, scene_tensors, settings_from_scene
+    sc = random_scene(P, W, H, seed=5, kind="avatar", scale_med=scale)
+    ref = oracle_forward(raster_oracle, sc)
+    cap = int(ref["D"] * frac)
+    got = hip_forward_state(sc, max_pairs=cap)
+    assert got["status"][1] == 1 and got["status"][0] == ref["D"]
+    off = got["tile_offset"].astype(np.int64)
+    np.testing.assert_array_equal(off[:-1].astype(np.uint32), ref["ranges"][:, 0])
+    depth_bits = got["depth"].view(np.uint32).astype(np.uint64)
+    whole = 0
+    for t in range(len(off) - 1):
+        s, e = min(off[t], cap), min(off[t + 1], cap)
+        if e <= s:
+            continue
+        mine = got["point_list"][s:e].astype(np.int64)
+        assert mine.min() >= 0 and mine.max() < P
+        full = ref["point_list"][off[t]:off[t + 1]].astype(np.int64)
+        if off[t + 1] <= cap:
+            np.testing.assert_array_equal(mine, full)
+            whole += 1
+        else:                                                # the cut-off tile: some subset of its pairs, in key order
+            keys = (depth_bits[mine] << np.uint64(32)) | mine.astype(np.uint64)
+            assert (np.diff(keys.astype(np.float64)) >= 0).all() and len(np.unique(mine)) == len(mine)
+            assert np.isin(mine, full).all()
+    assert whole >= 1
+    # the steady-state path (history says the buffer is large enough): forward + backward without a host check
+    key = (P, W, H)
+    saved = (R._capacity.pairs_per_gaussian, R._capacity.floor, dict(R._capacity.seen))
+    try:
+        R._capacity.pairs_per_gaussian, R._capacity.floor = 0, max(64, cap // 2)
+        R._capacity.seen[key] = 10
+        R._capacity.stamp[key] = __import__("time").monotonic()
+        rs = settings_from_scene(sc)
+        t = scene_tensors(sc, requires_grad=True)
+        with pytest.warns(UserWarning, match="pair buffer overflow"):     # (raised by whichever poll sees it first)
+            color, _ = GaussianRasterizer(rs)(means3D=t["means3D"], means2D=None, opacities=t["opacities"],
+                                              colors_precomp=t["colors"], scales=t["scales"], rotations=t["rotations"])
+            color.sum().backward()
+            torch.cuda.synchronize()
+            assert float(t["means3D"].grad.abs().max()) == 0.0 and int(R.overflow_flag("cuda")) == 1
+            R.check_overflow(block=True)
+    finally:
+        R._capacity.pairs_per_gaussian, R._capacity.floor = saved[0], saved[1]
+        R._capacity.seen = saved[2]
+        R._capacity.pending.clear()
+        R.clear_overflow_flag()
