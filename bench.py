@@ -618,8 +618,10 @@ def main():
     for i in range(args.warmup - probe):
         step(i)
     probe_r, probe_n = {}, {}
+    probe_pairs = 0.0
     if probe:
         rasterizer.check_overflow(block=True)
+        rasterizer.pair_statistics(reset=True)
         rasterizer.profile_enable(True)
         fused.profile_enable(True)
         rasterizer.profile_read(reset=True)
@@ -636,6 +638,9 @@ def main():
         parallel.timing_enable(False)
         pev[1].synchronize()
         probe_ms = pev[0].elapsed_time(pev[1]) / probe
+        # the scene of the instrumented steps (with --iteration far from 7 the model is still shrinking its Gaussians
+        # during the warm-up: the per-kernel table belongs to THIS pair count, not to the timed region's)
+        _pn, probe_pairs = rasterizer.pair_statistics(reset=True)
         rasterizer.profile_enable(False)
         fused.profile_enable(False)
     rasterizer.check_overflow(block=True)
@@ -735,7 +740,8 @@ def main():
                   "the launches); 2*FETCH+WRITE (gfx950 wide-read correction)")
     if probe:
         # one launch of every rasterizer kernel processes all B frames of the rank's batch
-        alg = {k: v * B for k, v in algorithmic_bytes(N, mean_pairs, H * W).items()}
+        # (priced at the pair count of the steps the events come from)
+        alg = {k: v * B for k, v in algorithmic_bytes(N, probe_pairs or mean_pairs, H * W).items()}
         stage_of = {"preprocess": "preprocess", "tile_scan": "binning", "scatter": "binning", "tile_sort": "binning",
                     "render_fwd": "render_fwd", "render_bwd": "render_bwd", "preprocess_bwd": "preprocess_bwd"}
 
@@ -871,7 +877,7 @@ def main():
         out["kernels"] = {
             "measured": f"HIP events around every launch during the last {probe} warm-up steps (instrumenting all "
                         f"~100 launches costs ~1.4 ms/iteration, so the timed steps only carry the dominant family's)",
-            "per_kernel": kern, "raster_per_stage": table, "raster_fwd_us": fwd_us, "raster_bwd_us": bwd_us,
+            "probe_pairs_per_frame": probe_pairs, "per_kernel": kern, "raster_per_stage": table, "raster_fwd_us": fwd_us, "raster_bwd_us": bwd_us,
             "raster_bwd_frac_of_8TBps": (alg["render_bwd"] + alg["preprocess_bwd"]) / (bwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS if bwd_us else None}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N, B)

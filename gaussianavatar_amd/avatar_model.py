@@ -447,23 +447,46 @@ class AvatarModel:
             parallel.allreduce_param_grads(list(self.net.parameters()) + [self.geo_feature], average=False)
         parallel.wait_overflow_flag()     # every rank skips the step if any rank dropped a frame's gradient
         pose_on = self._pose_opt_active(epoch)
-        keep = None
+        dropped = None
         if pose_on and self.device.type == "cuda":
-            # the pose optimiser drops an overflowed iteration too (its rasterizer gradients are zeros: a SparseAdam step
-            # would apply momentum alone, and real updates for the frames that did not overflow): read the flag before
-            # optim.Adam lowers it
+            # the pose optimiser must drop an overflowed iteration too: read the flag before optim.Adam lowers it
             from . import rasterizer
-            keep = 1.0 - rasterizer.overflow_flag(self.device).float()
+            dropped = rasterizer.overflow_flag(self.device).clone()
         self.optimizer.step()
+        if dropped is not None and not getattr(self.optimizer, "skip_on_overflow", False):
+            from . import rasterizer
+            rasterizer.clear_overflow_flag(self.device)      # (a main optimiser that does not lower the flag itself)
         self.scheduler.step()
         if pose_on:
             parallel.allgather_sparse_grads([self.pose.weight, self.transl.weight])
-            if keep is not None:
-                for p in (self.pose.weight, self.transl.weight):
-                    if p.grad is not None and p.grad.is_sparse:
-                        p.grad = p.grad.coalesce()
-                        p.grad._values().mul_(keep)
-            self.optimizer_pose.step()
+            self._pose_step(dropped)
+
+    def _pose_step(self, dropped):
+        """SparseAdam on the pose / translation rows of the batch — undone, row by row and without a host sync, when the
+        iteration overflowed (`dropped` = the device flag, 1 = drop): a SparseAdam step on zero gradients would still
+        decay both moments and apply a momentum-only update, so the rows the step touched — parameter and
+        both moments — are put back with a device-side select. (What is not undone is SparseAdam's host-side `step`
+        counter: the bias corrections of later steps run one step ahead, as in optim.Adam.)"""
+        opt = self.optimizer_pose
+        saved = []
+        if dropped is not None:
+            for p in (self.pose.weight, self.transl.weight):
+                if p.grad is None or not p.grad.is_sparse:
+                    continue
+                p.grad = p.grad.coalesce()
+                rows = p.grad._indices()[0]
+                st = opt.state.get(p, {})
+                saved.append((p, rows, p.data[rows].clone(),
+                              {k: (st[k][rows].clone() if k in st else None) for k in ("exp_avg", "exp_avg_sq")}))
+        opt.step()
+        if saved:
+            drop = dropped.bool()
+            for p, rows, old, moments in saved:
+                p.data[rows] = torch.where(drop, old, p.data[rows])
+                st = opt.state.get(p, {})
+                for k, m in moments.items():
+                    if k in st:
+                        st[k][rows] = torch.where(drop, m if m is not None else torch.zeros_like(st[k][rows]), st[k][rows])
 
     # ------------------------------------------------------------------ the hot path
     def _body(self, pose, transl, rest_pose):

@@ -828,7 +828,7 @@ size_t ganet_unet_fwd_workspace(const GanetUnetParams* p, int32_t B) {
 int ganet_unet_fwd(const GanetUnetParams* p, int32_t B, const float* x, int32_t training, float* saved, float* out,
                    void* workspace, size_t workspace_bytes, void* stream_) {
   if (!unet_ok(p, B) || !x || !saved || !out || !workspace) {
-    set_error("ganet_unet_fwd: invalid arguments (nf and cout multiples of 32, S a multiple of 32, cin <= 8)");
+    set_error("ganet_unet_fwd: invalid arguments (nf and cout multiples of 32, S a power of two >= 32, cin <= 8)");
     return 1;
   }
   if (workspace_bytes < ganet_unet_fwd_workspace(p, B)) { set_error("ganet_unet_fwd: workspace too small"); return 2; }

@@ -542,10 +542,11 @@ def _decoder_modules(dec):
     decoder object: nn.Module.__getattr__ walks _parameters / _buffers / _modules on every access, and the hot path asked
     for these ~130 times per iteration (65 us in decoder_supported, 45 us in the parameter list: tools/prof_enqueue.py)."""
     cached = _module_cache.get(dec)
-    if cached is None:
+    sig = tuple(map(id, dec._modules.values()))          # a replaced submodule (dec.bn3 = ...) invalidates the entry
+    if cached is None or cached[2] != sig:
         pairs = [(getattr(dec, c), getattr(dec, b)) for c, b in _decoder_bn_layers()]
         outs = [getattr(dec, f"conv8{t}") for t in _HEAD_TAGS]
-        cached = _module_cache[dec] = (pairs, outs)
+        cached = _module_cache[dec] = (pairs, outs, sig)
     return cached
 
 
@@ -652,8 +653,12 @@ def _native_decoder_params(dec, params, nl):
     is rebuilt only when a tensor moved: the optimiser updates parameters in place, so an iteration re-uses the previous
     one's (75 us per build, twice per iteration)."""
     bns = [bn for _, bn in _decoder_modules(dec)[0]]
+    # everything the struct points at or copies: parameters, the three BatchNorm buffers, eps / momentum (ADVICE r05: a
+    # reassigned running_var / num_batches_tracked or a changed momentum must rebuild it)
     key = tuple([p.data_ptr() for p in params] +
-                [bn.running_mean.data_ptr() if bn.track_running_stats else 0 for bn in bns])
+                [v for bn in bns for v in ((bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                            bn.num_batches_tracked.data_ptr()) if bn.track_running_stats else (0, 0, 0))] +
+                [v for bn in bns for v in (float(bn.eps), float(bn.momentum))])
     cached = _params_cache.get(dec)
     if cached is not None and cached[0] == key:
         return cached[1], cached[2]
@@ -678,6 +683,7 @@ def _build_decoder_params(dec, params, nl):
         if bn.track_running_stats:
             P.running_mean[i], P.running_var[i] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
             P.num_batches_tracked[i] = bn.num_batches_tracked.data_ptr()
+            keep += [bn.running_mean, bn.running_var, bn.num_batches_tracked]
         P.eps[i], P.momentum[i] = float(bn.eps), float(bn.momentum)
     for j in range(3):
         w, b = params[4 * nl + 2 * j], params[4 * nl + 2 * j + 1]
@@ -1221,7 +1227,7 @@ def decoder_mlp(dec, x, m_global=None):
 
 
 def _decoder_param_list(dec):
-    pairs, outs = _decoder_modules(dec)
+    pairs, outs, _sig = _decoder_modules(dec)
     params = []
     for c, b in pairs:
         params += [c.weight, c.bias, b.weight, b.bias]
@@ -1237,8 +1243,13 @@ _NATIVE_UNET = _dev.knobs.native_unet
 
 
 def unet_supported(net, x) -> bool:
-    """net: network.UnetNoCond5DS; x [B, cin, S, S]."""
+    """net: network.UnetNoCond5DS; x [B, cin, S, S]. Mirrors `unet_ok` of csrc/ganet_unet.hip (S a power of two >= 32,
+    B > 0, cin <= 8, nf and cout multiples of 32); the native kernels produce no input gradient, so an input that
+    requires one takes the torch path."""
     if not (_NATIVE_UNET and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[2] == x.shape[3]):
+        return False
+    S = int(x.shape[2])
+    if x.shape[0] < 1 or S < 32 or (S & (S - 1)) or (x.requires_grad and torch.is_grad_enabled()):
         return False
     ups = [getattr(net, f"upconv{k}") for k in range(1, 6)]
     if not all(isinstance(u.up, torch.nn.ConvTranspose2d) and not u.use_dropout for u in ups):
@@ -1247,7 +1258,7 @@ def unet_supported(net, x) -> bool:
     bns = [getattr(net, n).bn for n in _UNET_BN]
     plain = all(type(b) is torch.nn.BatchNorm2d and not b.affine and b.momentum is not None and b.track_running_stats
                 and b.training == net.training for b in bns)
-    return (plain and nf % 32 == 0 and cout % 32 == 0 and x.shape[2] % 32 == 0 and x.shape[1] <= 8
+    return (plain and nf % 32 == 0 and cout % 32 == 0 and x.shape[1] <= 8
             and net.conv1.conv.in_channels == x.shape[1] and net.upconv5.up.bias is not None
             and (net.training or not torch.is_grad_enabled()))
 

@@ -12,7 +12,8 @@ Overflow safety (no host sync): the rasterizer's backward pass raises a device-s
 overflowed its pair buffer — that frame's gradients are zeros (rasterizer.overflow_flag). `step()` hands the flag
 to the kernel, which then changes nothing: a step computed from truncated tile lists is never applied — and lowers the
 flag again behind its last launch (stream-ordered), so the flag describes ONE step whatever the caller's loop does in
-between (module.zero_grad(), `p.grad = None`, two steps per zero_grad: ADVICE r04). (A skipped step still advances the `step` counter of the bias
+between (module.zero_grad(), `p.grad = None`, two steps per zero_grad: ADVICE r04); `zero_grad()` lowers it as well, so a
+backward pass that is never followed by a step cannot make the next valid step skip itself. (A skipped step still advances the `step` counter of the bias
 corrections; at the reference's betas that shifts the step size of the following updates by < 1e-3 relative after
 a few hundred steps.)
 """
@@ -40,6 +41,18 @@ class Adam(torch.optim.Adam):
             return None
         from . import rasterizer
         return rasterizer.overflow_flag(device).data_ptr()
+
+    def zero_grad(self, set_to_none: bool = True):
+        """Also lowers the overflow flag: a backward pass that was never followed by a step (a gradient probe, an
+        exception between backward and step) must not make the NEXT step skip itself."""
+        super().zero_grad(set_to_none=set_to_none)
+        if self.skip_on_overflow:
+            for group in self.param_groups:
+                for p in group["params"]:
+                    if p.is_cuda:
+                        _native.ganet_check(_native.ganet().ganet_flag_clear(self._skip_flag(p.device),
+                                                                             _native.raw_stream(p.device)))
+                        return
 
     def _group_step(self, group) -> int:
         """Advance the group's step counter: one shared CPU tensor referenced from every parameter's

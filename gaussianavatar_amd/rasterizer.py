@@ -200,7 +200,8 @@ _overflow_flags = {}
 def overflow_flag(device) -> torch.Tensor:
     """The device-side int32[1] flag of `device` that a backward pass raises when its forward pass had overflowed
     (that frame's gradients are zeros, include/gsr.h: gsr_backward). `optim.Adam.step` skips its update while the
-    flag is set; `clear_overflow_flag` (called by AvatarModel.zero_grad / optim.Adam.zero_grad) starts a new step."""
+    flag is set and lowers it behind itself; `optim.Adam.zero_grad` (hence AvatarModel.zero_grad) lowers it too, so the
+    flag always describes the backward passes since the last zero_grad / step."""
     device = torch.device(device)
     idx = device.index if device.index is not None else torch.cuda.current_device()
     f = _overflow_flags.get(idx)
@@ -210,7 +211,7 @@ def overflow_flag(device) -> torch.Tensor:
 
 
 def clear_overflow_flag(device=None) -> None:
-    """Start a new optimisation step: lower the flag(s) a previous step's overflow raised (one 4-byte fill)."""
+    """Lower the flag(s) by hand (one 4-byte fill) — loops that use neither optim.Adam.step nor its zero_grad."""
     for idx, f in _overflow_flags.items():
         if device is None or torch.device(device).index in (None, idx):
             f.zero_()

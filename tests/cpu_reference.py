@@ -105,12 +105,16 @@ def forward(model, snap, batch, iteration, oracle, stage=1, free=False):
     rots = model.fix_rotation.cpu()
     opac = model.fix_opacity.cpu()
     bg = model.background.cpu().numpy()
-    images = []
+    images, raster_inputs = [], []
     for b in range(B):
         cam = camera_kwargs(batch, b)
         cam["bg"] = bg
         images.append(OracleRaster.apply(full[b], cols[b], scales[b], rots, opac, cam, oracle))
+        # what the rasterizer saw, for callers that re-render with the float64 oracle (coin-toss counts)
+        raster_inputs.append((full[b].detach().numpy(), cols[b].detach().numpy(), opac.detach().numpy().reshape(-1),
+                              scales[b].detach().numpy(), rots.detach().numpy(), cam))
     out["image"] = torch.stack(images)
+    out["raster_inputs"] = raster_inputs
     return out
 
 

@@ -217,3 +217,61 @@ def test_train_eval_loops_on_disk_dataset(tmp_path):
     assert res["novel_pose_shape"] == [3, 1024, 1024]
     assert res["loss_last"] < 0.3 * res["loss_first"], res
     assert res["psnr_test"] > res["psnr_untrained"] + 6.0, res
+
+
+def test_an_overflowed_iteration_changes_neither_the_net_nor_the_pose_rows():
+    """An iteration whose forward pass overflowed its pair buffer yields zero rasterizer gradients and a raised device flag;
+    `AvatarModel.step` must then leave EVERYTHING as it was: the net / geometry features (optim.Adam reads the flag) and the
+    pose / translation rows of the batch with their SparseAdam moments (a SparseAdam step on the zero gradients
+    would still decay the moments and apply a momentum-only update — `_pose_step` puts the rows back). The next, valid
+    iteration moves all of them again."""
+    import time
+    from gaussianavatar_amd import rasterizer as R
+    from gaussianavatar_amd.avatar_model import collate_frames
+    from gaussianavatar_amd.losses import l1_loss_w
+    m, mp, npar, op = _small_model()
+    epoch = op.pose_op_start_iter + 1                      # pose optimisation active
+    batch = collate_frames([m.train_dataset[i] for i in range(2)], "cuda")
+    gt = torch.full((2, 3, 96, 96), 0.4, device="cuda")
+
+    def iteration():
+        image, *_ = m.train_stage1(batch, 40)
+        loss = l1_loss_w(image, gt)
+        m.zero_grad(epoch)
+        loss.backward()
+        m.step(epoch)
+
+    def state():
+        sp = m.optimizer_pose.state
+        out = [p.detach().clone() for p in m.net.parameters()] + [m.geo_feature.detach().clone(),
+                                                                  m.pose.weight.detach().clone(), m.transl.weight.detach().clone()]
+        for p in (m.pose.weight, m.transl.weight):
+            out += [sp[p][k].clone() for k in ("exp_avg", "exp_avg_sq") if p in sp and k in sp[p]]
+        return out
+
+    iteration(); iteration()                               # moments exist, capacity history exists
+    R.check_overflow(block=True)
+    key = (m.query_points.shape[1], 96, 96)
+    saved = (R._capacity.pairs_per_gaussian, R._capacity.floor, dict(R._capacity.seen))
+    try:
+        R._capacity.pairs_per_gaussian, R._capacity.floor = 0, 64
+        R._capacity.seen[key] = 10                         # stale history: the buffer is far too small, nobody checks
+        R._capacity.stamp[key] = time.monotonic()
+        before = state()
+        with pytest.warns(UserWarning, match="pair buffer overflow"):
+            iteration()
+            R.check_overflow(block=True)
+        after = state()
+        assert len(before) == len(after)
+        for a, b in zip(before, after):
+            assert torch.equal(a, b)
+        assert int(R.overflow_flag("cuda")) == 0
+        iteration()                                        # the capacity has adapted: a valid step
+        R.check_overflow(block=True)
+        moved = state()
+        assert not torch.equal(before[0], moved[0]) and not torch.equal(before[-3], moved[-3])
+    finally:
+        R._capacity.pairs_per_gaussian, R._capacity.floor = saved[0], saved[1]
+        R._capacity.seen = saved[2]
+        R._capacity.pending.clear()
+        R.clear_overflow_flag()

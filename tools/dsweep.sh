@@ -13,6 +13,6 @@ for l in sys.stdin:
     d=json.loads(l)
     k=d['kernels']['per_kernel']
     ras={n:round(k[n]['us_per_iter']) for n in ('preprocess','tile_scan','scatter','tile_sort','render_fwd','render_bwd','preprocess_bwd') if n in k}
-    print('iteration $it it/s %.1f pairs/frame %s %s' % (d['value'], d['config'].get('mean_tile_pairs_per_frame'), ras))
+    print('iteration $it it/s %.1f pairs/frame timed %.0f, in the instrumented steps %.0f: %s' % (d['value'], d['config'].get('mean_tile_pairs_per_frame'), d['kernels'].get('probe_pairs_per_frame') or 0, ras))
 "
 done

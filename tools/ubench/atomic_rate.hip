@@ -22,15 +22,21 @@
 
 constexpr int NCOMP = 9, STRIDE = 16, WAVES = 4;
 
-template <int MODE, bool LOADS>
+// XCD = true (round 6): the segments of a "tile" (32 consecutive segments = one 1,024-record neighbourhood) are all taken
+// by workgroups of ONE XCD class (blockIdx.x % 8 == tile % 8), so a record is only ever updated from one XCD — does the
+// atomic rate depend on who else touches the line?
+template <int MODE, bool LOADS, bool XCD = false>
 __global__ void __launch_bounds__(256) k(int S, const uint32_t* __restrict__ idx, float* __restrict__ grad,
                                          const float4* __restrict__ stream, size_t stream_n, float* __restrict__ sink) {
   __shared__ float s_g[WAVES][64 * NCOMP];
   __shared__ uint32_t s_gi[WAVES][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nw = gridDim.x * WAVES;
+  const int nw = XCD ? (gridDim.x / 8) * WAVES : gridDim.x * WAVES;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int s = blockIdx.x * WAVES + wave; s < S; s += nw) {
+  const int first = XCD ? (blockIdx.x / 8) * WAVES + wave : blockIdx.x * WAVES + wave;
+  for (int i = first; i < (XCD ? S / 8 : S); i += nw) {
+    const int s = XCD ? ((i / 32) * 8 + (int)(blockIdx.x % 8)) * 32 + i % 32 : i;
+    if (s >= S) continue;
     const uint32_t gi = idx[(size_t)s * 64 + lane];
     if (LOADS) {
 #pragma unroll
@@ -65,13 +71,13 @@ __global__ void __launch_bounds__(256) k(int S, const uint32_t* __restrict__ idx
   if (LOADS && acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[0] = acc.x;
 }
 
-template <int MODE, bool LOADS>
+template <int MODE, bool LOADS, bool XCD = false>
 int run(const char* name, int S, const uint32_t* idx, float* grad, const float4* stream, size_t stream_n, float* sink, int blocks) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k<MODE, LOADS>), dim3(blocks), dim3(256), 0, 0, S, idx, grad, stream, stream_n, sink);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k<MODE, LOADS, XCD>), dim3(blocks), dim3(256), 0, 0, S, idx, grad, stream, stream_n, sink);
   CK(hipEventRecord(e0));
   const int reps = 20;
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k<MODE, LOADS>), dim3(blocks), dim3(256), 0, 0, S, idx, grad, stream, stream_n, sink);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k<MODE, LOADS, XCD>), dim3(blocks), dim3(256), 0, 0, S, idx, grad, stream, stream_n, sink);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   const double us = ms * 1e3 / reps, recs = (double)S * 64;
@@ -108,6 +114,8 @@ int main() {
       const char* nm = m ? "random" : "tile";
       char buf[64];
       snprintf(buf, sizeof buf, "flat9 atomics, %s", nm); if (run<0, false>(buf, S, ix, grad, stream, stream_n, sink, blocks)) return 1;
+      if (!m) { snprintf(buf, sizeof buf, "flat9 atomics, tile, one XCD each"); if (run<0, false, true>(buf, S, ix, grad, stream, stream_n, sink, blocks)) return 1; }
+      if (!m) { snprintf(buf, sizeof buf, "flat9 stores, tile, one XCD each"); if (run<2, false, true>(buf, S, ix, grad, stream, stream_n, sink, blocks)) return 1; }
       snprintf(buf, sizeof buf, "lane9 atomics, %s", nm); if (run<1, false>(buf, S, ix, grad, stream, stream_n, sink, blocks)) return 1;
       snprintf(buf, sizeof buf, "flat9 plain stores, %s", nm); if (run<2, false>(buf, S, ix, grad, stream, stream_n, sink, blocks)) return 1;
       snprintf(buf, sizeof buf, "flat9 atomics + loads, %s", nm); if (run<0, true>(buf, S, ix, grad, stream, stream_n, sink, blocks)) return 1;
