@@ -70,6 +70,26 @@ def joint_transforms(pose, transl, J, parents):
     return A
 
 
+def lbs_full(betas, pose, v_template, shapedirs, posedirs, J_regressor, parents, lbs_weights):
+    """The WHOLE of the reference's lbs() as `SMPL.forward` runs it every iteration (lbs.py:206-247; called at
+    body_models.py:369) — including what the render-and-fit path never reads: the pose blend shapes (lbs.py:216-229),
+    the per-vertex blend of the joint transforms and the vertex skinning (:239-247). betas [B,10], pose [B,Jn*3] ->
+    (verts [B,V,3], joints [B,Jn,3], A [B,Jn,4,4] without transl). bench.py's cpu_baseline times this form next to
+    `joint_transforms`, which is the same with the dead work removed."""
+    B = pose.shape[0]
+    Jn = parents.shape[0]
+    v_shaped = v_template[None] + torch.einsum("bl,mkl->bmk", betas, shapedirs)            # :206-207
+    J = torch.einsum("bik,ji->bjk", v_shaped, J_regressor)                                  # :210
+    rot = rodrigues(pose.reshape(-1, 3)).reshape(B, Jn, 3, 3)                               # :216-218
+    pose_feature = (rot[:, 1:] - torch.eye(3, dtype=pose.dtype)).reshape(B, -1)             # :220
+    v_posed = torch.matmul(pose_feature, posedirs).reshape(B, -1, 3) + v_shaped             # :222-232
+    A = joint_transforms(pose, None, J, parents)                                            # :234 (batch_rigid_transform)
+    joints = (A @ torch.cat([J, torch.ones(B, Jn, 1, dtype=pose.dtype)], 2)[..., None])[..., :3, 0]
+    T = torch.matmul(lbs_weights[None].expand(B, -1, -1), A.reshape(B, Jn, 16)).reshape(B, -1, 4, 4)   # :238-241
+    v_homo = torch.matmul(T, torch.cat([v_posed, torch.ones(B, v_posed.shape[1], 1, dtype=pose.dtype)], 2)[..., None])
+    return v_homo[:, :, :3, 0], joints, A                                                   # :243-247
+
+
 def cano2live(A, inv_mats):
     return A @ inv_mats
 
@@ -90,10 +110,19 @@ def project_points(points, full_proj_transform):
 
 
 def cpu_baseline_step(pose, transl, J, parents, inv_mats, query_points, res, weights,
-                      full_proj_transform):
+                      full_proj_transform, body=None, betas=None):
     """One fwd+bwd of the reference's PyTorch-CPU LBS + projection path with an L1-to-black
-    loss. pose/res must require grad. Returns the loss."""
-    A = joint_transforms(pose, transl, J, parents)
+    loss. pose/res must require grad. Returns the loss.
+    body = dict(v_template, shapedirs, posedirs, J_regressor, lbs_weights) + betas: the body model evaluated AS THE
+    REFERENCE RUNS IT — the whole lbs() with its 6,890-vertex blend shapes and vertex skinning, whose vertices the path
+    discards (`lbs_full`); body = None: rest joints precomputed, joint transforms only (the dead work removed)."""
+    if body is not None:
+        _verts, _joints, A = lbs_full(betas, pose, body["v_template"], body["shapedirs"], body["posedirs"],
+                                      body["J_regressor"], parents, body["lbs_weights"])
+        A = A.clone()
+        A[:, :, :3, 3] = A[:, :, :3, 3] + transl[:, None]                                   # body_models.py:383
+    else:
+        A = joint_transforms(pose, transl, J, parents)
     M = cano2live(A, inv_mats)
     full = skin(query_points, res, weights, M)
     loss = 0.0

@@ -62,7 +62,8 @@ def make_lbs():
     A = A.clone()
     A[:, :, :3, 3] += transl.unsqueeze(dim=1)            # body_models.py:383
     R = batch_rodrigues(pose.view(-1, 3))
-    out.update(smpl_pose=pose, smpl_transl=transl, smpl_betas=betas, smpl_A=A, smpl_rodrigues=R,
+    out.update(smpl_pose=pose, smpl_transl=transl, smpl_betas=betas, smpl_A=A, smpl_rodrigues=R, smpl_verts=verts,
+               smpl_joints=joints,
                **{"smpl_" + k: v for k, v in body.items()})
     # SMPL-X-shaped: 55 joints, random valid tree, random poses (config 5)
     g = torch.Generator().manual_seed(1)
@@ -71,12 +72,13 @@ def make_lbs():
     pose55 = torch.randn(3, 165, generator=g) * 0.4
     transl55 = torch.randn(3, 3, generator=g)
     betas55 = torch.randn(1, 10, generator=g).expand(3, -1).contiguous()
-    _, _, A55 = lbs(betas55, pose55, body55["v_template"], body55["shapedirs"], body55["posedirs"],
+    verts55, joints55, A55 = lbs(betas55, pose55, body55["v_template"], body55["shapedirs"], body55["posedirs"],
                     body55["J_regressor"], body55["parents"], body55["lbs_weights"],
                     pose2rot=True, return_affine_mat=True)
     A55 = A55.clone()
     A55[:, :, :3, 3] += transl55.unsqueeze(dim=1)
-    out.update(smplx_pose=pose55, smplx_transl=transl55, smplx_betas=betas55, smplx_A=A55,
+    out.update(smplx_pose=pose55, smplx_transl=transl55, smplx_betas=betas55, smplx_A=A55, smplx_verts=verts55,
+               smplx_joints=joints55,
                **{"smplx_" + k: v for k, v in body55.items()})
     # chain only (batch_rigid_transform), arbitrary rotations
     Rm = batch_rodrigues(torch.randn(2 * 24, 3, generator=g)).view(2, 24, 3, 3)
@@ -354,6 +356,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if sys.argv[1:] == ["net_full"]:
         make_net_full()
+        sys.exit(0)
+    if sys.argv[1:] == ["lbs"]:
+        make_lbs()
         sys.exit(0)
     lo = make_lbs()
     make_skin(lo)

@@ -25,6 +25,22 @@ def test_lbs_oracle_matches_reference_lbs_golden():
     assert A is None
 
 
+def test_lbs_full_oracle_matches_reference_lbs_vertices_and_joints():
+    """The whole of lbs() — pose blend shapes, per-vertex blend, vertex skinning — as bench.py's cpu_baseline times it
+    ("as the reference runs it"): vertices, posed joints and A against the reference's own outputs."""
+    from oracle import lbs_oracle as O
+    g = np.load(os.path.join(GOLD, "lbs_golden.npz"))
+    for model in ("smpl", "smplx"):
+        t = lambda k: torch.tensor(g[f"{model}_{k}"])
+        verts, joints, A = O.lbs_full(t("betas"), t("pose"), t("v_template"), t("shapedirs"), t("posedirs"),
+                                      t("J_regressor"), torch.tensor(g[f"{model}_parents"]), t("lbs_weights"))
+        np.testing.assert_allclose(verts.numpy(), g[f"{model}_verts"], rtol=0, atol=5e-6)
+        np.testing.assert_allclose(joints.numpy(), g[f"{model}_joints"], rtol=0, atol=5e-6)
+        A = A.clone()
+        A[:, :, :3, 3] += t("transl")[:, None]
+        np.testing.assert_allclose(A.numpy(), g[f"{model}_A"], rtol=0, atol=2e-6)
+
+
 def test_lbs_oracle_chain_matches_batch_rigid_transform_golden():
     """batch_rigid_transform with arbitrary rotation matrices (lbs.py:349-405)."""
     from oracle import lbs_oracle as O
