@@ -46,19 +46,6 @@ def _one_pass_backward(model, frames: int) -> bool:
     return bool(fused._FUSED_BWD) and M % 32 == 0
 
 
-def _map_path(model, frames: int) -> bool:
-    """Does the decoder take the map path (conv1 / conv5's input half commuted with the up-sampling, csrc/ganet_upz.hip)?
-    Mirrors fused.decoder_map_supported for the model's own shapes."""
-    from gaussianavatar_amd import fused, parallel
-    dec = model.net.decoder
-    S = int(round(float(model.uv_coord_map.shape[0]) ** 0.5))
-    R = int(model.geo_feature.shape[-1])
-    return (bool(fused._DECODER_MAP) and _one_pass_backward(model, frames) and bool(fused._NATIVE_DECODER)
-            and dec.in_size == 66 and dec.hsize == 128 and S % 32 == 0 and (frames * R * R) % 32 == 0 and R != S
-            and model.geo_feature.shape[1] == 64 and not parallel.texel_sharding()
-            and not (frames > 1 and parallel.world_size() > 1))
-
-
 def decoder_flops(model, frames: int = 1) -> dict:
     """Algorithmic flops (2 M N K per GEMM) of one iteration's decoder launches, by kernel family.
     Stage 1 evaluates the batch-invariant decoder once (frames=1): M = UV texels (S^2); stage 2
@@ -68,19 +55,6 @@ def decoder_flops(model, frames: int = 1) -> dict:
     h, cin = dec.hsize, dec.in_size
     hidden = cin * h + 3 * h * h + (h + cin) * h + 6 * h * h      # conv1, conv2-4, conv5, conv6/7 x 3 heads
     outs = h * (3 + 1 + 3)                                        # conv8 x 3 heads
-    if _map_path(model, frames):
-        # conv1 and conv5's input half run at the feature map's R^2 pixels (rowgemm: P = f Wf^T forward; df = dP Wf and
-        # dWf = dP^T f backward) and the up-sampling gathers / scatters 128-column rows: the M-row GEMMs left are the
-        # ten 128 x 128 layers and the heads
-        MP = float(model.geo_feature.shape[-1]) ** 2 * frames
-        hid = 10 * h * h
-        return {
-            "mlp_fwd": 2.0 * M * (hid + outs),
-            "layer_bwd": 4.0 * M * hid,
-            "wgrad_act": 2.0 * M * outs + 2.0 * MP * 2 * h * 64,
-            "head_bwd": 2.0 * M * outs,
-            "rowgemm": 2.0 * (2.0 * MP * 2 * h * 64),
-        }
     if _one_pass_backward(model, frames):
         # every hidden layer takes the one-pass kernel (data gradient + weight gradient in one launch): the ten with a
         # 128-column activated input (conv2-4, conv5's activated half, conv6/7 x 3) and the two fed by the raw input
@@ -117,17 +91,6 @@ def decoder_bytes(model, frames: int = 1) -> dict:
     # minimum: conv8 wgrad rides on head_bwd's operands (g, z7: counted in `head`); per head conv7 (G7, z7, z6 -> G6)
     # and conv6 (G6, z6 [z5 shared] ...); conv5 (G5, z5, z4, x -> G4, dx); conv4..2; conv1 (G1, z1, x -> dx)
     minimum = (head + 3 * 4 * h + (3 * 2 * h + 2 * h) + (3 * h + xp + h + cin) + 3 * 4 * h + (2 * h + xp + cin))
-    if _map_path(model, frames):
-        # no input tensor x [M,72]: conv1 = the up-sampling of P (writes z1), conv5 = a 128 -> 128 launch whose input half
-        # is gathered from the L2-resident P (16 MB per frame: not counted); the conv6 branches share one launch (z5 read
-        # once). Backward: the transposed up-sampling of dz1 / dz5 re-reads (G, z) of its layer.
-        fwd = 3 * (2 * h) + (2 * h) + (h + 3 * h) + 3 * (2 * h) + sum(h + o for o in outs)
-        layer = (3 * 4 * h + (4 * h) + (5 * h) + (5 * h) + 4 * h + 3 * 4 * h)
-        wgrad = sum(o + h for o in outs)
-        minimum = head + 3 * 4 * h + (3 * 2 * h + 2 * h) + 4 * h + 3 * 4 * h + 2 * h
-        return {"mlp_fwd": 4.0 * M * fwd, "layer_bwd": 4.0 * M * layer, "wgrad_act": 4.0 * M * wgrad,
-                "head_bwd": 4.0 * M * head, "upsample_z_fwd": 4.0 * M * h, "dz_upsample_t": 4.0 * M * 2 * (2 * h),
-                "backward_minimum": 4.0 * M * minimum}
     if _one_pass_backward(model, frames):
         layer = (3 * 4 * h                       # conv7 -> G6: G, z, src z in, out
                  + (4 * h) + (5 * h) + (5 * h)   # conv6 -> G5: first writes, then accumulates (out read + written)
@@ -833,15 +796,14 @@ def main():
                    "frac": d["frac_of_hbm_peak"], "algorithmic_bytes_per_iter": d["bytes_per_iter"]}
             # how far the backward pass is from its byte minimum (every tensor of every layer touched once)
             bw_launched = (dbytes.get("layer_bwd", dbytes.get("mlp_bwd_data", 0.0) + dbytes.get("wgrad_act", 0.0))
-                           + dbytes["head_bwd"] + dbytes.get("dz_upsample_t", 0.0))
+                           + dbytes["head_bwd"])
             byte_minimum = {"backward_minimum_bytes_per_iter": dbytes["backward_minimum"],
                             "backward_launched_bytes_per_iter": bw_launched,
                             "backward_launched_over_minimum": bw_launched / dbytes["backward_minimum"],
-                            "note": "algorithmic bytes of the decoder backward's launches (layer_bwd + head_bwd + dz_upsample_t) "
+                            "note": "algorithmic bytes of the decoder backward's launches (layer_bwd + head_bwd) "
                                     "against the bytes it would move if every layer touched each of its tensors once; the "
                                     "excess is the three conv6 branches accumulating into conv5's gradient through HBM and "
-                                    "re-reading z5, and the transposed up-sampling of conv5's dz re-reading (G5, z5) "
-                                    "(DESIGN.md section 4.3)"}
+                                    "re-reading z5 (DESIGN.md section 4.3)"}
             first, second = (mfma, hbm) if d["bound"] == "mfma" else (hbm, mfma)
             roof = {"kernel": dom_family, **first, "traffic": traffic, "traffic_note": traffic_note,
                     "avg_us": d["avg_us"], "launches_per_iter": d["launches_per_iter"], "us_per_iter": d["us_per_iter"],
@@ -891,8 +853,7 @@ def main():
         # this rank's iteration by component (the terms of DESIGN.md section 6's scaling model), from the instrumented
         # warm-up steps: kernel families by HIP events, collectives by events around the calls, the rest by difference
         fam = lambda names: sum(kern[k]["us_per_iter"] for k in names if k in kern)
-        dec_us = fam(("mlp_fwd", "mlp_stats", "layer_bwd", "mlp_bwd_data", "wgrad_act", "wgrad_reduce", "head_bwd", "bwd_stats",
-                      "rowgemm", "upsample_z_fwd", "dz_upsample_t"))
+        dec_us = fam(("mlp_fwd", "mlp_stats", "layer_bwd", "mlp_bwd_data", "wgrad_act", "wgrad_reduce", "head_bwd", "bwd_stats"))
         coll = {k: {"us_per_iter": 1e3 * ms / probe, "calls_per_iter": n / probe} for k, (ms, n) in probe_c.items()}
         coll_us = sum(v["us_per_iter"] for v in coll.values())
         out["rank0_breakdown"] = {

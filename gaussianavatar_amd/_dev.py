@@ -12,10 +12,6 @@ ONE variable, `GA_DEV="key=value,key=value"`, read once at import; without it ev
     row_sweep=0         decoder: every launch sweeps the rows first-to-last (no alternation)
     native_decoder=0    decoder: the per-layer launch sequence from Python instead of one native call each way
     one_pass_backward=0 decoder: separate weight- / data-gradient kernels for the hidden layers
-    decoder_map=1       decoder: conv1 / conv5's input half commuted with the bilinear up-sampling (ganet_upz.hip: no
-                        up-sampled input tensor x [M,72], no KIN = 72 launches). Built, parity-green and measured in round 5:
-                        65 us less kernel time per iteration, the same iterations/s (profiles/r05_decoder_map.md) — off by
-                        default until it wins
     native_unet=0       stage 2: the pose encoder as im2col + vendor GEMM + torch BatchNorm / element-wise kernels instead of
                         the hand-written kernels of csrc/ganet_unet.hip
 """
@@ -34,7 +30,6 @@ class DevKnobs:
     row_sweep: bool = True
     native_decoder: bool = True
     one_pass_backward: bool = True
-    decoder_map: bool = False
     native_unet: bool = True
 
 

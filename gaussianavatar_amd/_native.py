@@ -166,9 +166,7 @@ GANET_SYMBOLS = ["ganet_linear_wgrad_workspace", "ganet_linear_wgrad", "ganet_bn
                  "ganet_decoder_saved_floats", "ganet_decoder_fwd_workspace", "ganet_decoder_fwd",
                  "ganet_decoder_bwd_workspace", "ganet_decoder_bwd",
                  "ganet_decode_pack_fwd", "ganet_decode_pack_bwd", "ganet_records_bwd", "ganet_mean_sq_fwd", "ganet_mean_sq_bwd", "ganet_weighted_sum_fwd", "ganet_weighted_sum_bwd", "ganet_upsample_cat_fwd", "ganet_upsample_cat_bwd",
-                 "ganet_rowgemm", "ganet_upsample_z_fwd", "ganet_mlp_fwd_add", "ganet_dz_upsample_t_parts", "ganet_dz_upsample_t",
-                 "ganet_decoder_map_fwd_workspace", "ganet_decoder_map_fwd", "ganet_decoder_map_bwd_workspace",
-                 "ganet_decoder_map_bwd", "ganet_unet_saved_floats", "ganet_unet_fwd_workspace", "ganet_unet_fwd",
+                 "ganet_unet_saved_floats", "ganet_unet_fwd_workspace", "ganet_unet_fwd",
                  "ganet_unet_bwd_workspace", "ganet_unet_bwd", "ganet_profile_create", "ganet_profile_destroy", "ganet_profile_bind", "ganet_profile_count", "ganet_profile_read", "ganet_profile_kernel_name",
                  "ganet_conv5_packed_bytes", "ganet_conv5_pack", "ganet_conv5_apply",
                  "ganet_conv5_wgrad_workspace", "ganet_conv5_wgrad", "ganet_last_error", "ganet_abi_version"]
@@ -197,15 +195,6 @@ class GanetDecoderGrads(ctypes.Structure):
     _L = GANET_DEC_LAYERS
     _fields_ = [("dW", c_void_p * _L), ("db", c_void_p * _L), ("dgamma", c_void_p * _L), ("dbeta", c_void_p * _L),
                 ("dW8", c_void_p * 3), ("db8", c_void_p * 3), ("dx", c_void_p), ("x_cols", c_int32)]
-
-
-class GanetUpGrid(ctypes.Structure):
-    """include/ganet.h GanetUpGrid"""
-    _fields_ = [("frames", c_int32), ("S", c_int32), ("R", c_int32),
-                ("row_idx", c_void_p), ("row_w", c_void_p), ("col_idx", c_void_p), ("col_w", c_void_p),
-                ("row_ptr", c_void_p), ("row_src", c_void_p), ("row_wt", c_void_p),
-                ("col_ptr", c_void_p), ("col_src", c_void_p), ("col_wt", c_void_p),
-                ("uv", c_void_p), ("uv_frame_stride", c_int64), ("max_col_span", c_int32)]
 
 
 class GanetUnetParams(ctypes.Structure):
@@ -312,24 +301,6 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_upsample_cat_fwd.argtypes = [c_int32, c_int32, c_int32, c_int32, P, P, P, P, P, P, P, c_int64, P]
         lib.ganet_upsample_cat_bwd.restype = c_int
         lib.ganet_upsample_cat_bwd.argtypes = [c_int32, c_int32, c_int32, c_int32, P, c_int64, P, P, P, P, P, P, P, P, P]
-        lib.ganet_rowgemm.restype = c_int
-        lib.ganet_rowgemm.argtypes = [c_int64, c_int32, c_int32, P, c_int64, P, c_int64, P, c_int64, c_int32, P]
-        lib.ganet_upsample_z_fwd.restype = c_int
-        lib.ganet_upsample_z_fwd.argtypes = [P, P, c_int64, P, P, P, P, P, P]
-        lib.ganet_mlp_fwd_add.restype = c_int
-        lib.ganet_mlp_fwd_add.argtypes = [P, P, P, P, P, P, P, c_int64, P, P, P, P, c_int32, P]
-        lib.ganet_dz_upsample_t_parts.restype = c_int32
-        lib.ganet_dz_upsample_t_parts.argtypes = [P]
-        lib.ganet_dz_upsample_t.restype = c_int
-        lib.ganet_dz_upsample_t.argtypes = [P, P, P, P, P, c_int64, P, P]
-        lib.ganet_decoder_map_fwd_workspace.restype = c_size_t
-        lib.ganet_decoder_map_fwd_workspace.argtypes = [P]
-        lib.ganet_decoder_map_fwd.restype = c_int
-        lib.ganet_decoder_map_fwd.argtypes = [P, P, P, P, P, P, c_size_t, P]
-        lib.ganet_decoder_map_bwd_workspace.restype = c_size_t
-        lib.ganet_decoder_map_bwd_workspace.argtypes = [P]
-        lib.ganet_decoder_map_bwd.restype = c_int
-        lib.ganet_decoder_map_bwd.argtypes = [P, P, P, P, P, P, P, c_size_t, P, P]
         lib.ganet_unet_saved_floats.restype = c_size_t
         lib.ganet_unet_saved_floats.argtypes = [P, c_int32]
         lib.ganet_unet_fwd_workspace.restype = c_size_t
@@ -363,7 +334,7 @@ def ganet() -> ctypes.CDLL:
         lib.ganet_conv5_wgrad.argtypes = [c_int32, c_int32, c_int32, P, P, P, P, c_size_t, P]
         lib.ganet_last_error.restype = c_char_p
         lib.ganet_abi_version.restype = c_int
-        if lib.ganet_abi_version() != 8:
+        if lib.ganet_abi_version() != 9:
             raise RuntimeError("libganet_hip.so ABI version mismatch; rebuild")
         _ganet = lib
     return _ganet

@@ -49,7 +49,6 @@ LIBS = {
         ("ganet_decoder.hip", []),
         ("ganet_pack.hip", []),
         ("ganet_upsample.hip", []),
-        ("ganet_upz.hip", []),
         ("ganet_unet.hip", []),
         ("ganet_conv.hip", []),
         ("ganet_optim.hip", []),

@@ -443,7 +443,7 @@ int ganet_profile_read(GanetProfile* p, double* ms_sum, int64_t* launches, int r
 const char* ganet_profile_kernel_name(int id) {
   static const char* names[K_COUNT] = {"mlp_fwd", "mlp_stats", "wgrad_act", "wgrad_reduce",
                                        "mlp_bwd_data", "head_bwd", "bwd_stats", "ssim_fwd", "ssim_bwd",
-                                       "layer_bwd", "rowgemm", "upsample_z_fwd", "dz_upsample_t"};
+                                       "layer_bwd"};
   return (id >= 0 && id < K_COUNT) ? names[id] : "";
 }
 

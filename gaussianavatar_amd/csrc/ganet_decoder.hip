@@ -52,47 +52,6 @@ __global__ void assemble_wgrads_kernel(int cin, int ldp, const float* __restrict
   }
 }
 
-// map mode (ganet_upz.hip): W1 [128, 66], W5 [128, 194] -> Wf [256][64] (rows 0..127: W1's feature columns, 128..255:
-// W5's), its transpose WfT [64][256], the uv columns Wuv1 / Wuv5 [128][2], and W5's activation half w5y [128][128]
-__global__ void prep_map_weights_kernel(const float* __restrict__ W1, const float* __restrict__ W5, float* __restrict__ Wf,
-                                        float* __restrict__ WfT, float* __restrict__ Wuv1, float* __restrict__ Wuv5,
-                                        float* __restrict__ w5y) {
-  constexpr int C = 64, CIN = 66;
-  const int n = blockIdx.x;                 // 0..127
-  for (int k = threadIdx.x; k < CIN + H; k += blockDim.x) {
-    const float a = k < CIN ? W1[n * CIN + k] : 0.f;
-    const float b = W5[n * (CIN + H) + k];
-    if (k < C) {
-      if (Wf) { Wf[n * C + k] = a; Wf[(H + n) * C + k] = b; }
-      if (WfT) { WfT[k * 2 * H + n] = a; WfT[k * 2 * H + H + n] = b; }
-    } else if (k < CIN) {
-      if (Wuv1) { Wuv1[n * 2 + (k - C)] = a; Wuv5[n * 2 + (k - C)] = b; }
-    } else if (w5y) {
-      w5y[n * H + (k - CIN)] = b;
-    }
-  }
-}
-
-// map mode: dW1 [128, 66] <- [ dW1f [128,64] | dWuv1 [128,2] ];  dW5 [128, 194] <- [ dW5f | dWuv5 | dWy [128,128] ]
-__global__ void assemble_map_wgrads_kernel(const float* __restrict__ dW1f, const float* __restrict__ dW5f,
-                                           const float* __restrict__ dWuv1, const float* __restrict__ dWuv5,
-                                           const float* __restrict__ dWy, float* __restrict__ dW1,
-                                           float* __restrict__ dW5) {
-  constexpr int C = 64, CIN = 66;
-  const int n = blockIdx.x;
-  for (int k = threadIdx.x; k < CIN + H; k += blockDim.x) {
-    if (k < C) {
-      dW1[n * CIN + k] = dW1f[n * C + k];
-      dW5[n * (CIN + H) + k] = dW5f[n * C + k];
-    } else if (k < CIN) {
-      dW1[n * CIN + k] = dWuv1[n * 2 + (k - C)];
-      dW5[n * (CIN + H) + k] = dWuv5[n * 2 + (k - C)];
-    } else {
-      dW5[n * (CIN + H) + k] = dWy[n * H + (k - CIN)];
-    }
-  }
-}
-
 struct Sweep {      // alternate the row sweep of consecutive big launches (include/ganet.h: row_order)
   int k = 0;
   int next() { ++k; return (k & 1) ? GANET_ROWS_UP : GANET_ROWS_DOWN; }
@@ -122,13 +81,6 @@ bool params_ok(const GanetDecoderParams* p) {
   return true;
 }
 
-// map mode: feature map [frames,R,R,64] channels-last + texel grid instead of the up-sampled input rows
-bool map_ok(const GanetUpGrid* t, const float* feat, const GanetDecoderParams* p) {
-  return t && feat && aligned16(feat) && p && p->cin == 66 && t->frames > 0 && t->S > 0 && (t->S % 32) == 0 && t->R > 0 &&
-         (((int64_t)t->frames * t->R * t->R) % 32) == 0 && t->row_idx && t->row_w && t->col_idx && t->col_w && t->uv;
-}
-constexpr int CF = 64;                    // feature channels of the map
-
 }  // namespace
 
 }  // namespace ganet
@@ -149,40 +101,14 @@ size_t ganet_decoder_fwd_workspace(void) {
   return (3 * ganet_mlp_stats_floats(H) + (size_t)H * XP + (size_t)H * (XP + H)) * sizeof(float);
 }
 
-size_t ganet_decoder_map_fwd_workspace(const GanetUpGrid* t) {
-  if (!t || t->frames <= 0 || t->R <= 0) return 0;
-  // column-sum partials (three sets) | Wf [256][64] | Wuv1, Wuv5 [128][2] | w5y [128][128] | P [frames R^2][256]
-  return (3 * ganet_mlp_stats_floats(H) + (size_t)2 * H * CF + (size_t)4 * H + (size_t)H * H +
-          (size_t)t->frames * t->R * t->R * 2 * H) * sizeof(float);
-}
-
-// x != NULL: the up-sampled input rows [M,72]; else map mode (grid + feat, ganet_upz.hip)
-static int decoder_fwd_impl(int64_t M, const float* x, const GanetUpGrid* grid, const float* feat,
-                            const GanetDecoderParams* p, float* saved, float* const* out, void* workspace,
-                            hipStream_t stream) {
-  const bool map = x == nullptr;
+static int decoder_fwd_impl(int64_t M, const float* x, const GanetDecoderParams* p, float* saved, float* const* out,
+                            void* workspace, hipStream_t stream) {
   const SavedView sv = view_saved(saved, M);
   float* col_part = static_cast<float*>(workspace);      // three sets: the conv6 branches' statistics in one launch
   float* w1p = col_part + 3 * ganet_mlp_stats_floats(H);
   float* w5p = w1p + (size_t)H * XP;
-  // map mode carves the same region differently
-  float* Wf = w1p;
-  float* Wuv1 = Wf + (size_t)2 * H * CF;
-  float* Wuv5 = Wuv1 + 2 * H;
-  float* w5y = Wuv5 + 2 * H;
-  float* Pm = w5y + (size_t)H * H;
-  UpGrid ug{};
-  if (map) {
-    ug = up_grid_of(grid);
-    hipLaunchKernelGGL(prep_map_weights_kernel, dim3(H), dim3(256), 0, stream, p->W[0], p->W[4], Wf, (float*)nullptr, Wuv1,
-                       Wuv5, w5y);
-    GA_TRY(check_hip(hipGetLastError(), "prep_map_weights_kernel"));
-    // P = f . [W1_f | W5_f]^T at the map's resolution
-    GA_TRY(rowgemm_launch((int64_t)grid->frames * grid->R * grid->R, 2 * H, CF, feat, CF, Wf, CF, Pm, 2 * H, 0, stream));
-  } else {
-    hipLaunchKernelGGL(pad_weights_kernel, dim3(H), dim3(256), 0, stream, p->cin, p->W[0], p->W[4], w1p, w5p);
-    GA_TRY(check_hip(hipGetLastError(), "pad_weights_kernel"));
-  }
+  hipLaunchKernelGGL(pad_weights_kernel, dim3(H), dim3(256), 0, stream, p->cin, p->W[0], p->W[4], w1p, w5p);
+  GA_TRY(check_hip(hipGetLastError(), "pad_weights_kernel"));
   Sweep sweep;
   // layer i: z_i = [x1 | act(bn(z_src))] W^T + b with the column sums of its BatchNorm statistics (about the running
   // mean) into `cp`; the statistics kernel is a separate ~5 us launch that takes up to three layers at once
@@ -204,27 +130,9 @@ static int decoder_fwd_impl(int64_t M, const float* x, const GanetUpGrid* grid, 
     const FwdStatsJob job = stats_job(i, col_part);
     return mlp_stats_launch(1, &job, M, H, stream);
   };
-  if (map) {
-    // conv1 = the up-sampling of P's first half (+ uv term, bias), statistics in its epilogue
-    sweep.next();
-    GA_TRY(upsample_z_fwd_launch(ug, Pm, 2 * H, Wuv1, p->bias[0], p->running_mean[0], sv.z[0], col_part, stream));
-    const FwdStatsJob job = stats_job(0, col_part);
-    GA_TRY(mlp_stats_launch(1, &job, M, H, stream));
-  } else {
-    GA_TRY(hidden(0, x, w1p, -1));
-  }
+  GA_TRY(hidden(0, x, w1p, -1));
   for (int i = 1; i <= 3; ++i) GA_TRY(hidden(i, nullptr, p->W[i], i - 1));
-  if (map) {
-    // conv5 = a plain hidden layer on act(z4) with the input half gathered from P's second half
-    const FwdAddend add{ug, Pm + H, 2 * H, Wuv5};
-    const int rc = layer_fwd_spec_add(M, sv.z[3], sv.stat[3] + 2 * H, sv.stat[3] + 3 * H, w5y, p->bias[4], sv.z[4], col_part,
-                                      p->running_mean[4], add, sweep.next() == GANET_ROWS_DOWN ? 1 : 0, stream);
-    if (rc != 0) { if (rc < 0) set_error("ganet_decoder_map_fwd: shape not supported by the skip-layer kernel"); return rc < 0 ? 4 : rc; }
-    const FwdStatsJob job = stats_job(4, col_part);
-    GA_TRY(mlp_stats_launch(1, &job, M, H, stream));
-  } else {
-    GA_TRY(hidden(4, x, w5p, 3));
-  }
+  GA_TRY(hidden(4, x, w5p, 3));
   // (the heads level by level with batched statistics launches, as the backward pass runs them, measured 0.4 % slower
   // here than head after head: 274.0 vs 275.0 it/s)
   // conv6 of the three heads: ONE launch (they share their input z5: the branch workgroups of a slab sit on the same
@@ -265,21 +173,7 @@ int ganet_decoder_fwd(int64_t M, const float* x, const GanetDecoderParams* p, fl
     set_error("ganet_decoder_fwd: workspace too small");
     return 2;
   }
-  return decoder_fwd_impl(M, x, nullptr, nullptr, p, saved, out, workspace, static_cast<hipStream_t>(stream_));
-}
-
-int ganet_decoder_map_fwd(const GanetUpGrid* grid, const float* feat, const GanetDecoderParams* p, float* saved,
-                          float* const* out, void* workspace, size_t workspace_bytes, void* stream_) {
-  if (!params_ok(p) || !map_ok(grid, feat, p) || !saved || !out || !out[0] || !out[1] || !out[2] || !workspace) {
-    set_error("ganet_decoder_map_fwd: invalid arguments (cin 66, S a multiple of 32, frames*R*R a multiple of 32)");
-    return 1;
-  }
-  if (workspace_bytes < ganet_decoder_map_fwd_workspace(grid)) {
-    set_error("ganet_decoder_map_fwd: workspace too small");
-    return 2;
-  }
-  const int64_t M = (int64_t)grid->frames * grid->S * grid->S;
-  return decoder_fwd_impl(M, nullptr, grid, feat, p, saved, out, workspace, static_cast<hipStream_t>(stream_));
+  return decoder_fwd_impl(M, x, p, saved, out, workspace, static_cast<hipStream_t>(stream_));
 }
 
 static size_t bwd_wg_slot(int64_t M) {
@@ -303,19 +197,9 @@ size_t ganet_decoder_bwd_workspace(int64_t M) {
   return b;
 }
 
-size_t ganet_decoder_map_bwd_workspace(const GanetUpGrid* t) {
-  if (!t || t->frames <= 0 || t->S <= 0 || t->R <= 0) return 0;
-  const int64_t M = (int64_t)t->frames * t->S * t->S;
-  // + dP [frames R^2][256] | WfT [64][256] | dW1f, dW5f [128][64] | dWuv1, dWuv5 [128][2]   (all 256-byte multiples)
-  return ganet_decoder_bwd_workspace(M) +
-         ((size_t)t->frames * t->R * t->R * 2 * H + (size_t)CF * 2 * H + (size_t)2 * H * CF + (size_t)4 * H) * sizeof(float);
-}
-
-// x != NULL: the up-sampled input rows [M,72] (g->dx = their gradient); else map mode: grid + feat (g->dx = dL/dfeat)
-static int decoder_bwd_impl(int64_t M, const float* x, const GanetUpGrid* grid, const float* feat,
-                            const GanetDecoderParams* p, const float* saved_, const float* const* d_out,
-                            const GanetDecoderGrads* g, void* workspace, void* stream_, void* side_stream_) {
-  const bool map = x == nullptr;
+static int decoder_bwd_impl(int64_t M, const float* x, const GanetDecoderParams* p, const float* saved_,
+                            const float* const* d_out, const GanetDecoderGrads* g, void* workspace, void* stream_,
+                            void* side_stream_) {
   for (int i = 0; i < NL; ++i)
     if (!g->dW[i] || !g->db[i] || !g->dgamma[i] || !g->dbeta[i]) { set_error("ganet_decoder_bwd: missing gradient buffer"); return 1; }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -339,23 +223,6 @@ static int decoder_bwd_impl(int64_t M, const float* x, const GanetUpGrid* grid, 
   float* dWx = reinterpret_cast<float*>(w); w += (size_t)H * H * sizeof(float);
   float* dWy = reinterpret_cast<float*>(w); w += (size_t)H * H * sizeof(float);
   float* db_dump = reinterpret_cast<float*>(w); w += 2 * H * sizeof(float);
-  // map mode: the gradient of P = f . [W1_f | W5_f]^T at the map's resolution and the pieces of dW1 / dW5
-  const int64_t MP = map ? (int64_t)grid->frames * grid->R * grid->R : 0;
-  float* dP = reinterpret_cast<float*>(w); if (map) w += (size_t)MP * 2 * H * sizeof(float);
-  float* WfT = reinterpret_cast<float*>(w); if (map) w += (size_t)CF * 2 * H * sizeof(float);
-  float* dW1f = reinterpret_cast<float*>(w); if (map) w += (size_t)H * CF * sizeof(float);
-  float* dW5f = reinterpret_cast<float*>(w); if (map) w += (size_t)H * CF * sizeof(float);
-  float* dWuv1 = reinterpret_cast<float*>(w); if (map) w += (size_t)2 * H * sizeof(float);
-  float* dWuv5 = reinterpret_cast<float*>(w); if (map) w += (size_t)2 * H * sizeof(float);
-  UpGrid ug{};
-  if (map) {
-    ug = up_grid_of(grid);
-    if ((size_t)dz_upsample_t_blocks(ug) * (2 * H + H) * sizeof(float) > wg ||
-        ganet_wgrad_act_workspace(MP, H, CF) > wg) { set_error("ganet_decoder_map_bwd: partial-tile slot too small"); return 2; }
-    hipLaunchKernelGGL(prep_map_weights_kernel, dim3(H), dim3(256), 0, static_cast<hipStream_t>(stream_), p->W[0], p->W[4],
-                       (float*)nullptr, WfT, (float*)nullptr, (float*)nullptr, (float*)nullptr);
-    GA_TRY(check_hip(hipGetLastError(), "prep_map_weights_kernel"));
-  }
 
   GanetWgradJob jobs[GANET_MAX_WGRAD_JOBS];
   int njobs = 0;
@@ -464,15 +331,7 @@ static int decoder_bwd_impl(int64_t M, const float* x, const GanetUpGrid* grid, 
                                           0, nullptr, nullptr, nullptr, sweep.next(), stream));
     return 0;
   };
-  // map mode: the input half of a layer = the transposed up-sampling of its dz into dP (+ the uv columns' weight
-  // gradient and the bias gradient from the same sweep)
-  auto input_bwd_map = [&](int i, const float* G, int col0, float* dWuv, float* db) -> int {
-    float* part = static_cast<float*>(add_job(H, 2, dWuv, db, dz_upsample_t_blocks(ug)));
-    sweep.next();
-    return dz_upsample_t_launch(ug, *grid, G, sv.z[i], coef[i], dP + col0, 2 * H, part, stream);
-  };
-  if (map) GA_TRY(input_bwd_map(4, G5, H, dWuv5, db_dump));
-  else GA_TRY(input_bwd(4, G5, W5, ld5, 0, dWx, db_dump));
+  GA_TRY(input_bwd(4, G5, W5, ld5, 0, dWx, db_dump));
   float* Gcur = Gbuf[0];
   GA_TRY(layer_bwd(4, G5, 3, W5 + cin, ld5, Gcur, 0, 1, dWy, g->db[4], col_part));
   float* Gnext = Gbuf[1];
@@ -482,36 +341,13 @@ static int decoder_bwd_impl(int64_t M, const float* x, const GanetUpGrid* grid, 
     float* t = Gcur; Gcur = Gnext; Gnext = t;
   }
   GA_TRY(finish(0, n_fused));
-  if (map) {
-    GA_TRY(input_bwd_map(0, Gcur, 0, dWuv1, g->db[0]));
-    // dL/dfeat = dP . [W1_f ; W5_f]; dWf = dP^T feat (two 128-row halves; off the chain: side stream)
-    if (g->dx) GA_TRY(rowgemm_launch(MP, CF, 2 * H, dP, 2 * H, WfT, 2 * H, g->dx, CF, 0, stream));
-    for (int hlf = 0; hlf < 2; ++hlf) {
-      void* ws = add_job(H, CF, hlf ? dW5f : dW1f, db_dump + H, 0);
-      jobs[njobs - 1].M = MP;
-      hipStream_t st = stream;
-      if (side) {
-        GA_TRY(check_hip(hipEventRecord(ev_main, stream), "hipEventRecord"));
-        GA_TRY(check_hip(hipStreamWaitEvent(side, ev_main, 0), "hipStreamWaitEvent"));
-        st = side;
-        side_used = true;
-      }
-      GA_TRY(ganet_wgrad_act(MP, H, CF, dP + hlf * H, 2 * H, nullptr, 0, nullptr, feat, CF, nullptr, nullptr, nullptr,
-                             nullptr, ws, wg, GANET_ROWS_DEFAULT, st));
-    }
-  } else {
-    GA_TRY(input_bwd(0, Gcur, p->W[0], cin, 1, dW0p, g->db[0]));
-  }
+  GA_TRY(input_bwd(0, Gcur, p->W[0], cin, 1, dW0p, g->db[0]));
   if (side_used) {
     GA_TRY(check_hip(hipEventRecord(ev_side, side), "hipEventRecord"));
     GA_TRY(check_hip(hipStreamWaitEvent(stream, ev_side, 0), "hipStreamWaitEvent"));
   }
   GA_TRY(ganet_wgrad_reduce_batch(njobs, jobs, stream));
-  if (map)
-    hipLaunchKernelGGL(assemble_map_wgrads_kernel, dim3(H), dim3(256), 0, stream, dW1f, dW5f, dWuv1, dWuv5, dWy, g->dW[0],
-                       g->dW[4]);
-  else
-    hipLaunchKernelGGL(assemble_wgrads_kernel, dim3(H), dim3(256), 0, stream, cin, ldp, dW0p, dWx, dWy, g->dW[0], g->dW[4]);
+  hipLaunchKernelGGL(assemble_wgrads_kernel, dim3(H), dim3(256), 0, stream, cin, ldp, dW0p, dWx, dWy, g->dW[0], g->dW[4]);
   return check_hip(hipGetLastError(), "assemble_wgrads_kernel");
 }
 
@@ -526,24 +362,7 @@ int ganet_decoder_bwd(int64_t M, const float* x, const GanetDecoderParams* p, co
     set_error("ganet_decoder_bwd: workspace too small");
     return 2;
   }
-  return decoder_bwd_impl(M, x, nullptr, nullptr, p, saved_, d_out, g, workspace, stream_, side_stream_);
-}
-
-int ganet_decoder_map_bwd(const GanetUpGrid* grid, const float* feat, const GanetDecoderParams* p, const float* saved_,
-                          const float* const* d_out, const GanetDecoderGrads* g, void* workspace, size_t workspace_bytes,
-                          void* stream_, void* side_stream_) {
-  if (!params_ok(p) || !map_ok(grid, feat, p) || !grid->row_ptr || !grid->row_src || !grid->row_wt || !grid->col_ptr ||
-      !grid->col_src || !grid->col_wt || !saved_ || !d_out || !g || !workspace || (g->dx && g->x_cols != CF)) {
-    set_error("ganet_decoder_map_bwd: invalid arguments (cin 66, S a multiple of 32, frames*R*R a multiple of 32, "
-              "grads->x_cols 64)");
-    return 1;
-  }
-  if (workspace_bytes < ganet_decoder_map_bwd_workspace(grid)) {
-    set_error("ganet_decoder_map_bwd: workspace too small");
-    return 2;
-  }
-  const int64_t M = (int64_t)grid->frames * grid->S * grid->S;
-  return decoder_bwd_impl(M, nullptr, grid, feat, p, saved_, d_out, g, workspace, stream_, side_stream_);
+  return decoder_bwd_impl(M, x, p, saved_, d_out, g, workspace, stream_, side_stream_);
 }
 
 }  // extern "C"

@@ -73,15 +73,10 @@ struct FwdBranches {
   const float* stat_shift[3];
 };
 
-// ADD (the skip layer, ganet_upz.hip): the layer's second input — the raw decoder input x [M,66] = [up-sampled features | uv]
-// times W5[:, 0:66] — enters as a per-row additive term that the PRODUCERS gather: bilinear taps of P = f . W5_f^T at the
-// feature map's resolution (L2-resident) + W5_uv . uv. The term of slab r + 1 goes into that slab's output-tile region
-// of LDS (drained one round earlier, idle until the consumers' epilogue of round r + 1), the consumers add it before
-// the statistics. A slab is 32 consecutive texels of ONE texel row (S a multiple of 32): the row taps are wave-uniform.
-template <int NB, bool ADD>
+template <int NB>
 __global__ void __attribute__((amdgpu_flat_work_group_size(FWG, FWG), amdgpu_waves_per_eu(3, 3)))
 layer_fwd_spec_kernel(int64_t M, const float* __restrict__ x, const float* __restrict__ in_scale,
-                      const float* __restrict__ in_shift, FwdBranches br, int reverse, FwdAddend add) {
+                      const float* __restrict__ in_shift, FwdBranches br, int reverse) {
   extern __shared__ u32x4 s_mem[];
   char* const lds = reinterpret_cast<char*>(s_mem);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -106,17 +101,7 @@ layer_fwd_spec_kernel(int64_t M, const float* __restrict__ x, const float* __res
   const int64_t nslab = M / FSLAB;
   const int rounds = (int)((nslab + vgrid - 1) / vgrid);
   const int roundsN = (rounds + 3) & ~3;            // both roles run the same number of barriers
-  // ADD (nslab a multiple of 8 vgrid): XCD x (= blockIdx % 8) sweeps its own contiguous eighth of the slabs, so that the
-  // rows of P it gathers are a band of the map that stays in ITS L2 (ganet_upz.hip: upsample_z_fwd_pipe_kernel)
-  const bool banded = ADD && NB == 1 && (vgrid % 8) == 0 && (nslab % vgrid) == 0;
-  const int64_t band0 = banded ? (int64_t)(vblock % 8) * (nslab / 8) : 0;
-  auto slab_of = [&](int r) -> int64_t {
-    if (banded) return r < rounds ? band0 + (int64_t)r * (vgrid / 8) + vblock / 8 : nslab;
-    return (int64_t)r * vgrid + vblock;
-  };
-  // (ADD: letting consecutive rounds of a workgroup walk down the four texel rows that share their row taps — so that
-  // three of four gathers would find their rows of P in the L1 / L2 — measured SLOWER, 102 -> 126 us per launch: the
-  // common front over contiguous rows is what the HBM stream wants)
+  auto slab_of = [&](int r) -> int64_t { return (int64_t)r * vgrid + vblock; };
   auto phys = [&](int64_t slab) -> int64_t {
     const int64_t sl = slab < nslab ? slab : nslab - 1;        // past the end: re-read the last slab (never used)
     return reverse ? nslab - 1 - sl : sl;
@@ -169,73 +154,11 @@ layer_fwd_spec_kernel(int64_t M, const float* __restrict__ x, const float* __res
       *reinterpret_cast<float4*>(op) = o0;
       *reinterpret_cast<float4*>(op + 4) = o1;
     };
-    // ---- ADD: the gathered term of this lane's 8 columns of row prow. Taps (a round ahead), then the eight 16-byte
-    // loads from P, then the combination into the slab's tile region.
-    struct Taps { int q0, q1; float b0, b1, uu, vv; int base0, base1; float a0, a1; };      // (32-bit offsets into P: < 2^31 floats)
-    struct Gath { f32x4 v[8]; };
-    float wu[8], wv[8];
-    if (ADD) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { wu[e] = add.Wuv[(8 * pq + e) * 2]; wv[e] = add.Wuv[(8 * pq + e) * 2 + 1]; }
-    }
-    auto issue_taps = [&](Taps& t, int64_t ps) {
-      const int S = add.g.S, R = add.g.R;
-      // slab ps -> (frame f, texel row i, first texel j) without a 64-bit division (~100 instructions on the producers'
-      // critical path, every round): slabs per row / per frame are small 32-bit numbers, one frame is the common case
-      const int spr = S / FSLAB;                         // slabs per texel row
-      const int psi = (int)ps;                           // (nslab < 2^31)
-      const int grow = (spr & (spr - 1)) == 0 ? psi >> __builtin_ctz(spr) : psi / spr;
-      const int jcol = psi - grow * spr;
-      const int f = add.g.frames == 1 ? 0 : grow / S;
-      const int i = grow - f * S, j = jcol * FSLAB + prow;
-      const int2 ri = *reinterpret_cast<const int2*>(add.g.row_idx + 2 * i);
-      const float2 rw = *reinterpret_cast<const float2*>(add.g.row_w + 2 * i);
-      const int2 ci = *reinterpret_cast<const int2*>(add.g.col_idx + 2 * j);
-      const float2 cw = *reinterpret_cast<const float2*>(add.g.col_w + 2 * j);
-      const float2 uvv = *reinterpret_cast<const float2*>(add.g.uv + ((int64_t)f * add.g.uv_frame_stride + (i * S + j) * 2));
-      t.q0 = ci.x; t.q1 = ci.y; t.b0 = cw.x; t.b1 = cw.y; t.uu = uvv.x; t.vv = uvv.y;
-      const int ldp = (int)add.ldp;
-      t.base0 = ((f * R + ri.x) * R) * ldp + 8 * pq;
-      t.base1 = ((f * R + ri.y) * R) * ldp + 8 * pq;
-      t.a0 = rw.x; t.a1 = rw.y;
-    };
-    auto issue_gather = [&](Gath& gq, const Taps& t) {
-      const int ldp = (int)add.ldp;
-      const float* p00 = add.P + (t.base0 + t.q0 * ldp);
-      const float* p01 = add.P + (t.base0 + t.q1 * ldp);
-      const float* p10 = add.P + (t.base1 + t.q0 * ldp);
-      const float* p11 = add.P + (t.base1 + t.q1 * ldp);
-      gq.v[0] = *reinterpret_cast<const f32x4*>(p00); gq.v[1] = *reinterpret_cast<const f32x4*>(p00 + 4);
-      gq.v[2] = *reinterpret_cast<const f32x4*>(p01); gq.v[3] = *reinterpret_cast<const f32x4*>(p01 + 4);
-      gq.v[4] = *reinterpret_cast<const f32x4*>(p10); gq.v[5] = *reinterpret_cast<const f32x4*>(p10 + 4);
-      gq.v[6] = *reinterpret_cast<const f32x4*>(p11); gq.v[7] = *reinterpret_cast<const f32x4*>(p11 + 4);
-    };
-    auto finish_gather = [&](const Gath& gq, const Taps& t, int buf) {
-      const float w00 = t.a0 * t.b0, w01 = t.a0 * t.b1, w10 = t.a1 * t.b0, w11 = t.a1 * t.b1;
-      float o[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int hq = e >> 2, el = e & 3;
-        float v = w00 * gq.v[hq][el];
-        v = fmaf(w01, gq.v[2 + hq][el], v);
-        v = fmaf(w10, gq.v[4 + hq][el], v);
-        v = fmaf(w11, gq.v[6 + hq][el], v);
-        v = fmaf(wu[e], t.uu, v);
-        o[e] = fmaf(wv[e], t.vv, v);
-      }
-      char* const zs = lds + buf * BUF + IMG + prow * 512 + pq * 32;
-      *reinterpret_cast<f32x4*>(zs) = f32x4{o[0], o[1], o[2], o[3]};
-      *reinterpret_cast<f32x4*>(zs + 16) = f32x4{o[4], o[5], o[6], o[7]};
-    };
-    Taps tp{};
-    Gath gq{};
     // four slabs of raw rows in flight (32 KB per slab and workgroup); the round loop is unrolled by four so that a
     // set is a fixed group of registers (a loop-carried copy would wait for the loads)
     Raw q[4];
     load_raw(q[0], phys(slab_of(0)));
-    if (ADD) { issue_taps(tp, phys(slab_of(0))); issue_gather(gq, tp); }
     produce(q[0], 0);
-    if (ADD) { finish_gather(gq, tp, 0); issue_taps(tp, phys(slab_of(1))); }
 #pragma unroll
     for (int i = 1; i < 5; ++i) load_raw(q[i & 3], phys(slab_of(i)));
     __syncthreads();                                     // slab 0 in LDS
@@ -244,23 +167,12 @@ layer_fwd_spec_kernel(int64_t M, const float* __restrict__ x, const float* __res
     auto pin = [&](Raw& s) { asm volatile("" : "+v"(s.s0), "+v"(s.s1) :: "memory"); };
     auto round = [&](Raw& s0, int r) {                   // slab r + 1 -> buffer (r + 1) & 1, then slab r + 5's loads
       LFWD_STAMP(1, r, 0);
-      if (ADD) {                                         // slab r + 1's taps arrived a round ago: its rows of P now
-        issue_gather(gq, tp);
-        __builtin_amdgcn_sched_barrier(0);
-      }
       drain(r - 1);
       LFWD_STAMP(1, r, 1);
       pin(s0);
       LFWD_STAMP(1, r, 2);
       produce(s0, (r + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
-      if (ADD) {                                         // (the tile region of buffer (r + 1) & 1 was drained above)
-        asm volatile("" : "+v"(gq.v[0]), "+v"(gq.v[1]), "+v"(gq.v[2]), "+v"(gq.v[3]), "+v"(gq.v[4]), "+v"(gq.v[5]),
-                          "+v"(gq.v[6]), "+v"(gq.v[7]) :: "memory");
-        finish_gather(gq, tp, (r + 1) & 1);
-        issue_taps(tp, phys(slab_of(r + 2)));
-        __builtin_amdgcn_sched_barrier(0);
-      }
       load_raw(s0, phys(slab_of(r + 5)));
       __builtin_amdgcn_sched_barrier(0);
       LFWD_STAMP(1, r, 3);
@@ -338,7 +250,6 @@ layer_fwd_spec_kernel(int64_t M, const float* __restrict__ x, const float* __res
           float val = acc[0][q];
           if (GANET_LFWD_CHAINS == 2) val += acc[GANET_LFWD_CHAINS - 1][q];
           val += bias_r;
-          if (ADD) val += zs[row * 128];                 // the producers' gathered term of this slab
           zs[row * 128] = val;
           const float d = val - sshift;
           csum += d;
@@ -380,20 +291,20 @@ extern "C" int ganet_dev_lfwd_trace(void* out) { return (int)hipMemcpyFromSymbol
 
 // Hidden layer forward, [M,128] -> [M,128], contiguous rows, M a multiple of 32: returns -1 for anything else (the
 // caller then takes mlp_fwd_split_kernel).
-template <int NB, bool ADD = false>
+template <int NB>
 static int launch_layer_fwd(int blocks, int64_t M, const float* x, const float* in_scale, const float* in_shift,
-                            const FwdBranches& br, int reverse, hipStream_t stream, const FwdAddend& add = FwdAddend{}) {
+                            const FwdBranches& br, int reverse, hipStream_t stream) {
   const size_t lds = (size_t)2 * BUF;
   static PerDeviceFlag attr_set;
   if (!attr_set) {
-    if (int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_fwd_spec_kernel<NB, ADD>),
+    if (int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_fwd_spec_kernel<NB>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "layer_fwd lds"))
       return rc;
     attr_set = true;
   }
   ProfScope prof_(K_MLP_FWD, stream);
-  hipLaunchKernelGGL((layer_fwd_spec_kernel<NB, ADD>), dim3(blocks), dim3(FWG), lds, stream, M, x, in_scale, in_shift, br,
-                     reverse, add);
+  hipLaunchKernelGGL((layer_fwd_spec_kernel<NB>), dim3(blocks), dim3(FWG), lds, stream, M, x, in_scale, in_shift, br,
+                     reverse);
   return check_hip(hipGetLastError(), "layer_fwd_spec_kernel");
 }
 
@@ -404,18 +315,6 @@ int layer_fwd_spec(int64_t M, const float* x, int64_t ldx, const float* in_scale
   FwdBranches br{};
   br.W[0] = W; br.bias[0] = bias; br.z[0] = z; br.col_part[0] = col_part; br.stat_shift[0] = stat_shift;
   return launch_layer_fwd<1>(FBLOCKS, M, x, in_scale, in_shift, br, reverse, stream);
-}
-
-// The skip layer with its input half as a gathered additive term (ganet_upz.hip): -1 when the shape does not qualify.
-int layer_fwd_spec_add(int64_t M, const float* x, const float* in_scale, const float* in_shift, const float* W,
-                       const float* bias, float* z, float* col_part, const float* stat_shift, const FwdAddend& add,
-                       int reverse, hipStream_t stream) {
-  const UpGrid& g = add.g;
-  if (M < FSLAB || (M % FSLAB) != 0 || !aligned16(z) || g.S <= 0 || (g.S % FSLAB) != 0 ||
-      M != (int64_t)g.frames * g.S * g.S || M >= (int64_t)1 << 31 || (int64_t)g.frames * g.R * g.R * add.ldp >= (int64_t)1 << 31 || !add.P || (add.ldp % 4) != 0 || !aligned16(add.P) || !add.Wuv) return -1;
-  FwdBranches br{};
-  br.W[0] = W; br.bias[0] = bias; br.z[0] = z; br.col_part[0] = col_part; br.stat_shift[0] = stat_shift;
-  return launch_layer_fwd<1, true>(FBLOCKS, M, x, in_scale, in_shift, br, reverse, stream, add);
 }
 
 // Three layers on the same input (the decoder's conv6 branches) in one launch: -1 when the shape does not qualify.

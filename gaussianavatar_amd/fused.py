@@ -300,26 +300,6 @@ def bilinear_taps(Wm: torch.Tensor):
     return (idx32, w, ptr.to(torch.int32).to(dev), src.to(torch.int32).to(dev), wc.float().to(dev))
 
 
-def tap_col_span(taps, group: int = 8) -> int:
-    """GanetUpGrid.max_col_span of a tap list (bilinear_taps): the most texels the taps of `group` consecutive map
-    indices span, or 0 when the grid is not monotone (a tap index that decreases along the texel axis)."""
-    idx32, w, ptr, src, _ = taps
-    first = idx32[:, 0].cpu()
-    if bool((first[1:] < first[:-1]).any()):
-        return 0
-    ptr, src = ptr.cpu().tolist(), src.cpu().tolist()
-    R = len(ptr) - 1
-    span = 0
-    for q0 in range(0, R, group):
-        a, b = ptr[q0], ptr[min(R, q0 + group)]
-        if b > a:
-            seg = src[a:b]
-            if min(seg) != seg[0] or max(seg) != seg[-1]:
-                return 0
-            span = max(span, seg[-1] - seg[0] + 1)
-    return span
-
-
 class _UpsampleCatFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pix, uv, rows, cols, ldx):
@@ -1101,106 +1081,6 @@ def _decoder_bwd_native(ctx, lib, sv, d_outs):
 
 
 _DecoderFn._backward_native = staticmethod(_decoder_bwd_native)
-
-
-# ------------------------------------------------------------------------------------------------
-# The decoder fed by the feature MAP (csrc/ganet_upz.hip): conv1 and the input half of conv5 commute with the bilinear
-# up-sampling — their GEMMs run at the map's R^2 pixels, the up-sampling gathers 128-column rows — so the up-sampled
-# input tensor x [M,72], its gradient, both KIN = 72 launches each way and the separate up-sampling kernels leave the
-# iteration. Training mode, single-rank statistics, one native call each way (ganet_decoder_map_fwd / _bwd).
-_DECODER_MAP = _dev.knobs.decoder_map
-
-
-def decoder_map_supported(dec, pix, uv, S: int, m_global=None) -> bool:
-    """pix [b,64,R,R] (the geometry / pose feature map), uv [b or 1, S*S, 2]."""
-    if not (_DECODER_MAP and pix.is_cuda and pix.dtype == torch.float32 and pix.dim() == 4 and pix.shape[1] == 64):
-        return False
-    b, _, R, R2 = pix.shape
-    M = b * S * S
-    probe = pix.new_empty((1, dec.in_size))
-    return (R == R2 and dec.in_size == 66 and decoder_supported(dec, probe) and torch.is_grad_enabled()
-            and S % 32 == 0 and (b * R * R) % 32 == 0 and uv.dim() == 3 and uv.shape[1:] == (S * S, 2)
-            and uv.stride(2) == 1 and uv.stride(1) == 2 and not uv.requires_grad
-            and _native_decoder_ok(dec, M, m_global is not None and int(m_global) != M))
-
-
-def _up_grid(b, S, R, rows, cols, uv):
-    """GanetUpGrid for the tap lists of bilinear_taps (rows / cols) and the texels' uv coordinates."""
-    g = _native.GanetUpGrid()
-    g.frames, g.S, g.R = b, S, R
-    g.row_idx, g.row_w, g.row_ptr, g.row_src, g.row_wt = (t.data_ptr() for t in rows)
-    g.col_idx, g.col_w, g.col_ptr, g.col_src, g.col_wt = (t.data_ptr() for t in cols)
-    g.uv = uv.data_ptr()
-    g.uv_frame_stride = 0 if (uv.shape[0] == 1 or b == 1) else uv.stride(0)
-    # (the tiled transposed up-sampling needs a monotone grid in BOTH directions: its tiles walk contiguous texel rows)
-    key = (rows[2].data_ptr(), cols[2].data_ptr())
-    if _span_cache.get("key") != key:
-        _span_cache["key"], _span_cache["val"] = key, (tap_col_span(cols) if tap_col_span(rows) > 0 else 0)
-    g.max_col_span = _span_cache["val"]
-    return g
-
-
-_span_cache = {}
-
-
-class _DecoderMapFn(torch.autograd.Function):
-    """(pix [b,64,R,R], uv [b or 1, S*S, 2], flat parameter list as _DecoderFn) -> the three heads' logits for the
-    b*S*S texels: _UpsampleCatFn + _DecoderFn without the input tensor in between."""
-
-    @staticmethod
-    def forward(ctx, pix, dec, uv, rows, cols, *params):
-        lib = _native.ganet()
-        dev = pix.device
-        b, _, R, _ = pix.shape
-        S = rows[0].shape[0]
-        M = b * S * S
-        nl = len(_decoder_bn_layers())
-        feat = pix.permute(0, 2, 3, 1).contiguous()                     # channels-last [b,R,R,64] (no copy if it already is)
-        grid = _up_grid(b, S, R, rows, cols, uv)
-        P, keep = _native_decoder_params(dec, params, nl)
-        saved = torch.empty(lib.ganet_decoder_saved_floats(M), dtype=torch.float32, device=dev)
-        outs = [torch.empty((M, P.n8[j]), dtype=torch.float32, device=dev) for j in range(3)]
-        wsb = lib.ganet_decoder_map_fwd_workspace(ctypes.byref(grid))
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-        optrs = (ctypes.c_void_p * 3)(*[o.data_ptr() for o in outs])
-        _native.ganet_check(lib.ganet_decoder_map_fwd(ctypes.byref(grid), _ptr(feat), ctypes.byref(P), _ptr(saved), optrs,
-                                                      _ptr(ws), wsb, _stream(dev)))
-        ctx.dec, ctx.nl, ctx.dims = dec, nl, (b, S, R)
-        ctx.taps = (rows, cols, uv)
-        ctx.save_for_backward(feat, saved, *params)
-        return tuple(outs)
-
-    @staticmethod
-    def backward(ctx, *d_outs):
-        lib = _native.ganet()
-        sv = ctx.saved_tensors
-        feat, saved, params = sv[0], sv[1], sv[2:]
-        dev = feat.device
-        b, S, R = ctx.dims
-        M = b * S * S
-        rows, cols, uv = ctx.taps
-        grid = _up_grid(b, S, R, rows, cols, uv)
-        P, keep = _native_decoder_params(ctx.dec, params, ctx.nl)
-        G, views = _decoder_grad_views(params, ctx.nl, dev)
-        dfeat = None
-        if ctx.needs_input_grad[0]:
-            dfeat = torch.empty_like(feat)
-            G.dx, G.x_cols = dfeat.data_ptr(), 64
-        douts, dptrs = _decoder_head_grads(d_outs, params, ctx.nl, M, dev)
-        wsb = lib.ganet_decoder_map_bwd_workspace(ctypes.byref(grid))
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-        side = _side_stream(dev) if (_WGRAD_STREAM and not _profiling) else None
-        _native.ganet_check(lib.ganet_decoder_map_bwd(ctypes.byref(grid), _ptr(feat), ctypes.byref(P), _ptr(saved), dptrs,
-                                                      ctypes.byref(G), _ptr(ws), wsb, _stream(dev),
-                                                      None if side is None else ctypes.c_void_p(side.cuda_stream)))
-        dpix = None if dfeat is None else dfeat.permute(0, 3, 1, 2)
-        return (dpix, None, None, None, None) + tuple(views)
-
-
-def decoder_from_map(dec, pix, uv, rows, cols):
-    """The decoder on the texel grid described by the tap lists `rows` / `cols` (bilinear_taps) of the feature map pix:
-    -> (residual [M,3], scale logits [M,1], colour logits [M,3]), M = b*S*S. See decoder_map_supported."""
-    return _DecoderMapFn.apply(pix, dec, uv, rows, cols, *_decoder_param_list(dec))
 
 
 def _allreduce_partials(col_parts, width: int) -> None:

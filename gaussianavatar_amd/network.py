@@ -326,18 +326,6 @@ class POP_no_unet(nn.Module):
             uv_loc = uv_loc.expand(b, -1, -1)
         if feat_res != uv_res:
             pad = fused.decoder_input_pad(self.decoder, pix.new_empty(1)) if mats is not None else 0
-            if (mats is not None and pad and C == 64 and uv_loc.shape[-1] == 2 and rows is None
-                    and fused.decoder_map_supported(self.decoder, pix, uv_loc, uv_res, m_global)):
-                # training iteration: conv1 / conv5's input half commute with the up-sampling (their GEMMs run on the
-                # feature map, csrc/ganet_upz.hip): no up-sampled input tensor, one native call each way
-                taps = self._bilinear_taps(mats)
-                r, s, c = fused.decoder_from_map(self.decoder, pix, uv_loc, taps[0], taps[1])
-                if raw_heads is False:
-                    s, c = torch.sigmoid(s), torch.sigmoid(c)
-                r, s, c = (t.reshape(b, HW, -1) for t in (r, s, c))
-                if shared:
-                    r, s, c = (t.expand(B, -1, -1) for t in (r, s, c))
-                return r, s, c
             if mats is not None and pad and C == 64 and uv_loc.shape[-1] == 2:
                 # separable query grid + fused decoder: one kernel writes the decoder's input rows
                 # (bilinear 2x2 taps, uv columns, zero padding) — no dense GEMMs, no cat

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GANET_ABI_VERSION 8
+#define GANET_ABI_VERSION 9
 #define GANET_MAX_TERMS 8
 
 /* ---- dW[N,K] = sum_m g[m,n] x[m,k] ; db[N] = sum_m g[m,n] (db may be NULL).
@@ -333,69 +333,11 @@ int ganet_upsample_cat_bwd(int32_t frames, int32_t S, int32_t R, int32_t C, cons
                            const int32_t* col_ptr, const int32_t* col_src, const float* col_w,
                            float* tmp, float* dfeat, void* stream);
 
-/* ---- the decoder's two input GEMMs commuted with the bilinear up-sampling (ganet_upz.hip) --------------------------
- * conv1 and the input half of conv5 are 1x1 convolutions of x[m] = [grid_sample(f)[m] | uv[m]]
- * (/root/reference/model/network.py:60-81, /root/reference/model/modules.py:555,559) and bilinear sampling is linear in
- * the feature map f [frames,R,R,64], so W x[m] = sum_taps w_t (W_f f)[src_t(m)] + W_uv uv[m]: the GEMM runs at the
- * map's R^2 pixels instead of the S^2 texels and the up-sampling gathers rows of P = f . W_f^T. GanetUpGrid describes the
- * separable texel grid: forward tap lists as ganet_upsample_cat_fwd takes them (the FIRST tap of a row / column is the
- * one with the larger weight, never 0), the transposed lists in CSR form as ganet_upsample_cat_bwd takes them, and
- * the uv coordinates of the texels (uv_frame_stride floats between frames, 0 = one map for all frames). All 8-byte
- * aligned device pointers.
- *   ganet_rowgemm          C[M,N] (+)= A[M,K] . Bt[N,K]^T   (M, N multiples of 32, K of 64; fp32 MFMA)
- *   ganet_upsample_z_fwd   z[m, 0:128] = bilinear(P[:, 0:128])[m] + Wuv[128,2] . uv[m] + bias (bias may be NULL), and
- *                          col_part (optional, ganet_mlp_stats_floats(128) floats) = per-workgroup column sums of
- *                          z - stat_shift and (z - stat_shift)^2 for ganet_mlp_stats. P: [frames*R*R, ldp >= 128].
- *   ganet_dz_upsample_t    dP[f,p,q, 0:128] (row stride ldp) = sum over the texels m whose taps hit pixel (p,q) of
- *                          w . dz[m, :], dz = coef[0] G + coef[1] Z + coef[2] (per column; the BatchNorm backward folded
- *                          as in ganet_mlp_bwd_data): the transposed up-sampling of dL/dz without storing it. partial
- *                          (optional): ganet_dz_upsample_t_parts(grid) blocks of [128*2 + 128] floats — per-workgroup
- *                          sums of dz uv^T ([128,2]) and dz ([128]) over all texels, to be finished by
- *                          ganet_wgrad_reduce_batch (job N = 128, K = 2, nblocks = ..._parts). */
-typedef struct GanetUpGrid {
-  int32_t frames, S, R;
-  const int32_t* row_idx; const float* row_w;                          /* [S,2] */
-  const int32_t* col_idx; const float* col_w;                          /* [S,2] */
-  const int32_t* row_ptr; const int32_t* row_src; const float* row_wt; /* CSR: [R+1], [nnz], [nnz] */
-  const int32_t* col_ptr; const int32_t* col_src; const float* col_wt;
-  const float* uv;                                                      /* [frames or 1][S*S][2] */
-  int64_t uv_frame_stride;
-  int32_t max_col_span;   /* the most texel columns the taps of 8 consecutive map columns (0-7, 8-15, ...) span, for a grid
-                             whose tap indices never decrease along a texel row / column and whose CSR lists are sorted by
-                             texel; 0 = unknown or not such a grid. ganet_dz_upsample_t takes its tiled kernel for
-                             1..48 and the one-wave-per-pixel kernel otherwise. */
-} GanetUpGrid;
-int ganet_rowgemm(int64_t M, int32_t N, int32_t K, const float* A, int64_t lda, const float* Bt, int64_t ldb, float* C,
-                  int64_t ldc, int32_t accumulate, void* stream);
-int ganet_upsample_z_fwd(const GanetUpGrid* grid, const float* P, int64_t ldp, const float* Wuv, const float* bias,
-                         const float* stat_shift, float* z, float* col_part, void* stream);
-/* z[M,128] = softplus(in_scale . x2 + in_shift)[M,128] . W[128,128]^T + bias + bilinear(P[:, 0:128])[m] + Wuv . uv[m]:
- * ganet_mlp_fwd's hidden-layer case with the skip layer's input half as a gathered additive term (M = frames*S*S,
- * S a multiple of 32); col_part / stat_shift / row_order as ganet_mlp_fwd. */
-int ganet_mlp_fwd_add(const GanetUpGrid* grid, const float* x2, const float* in_scale, const float* in_shift,
-                      const float* W, const float* bias, const float* P, int64_t ldp, const float* Wuv, float* z,
-                      float* col_part, const float* stat_shift, int32_t row_order, void* stream);
-int32_t ganet_dz_upsample_t_parts(const GanetUpGrid* grid);
-int ganet_dz_upsample_t(const GanetUpGrid* grid, const float* G, const float* Z, const float* coef, float* dP, int64_t ldp,
-                        float* partial, void* stream);
-/* The whole decoder fed by the feature MAP instead of the up-sampled rows: what ganet_upsample_cat_fwd +
- * ganet_decoder_fwd compute (and ganet_decoder_bwd + ganet_upsample_cat_bwd), without the [M,72] input tensor and its
- * gradient. feat: [frames,R,R,64] channels-last; M = frames*S*S rows (a multiple of 32, S a multiple of 32);
- * params->cin must be 66. Backward: grads->dx receives dL/dfeat [frames,R,R,64] (x_cols must be 64; NULL = not
- * needed). Workspaces: ganet_decoder_map_{fwd,bwd}_workspace(grid). */
-size_t ganet_decoder_map_fwd_workspace(const GanetUpGrid* grid);
-int ganet_decoder_map_fwd(const GanetUpGrid* grid, const float* feat, const GanetDecoderParams* params, float* saved,
-                          float* const* out, void* workspace, size_t workspace_bytes, void* stream);
-size_t ganet_decoder_map_bwd_workspace(const GanetUpGrid* grid);
-int ganet_decoder_map_bwd(const GanetUpGrid* grid, const float* feat, const GanetDecoderParams* params,
-                          const float* saved, const float* const* d_out, const GanetDecoderGrads* grads, void* workspace,
-                          size_t workspace_bytes, void* stream, void* side_stream);
-
 /* ---- the stage-2 pose encoder as ONE call each way (ganet_unet.hip): UnetNoCond5DS of
  * /root/reference/model/modules.py:185-232 (blocks :62-111) — five 4x4 / stride-2 convolutions down (nf, 2nf, 4nf, 8nf, 8nf
  * channels; BatchNorm2d(affine=False) after conv2..4; LeakyReLU(0.2) in front of conv2..5, in place, so the skip tensors
  * carry it too), five ReLU -> 4x4 / stride-2 transposed convolutions up with skip concatenations (BatchNorm after
- * upconv1..4, bias on upconv5). x: [B, cin, S, S] NCHW (S a multiple of 32, cin <= 8); out: [B, S, S, cout]
+ * upconv1..4, bias on upconv5). x: [B, cin, S, S] NCHW (S a power of two >= 32, cin <= 8); out: [B, S, S, cout]
  * channels-last; nf and cout multiples of 32. Weights in torch's layouts: Wd[k] = conv{k+1}.conv.weight
  * [co][ci][4][4], Wu[k] = upconv{k+1}.up.weight [ci][co][4][4], bias5 = upconv5.up.bias. BatchNorm index: 0..2 =
  * conv2..4, 3..6 = upconv1..4 (running statistics updated like F.batch_norm(training=True); training = 0: the running

@@ -8,10 +8,10 @@ from gaussianavatar_amd import _dev
 
 
 def test_ga_dev_switches_parse_and_reject_unknown_keys():
-    k = _dev._parse("decoder_map=1, encoder_stream=0,unet_wgrad_stream=off,lib_dir=/tmp/x")
-    assert k.decoder_map is True and k.encoder_stream is False and k.unet_wgrad_stream is False and k.lib_dir == "/tmp/x"
+    k = _dev._parse("row_sweep=1, encoder_stream=0,unet_wgrad_stream=off,lib_dir=/tmp/x")
+    assert k.row_sweep is True and k.encoder_stream is False and k.unet_wgrad_stream is False and k.lib_dir == "/tmp/x"
     d = _dev._parse("")
-    assert d.decoder_map is False and d.encoder_stream is True and d.native_unet is True and d.wgrad_stream is True
+    assert d.one_pass_backward is True and d.encoder_stream is True and d.native_unet is True and d.wgrad_stream is True
     with pytest.raises(ValueError):
         _dev._parse("no_such_switch=1")
 
