@@ -44,11 +44,23 @@ tile_scan_kernel(int T, int64_t max_pairs, uint32_t* __restrict__ tile_count,
   const int per = (T + SCAN_THREADS - 1) / SCAN_THREADS;
   const int lo = tid * per;
   const int hi = min(lo + per, T);
+  // a thread's counts stay in registers when it owns at most MAXPER tiles (T <= 8192: every frame up to 2048 x 1024):
+  // the kernel is a chain of memory round trips, and the four passes over the histogram used to pay one each
+  constexpr int MAXPER = 8, NCLS = 34;              // MAXPER x SCAN_THREADS = 8192: gsr_common.h tile_order_is_sorted
+  const bool ordered = per <= MAXPER;
+  uint32_t cnt_[MAXPER];
+#pragma unroll
+  for (int k = 0; k < MAXPER; ++k) cnt_[k] = (ordered && lo + k < hi) ? tile_count[lo + k] : 0u;
   uint32_t sum = 0, mx = 0;
-  for (int t = lo; t < hi; ++t) {
-    const uint32_t c = tile_count[t];
-    sum += c;
-    mx = max(mx, c);
+  if (ordered) {
+#pragma unroll
+    for (int k = 0; k < MAXPER; ++k) { sum += cnt_[k]; mx = max(mx, cnt_[k]); }
+  } else {
+    for (int t = lo; t < hi; ++t) {
+      const uint32_t c = tile_count[t];
+      sum += c;
+      mx = max(mx, c);
+    }
   }
   // inclusive scan of `sum` across the wave, then across the 16 waves
   const int lane = tid & (GSR_WAVE - 1), wave = tid / GSR_WAVE;
@@ -71,8 +83,7 @@ tile_scan_kernel(int T, int64_t max_pairs, uint32_t* __restrict__ tile_count,
     gmax = max(gmax, s_max[w]);
   }
   uint32_t run = base + incl - sum;   // exclusive prefix of this thread's chunk
-  for (int t = lo; t < hi; ++t) {
-    const uint32_t c = tile_count[t];
+  auto emit = [&](int t, uint32_t c) {
     tile_offset[t] = run;
     tile_cursor[t] = run;
     // a list beyond the merge launch's LDS capacity is sorted bucket by bucket (tile_merge_all_kernel: psrs_bucket):
@@ -85,6 +96,13 @@ tile_scan_kernel(int T, int64_t max_pairs, uint32_t* __restrict__ tile_count,
         if (w0 + b < (uint32_t)work_cap) sort_work[w0 + b] = ((uint32_t)t << 8) | b;
     }
     run += c;
+  };
+  if (ordered) {
+#pragma unroll
+    for (int k = 0; k < MAXPER; ++k)
+      if (lo + k < hi) emit(lo + k, cnt_[k]);
+  } else {
+    for (int t = lo; t < hi; ++t) emit(t, tile_count[t]);
   }
   if (tid == 0) {
     tile_offset[T] = total;
@@ -97,10 +115,8 @@ tile_scan_kernel(int T, int64_t max_pairs, uint32_t* __restrict__ tile_count,
   // LDS, so only two of its workgroups fit on a CU and the launch is a list-scheduling problem: with
   // the long lists of the avatar's interior tiles dispatched first, the short ones fill the gaps instead
   // of a few long ones forming the tail. Order within a class is arbitrary (it only affects scheduling).
-  constexpr int MAXPER = 8, NCLS = 34;              // MAXPER x SCAN_THREADS = 8192: gsr_common.h tile_order_is_sorted
   __shared__ uint32_t s_cls[NCLS];
   uint32_t pos[MAXPER];
-  const bool ordered = per <= MAXPER;
   if (tid < NCLS) s_cls[tid] = 0;
   __syncthreads();
   auto cls_of = [](uint32_t c) { return c ? 32 - __clz(c) : 0; };   // 0 for empty, else 1..32
@@ -124,11 +140,13 @@ tile_scan_kernel(int T, int64_t max_pairs, uint32_t* __restrict__ tile_count,
   const uint32_t run0 = base + incl - sum;
   if (ordered) {
     uint32_t r = run0;
-    for (int k = 0; k < per; ++k) {                      // uniform trip count: the ballots need every lane
-      const int t = lo + k;
-      const uint32_t c = t < hi ? tile_count[t] : 0u;
-      place(t < hi ? cls_of(capped(r, c)) : -1, t < hi);
-      r += c;
+#pragma unroll
+    for (int k = 0; k < MAXPER; ++k) {
+      if (k < per) {                                     // uniform trip count: the ballots need every lane
+        const int t = lo + k;
+        place(t < hi ? cls_of(capped(r, cnt_[k])) : -1, t < hi);
+        r += cnt_[k];
+      }
     }
   }
   __syncthreads();
@@ -140,15 +158,23 @@ tile_scan_kernel(int T, int64_t max_pairs, uint32_t* __restrict__ tile_count,
   __syncthreads();
   if (ordered) {
     uint32_t r = run0;
-    for (int k = 0; k < per; ++k) {
-      const int t = lo + k;
-      const uint32_t c = t < hi ? tile_count[t] : 0u;
-      pos[k] = place(t < hi ? cls_of(capped(r, c)) : -1, t < hi);
-      r += c;
+#pragma unroll
+    for (int k = 0; k < MAXPER; ++k) {
+      if (k < per) {
+        const int t = lo + k;
+        pos[k] = place(t < hi ? cls_of(capped(r, cnt_[k])) : -1, t < hi);
+        r += cnt_[k];
+      }
     }
   }
   __syncthreads();                    // every count has been read: the buffer may be overwritten
-  for (int t = lo, k = 0; t < hi; ++t, ++k) tile_count[ordered ? pos[k] : t] = (uint32_t)t;
+  if (ordered) {
+#pragma unroll
+    for (int k = 0; k < MAXPER; ++k)
+      if (lo + k < hi) tile_count[pos[k]] = (uint32_t)(lo + k);
+  } else {
+    for (int t = lo; t < hi; ++t) tile_count[t] = (uint32_t)t;
+  }
 }
 
 // ------------------------------------------------------------------ K3
