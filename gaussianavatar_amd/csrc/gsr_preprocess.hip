@@ -220,7 +220,15 @@ preprocess_kernel(int P, int W, int H, int gx, int gy, float tanfovx, float tanf
 
 // K7 — Appendix A.5. One thread per Gaussian; reads the screen-space gradient accumulators
 // written by K6 (grad_acc: dxy2 (already scaled by 0.5W, 0.5H), dconic3, dopac1, drgb3).
-__global__ void __launch_bounds__(256)
+#ifndef GSR_PBWD_WAVES
+#define GSR_PBWD_WAVES 0
+#endif
+#if GSR_PBWD_WAVES > 0
+#define GSR_PBWD_OCC __attribute__((amdgpu_waves_per_eu(GSR_PBWD_WAVES, GSR_PBWD_WAVES)))
+#else
+#define GSR_PBWD_OCC
+#endif
+__global__ void __launch_bounds__(256) GSR_PBWD_OCC
 preprocess_bwd_kernel(int P, int W, int H, float tanfovx, float tanfovy, float scale_modifier,
                       const float* __restrict__ view, const float* __restrict__ proj,
                       const float* __restrict__ means3D, const float* __restrict__ scales,

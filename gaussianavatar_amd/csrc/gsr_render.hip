@@ -188,8 +188,26 @@ __device__ __forceinline__ float write_lane_at(float v, float s, int lane) {
 
 // ------------------------------------------------------------------------------------ forward
 // RECORD = false: the forward-only render (gsr_forward_eval*): nothing is left for a backward pass.
+// Waves per SIMD the register allocator is asked to make room for (round 6, tools/build_gsr_variant.sh -DGSR_FWD_WAVES=n /
+// -DGSR_BWD_WAVES=n; same box, bench_raster.py): the blend kernels are latency-bound on their gathers and their LDS ring.
+// Forward at 6 (79 registers + 12 bytes of scratch instead of 87 and 5 waves): 111 -> 106 us at the avatar set, 164 -> 156 on the
+// general set, 381 -> 367 at 5 M pairs per frame; 7: the same; 8: slower (72 bytes of scratch). The backward pass is bound by its
+// atomics: 6 / 7 / 8 measured 104 -> 108 / 116 / 117 us — it keeps the allocator's own choice (90 registers, 5 waves).
+#ifndef GSR_FWD_WAVES
+#define GSR_FWD_WAVES 6
+#endif
+#if GSR_FWD_WAVES > 0
+#define GSR_FWD_OCC __attribute__((amdgpu_waves_per_eu(GSR_FWD_WAVES, GSR_FWD_WAVES)))
+#else
+#define GSR_FWD_OCC
+#endif
+#ifdef GSR_BWD_WAVES
+#define GSR_BWD_OCC __attribute__((amdgpu_waves_per_eu(GSR_BWD_WAVES, GSR_BWD_WAVES)))
+#else
+#define GSR_BWD_OCC
+#endif
 template <bool RECORD>
-__global__ void __launch_bounds__(GSR_TILE_PIX)
+__global__ void __launch_bounds__(GSR_TILE_PIX) GSR_FWD_OCC
 render_fwd_kernel(int W, int H, int gx, int T, int64_t max_pairs, int seg_cap, const uint32_t* __restrict__ tile_order,
                   const uint32_t* __restrict__ tile_offset,
                   const uint32_t* __restrict__ point_list, const float4* __restrict__ xyext,
@@ -383,7 +401,7 @@ struct SegRec { uint2 info; uint2 ent; float4 ck; };
 
 struct SegData { float2 c; float4 co; float4 col; float4 pa; int last; float g0, g1, g2; };
 
-__global__ void __launch_bounds__(GSR_TILE_PIX)
+__global__ void __launch_bounds__(GSR_TILE_PIX) GSR_BWD_OCC
 render_bwd_kernel(int W, int H, int list_cap, const float2* __restrict__ xy,
                   const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb,
                   const float* __restrict__ bg, const uint32_t* __restrict__ n_contrib,

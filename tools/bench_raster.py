@@ -209,6 +209,22 @@ def run_set(kind, size_key, seeds, iters, scene, warm=10):
         _n, p = rasterizer.pair_statistics(True)
         pairs_l.append(p)
         rasterizer.profile_enable(False)
+    # the forward-only render of the last seed's scene (torch.no_grad(): eval.py / render_novel_pose.py), 2 frames per launch
+    eval_us = None
+    if gs["shs"] is None:
+        rs2 = settings(m, bt, W, H, 2)
+        def ev():
+            with torch.no_grad():
+                rasterize_gaussians_batch(pts, gs["colors"], gs["opac"], gs["scales"], gs["rots"], rs2)
+        for _ in range(5):
+            ev()
+        rasterizer.check_overflow(True)
+        rasterizer.profile_enable(["render_fwd"]); rasterizer.profile_read(True)
+        for _ in range(20):
+            ev()
+        ms, c = rasterizer.profile_read(True)["render_fwd"]
+        rasterizer.profile_enable(False)
+        eval_us = round(ms / c * 1e3, 1) if c else None
     med = {k: statistics.median(v) for k, v in per_kernel.items() if v}
     D = statistics.mean(pairs_l)                        # pairs per frame (the capacity poll's mean over the launches)
     ab = algorithmic_bytes(N, D, W * H)
@@ -217,7 +233,7 @@ def run_set(kind, size_key, seeds, iters, scene, warm=10):
     out = dict(set=kind, size=size_key, gaussians=N, image=[H, W], frames_per_launch=frames, seeds=list(seeds),
                timed_iterations=iters * len(seeds), pairs_per_frame=D,
                us_per_launch_median={k: round(v, 1) for k, v in med.items()},
-               wall_us_fwd_bwd_median=round(statistics.median(walls), 1),
+               wall_us_fwd_bwd_median=round(statistics.median(walls), 1), forward_only_render_us=eval_us,
                algorithmic_GBps={k: round(v, 1) for k, v in gbs.items()},
                frac_of_8TBps={k: round(v / 8000.0, 4) for k, v in gbs.items()},
                ps_per_pair={k: round(med[k] * 1e6 / (frames * D), 1) for k in med if D > 0},
@@ -312,7 +328,7 @@ def main():
             u = r["us_per_launch_median"]
             print(f"{size_key} {kind:12s} pairs/frame {r['pairs_per_frame']:9.0f}  " +
                   "  ".join(f"{k}={u[k]:.0f}" for k in list(PROFILE_KERNELS) + ["binning"] if k in u) +
-                  f"  wall={r['wall_us_fwd_bwd_median']:.0f}us  records/pair="
+                  f"  wall={r['wall_us_fwd_bwd_median']:.0f}us  eval_render={r['forward_only_render_us']}  records/pair="
                   f"{(r['frame0']['records'] / max(r['frame0']['pairs'], 1)) if r['frame0'] else float('nan'):.2f}", flush=True)
     doc = {"tool": "tools/bench_raster.py", "unit": "us per launch (median over seeds x iterations), 2 frames per launch "
            "unless frames_per_launch says otherwise", "device": torch.cuda.get_device_name(0), "rows": rows}
