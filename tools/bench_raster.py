@@ -34,7 +34,7 @@ from gaussianavatar_amd.rasterizer import (GaussianRasterizationSettings, Gaussi
                                            rasterize_gaussians_batch)
 
 SIZES = {"200k": (200000, 1024, 1024), "300k": (300000, 1920, 1080)}
-ALL_SETS = ("avatar_3mm", "avatar_10mm", "avatar_20mm", "general", "general_sh3")
+ALL_SETS = ("avatar_3mm", "avatar_10mm", "avatar_20mm", "warmup_150", "warmup_300", "general", "general_sh3")
 BINNING = ("tile_scan", "scatter", "tile_sort")
 
 
@@ -289,8 +289,12 @@ def pmc_traffic(kind, size_key):
 
 def child(kind, size_key):
     N, W, H = SIZES[size_key]
-    m, bt, pts = body(N, W, H)
-    it, _ = make_iteration(kind, m, bt, pts, gaussian_set(kind, N, 0), W, H)
+    if kind.startswith("warmup_"):
+        m, bt, pts, gs = warmup_set(int(kind.split("_")[1]), N, W, H, 0)
+    else:
+        m, bt, pts = body(N, W, H)
+        gs = gaussian_set(kind, N, 0)
+    it, _ = make_iteration(kind, m, bt, pts, gs, W, H)
     for _ in range(12):
         it()
     torch.cuda.synchronize()
@@ -315,7 +319,7 @@ def main():
         for kind in a.sets.split(","):
             seeds = range(1) if (kind.endswith("sh3") or kind.startswith("warmup_")) else range(a.seeds)
             r = run_set(kind, size_key, seeds, a.iters, scene)
-            if a.pmc and kind in ("avatar_3mm", "avatar_20mm", "general"):
+            if a.pmc and kind in ("avatar_3mm", "avatar_20mm", "general", "warmup_300"):
                 torch.cuda.synchronize()
                 tr = pmc_traffic(kind, size_key)
                 r["pmc_traffic_per_launch"] = tr

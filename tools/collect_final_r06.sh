@@ -10,3 +10,5 @@ bash tools/collect_final_r04.sh $tag
 O=gpurun_out/$tag; mkdir -p $O
 python tools/bench_raster.py --pmc --out $O/raster_ubench.json > $O/raster_ubench.txt 2>&1; grep "^[23]00k" $O/raster_ubench.txt
 ITERS="7 60 150 300" tools/dsweep.sh > $O/dsweep.txt 2>&1; cat $O/dsweep.txt
+python tools/cpu_enqueue.py > $O/cpu_enqueue.txt 2>&1; SYNC=1 python tools/cpu_enqueue.py > $O/cpu_enqueue_sync.txt 2>&1; tail -3 $O/cpu_enqueue_sync.txt
+tools/ubench_atomic.sh $O 2>/dev/null
