@@ -36,7 +36,9 @@
 #endif                                       // 8 was built and measured in round 4: see gsr_render.hip
 #define GSR_SEG_PIX (GSR_SUB * GSR_SUB)      // pixels of a render block = checkpoints per segment
 #ifndef GSR_BWD_BLOCKS
-#define GSR_BWD_BLOCKS 2048                  // persistent workgroups of render_bwd (256 CUs x 8)
+#define GSR_BWD_BLOCKS 8192                  // workgroups of render_bwd per launch (round 6: 2048 -> 8192 with a limit on the waves
+                                             // that take part, gsr_render.hip GSR_BWD_SEGS: 442 -> 403 us at 2.3 M pairs per frame,
+                                             // 527 -> 481 at 5 M, 104 -> 104 at the avatar set; 4096 without the limit: 100 / 420 / 507)
 #endif
 #define GSR_SEG_BLOCKS ((GSR_TILE / GSR_SUB) * (GSR_TILE / GSR_SUB))   // render blocks of a tile: 16 (or 4)
 #define GSR_PAIR_GRAD 9                      // floats of a per-pair gradient record (dxy2, dconic3, dopac1, drgb3)

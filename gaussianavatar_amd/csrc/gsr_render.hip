@@ -435,8 +435,15 @@ render_bwd_kernel(int W, int H, int list_cap, const float2* __restrict__ xy,
   const int xcd = blockIdx.x & 7;
   const uint32_t* my_list = seg_list + (size_t)xcd * list_cap;
   const int mine = min(seg_heads[64 * xcd], list_cap);
-  const int wpx = nwaves / 8;                                    // waves per XCD
+  // waves per XCD that take part: all of them for a long list; for a short one only as many as leave every wave
+  // GSR_BWD_SEGS segments (a wave's second-level loads overlap with its previous segment's pixel loop: a wave with a single
+  // segment hides nothing) — the rest of the grid exits at once
+#ifndef GSR_BWD_SEGS
+#define GSR_BWD_SEGS 2
+#endif
+  const int wpx = GSR_BWD_SEGS > 0 ? max(WAVES * 16, min(nwaves / 8, (mine + GSR_BWD_SEGS - 1) / GSR_BWD_SEGS)) : nwaves / 8;
   const int my_first = (blockIdx.x >> 3) * WAVES + wave;
+  if (my_first >= wpx) return;
   const float half_w = 0.5f * (float)W, half_h = 0.5f * (float)H;
   const size_t plane = (size_t)H * W;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
