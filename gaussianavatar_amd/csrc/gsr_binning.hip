@@ -393,7 +393,13 @@ __device__ __forceinline__ TileSpan tile_span(const uint32_t* tile_order, const 
 // order (descending size CLASS = floor(log2 n) + 1, tile_scan_kernel; `ordered` = that order exists, T <= 8192)
 // and stop at the first list whose class needs no work: ~590 of 4096 tiles are occupied, and one workgroup per tile and
 // chunk (32k mostly empty 1024-thread workgroups per frame over the four launches) cost more than the sort.
-constexpr int SORT_GRID = 768;
+#ifndef GSR_SORT_GRID
+#define GSR_SORT_GRID 768
+#endif
+#ifndef GSR_MERGE_GRID
+#define GSR_MERGE_GRID 256
+#endif
+constexpr int SORT_GRID = GSR_SORT_GRID;
 constexpr int CHUNK_WG = SORT_CHUNK / 8;  // chunk sort: 8 keys per thread
 
 // chunk blockIdx.z of the tiles of rank blockIdx.x, + SORT_GRID, ...: merge-sorted in LDS (merge_sort_lds); a
@@ -707,7 +713,7 @@ hipError_t launch_binning(const Dims& d, const Workspace& ws, const Batch& bt, h
         if (e != hipSuccess) return e;
         attr_set = true;
       }
-      hipLaunchKernelGGL(tile_merge_all_kernel, dim3(min(d.T, 256), bt.frames), dim3(MERGE_WG), merge_lds, stream, d.T, ordered,
+      hipLaunchKernelGGL(tile_merge_all_kernel, dim3(min(d.T, GSR_MERGE_GRID), bt.frames), dim3(MERGE_WG), merge_lds, stream, d.T, ordered,
                          d.max_pairs, ws.tile_count, ws.tile_offset, ws.pair_key, ws.pair_tmp, ws.point_list, ws.sort_work,
                          ws.status, bt.ws_stride);
     }
