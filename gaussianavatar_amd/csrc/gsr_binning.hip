@@ -4,7 +4,7 @@
 // of the pair count -> duplicateWithKeys -> 64-bit global radix sort -> identifyTileRanges;
 // SURVEY.md §2.1) with a per-tile one that never leaves the device:
 //   histogram (in K1) -> one-block scan over tiles -> atomic append per tile -> per-tile sort
-//   of (depth_bits<<32 | gaussian) keys in LDS.
+//   of (depth_bits<<32 | gaussian) keys in LDS (2048-key chunks, merged in LDS; lists beyond 8192 keys bucket by bucket).
 // The per-tile order is the same total order (depth bits, then Gaussian index; Appendix A.2),
 // so the lists are bit-identical to the reference's however the appends interleave.
 #include "gsr_common.h"

@@ -3,11 +3,14 @@
 // Pipeline (one frame, everything on one stream, no host read-back):
 //
 //   K1 preprocess      per Gaussian : project, EWA covariance, conic, radius, tile rect;
-//                                     per-tile histogram of (tile,Gaussian) pairs
-//   K2 tile_scan       one block    : exclusive scan of the histogram -> tile_offset, D
-//   K3 scatter         per Gaussian : append (depth_bits<<32 | index) to each touched tile
-//   K4 tile_sort       per tile     : sort the tile's keys in LDS (bitonic; merge passes
-//                                     through HBM for lists that do not fit) -> point_list
+//                                     per-tile histogram of (tile,Gaussian) pairs (a workgroup's rectangles counted
+//                                     in an LDS window of the tile grid: difference array + prefix sum)
+//   K2 tile_scan       one block    : exclusive scan of the histogram -> tile_offset, D; the tile order (longest list
+//                                     first) and the work list of the long-list sort
+//   K3 scatter         per Gaussian : append (depth_bits<<32 | index) to each touched tile (the same window count, one
+//                                     returning atomic per (workgroup, tile), a wave's pairs dealt to its lanes)
+//   K4 tile_sort       per tile     : merge sort of 2048-key chunks in LDS, chunk runs merged in LDS; lists beyond 8192
+//                                     keys as independent ~4096-key output buckets (regular sampling) -> point_list
 //   K5 render_fwd      per 4x4 block: cull the tile list, blend 64 survivors at a time (entry-parallel,
 //                                     DPP wave scans); records the consumed segments
 //   K6 render_bwd      per segment  : forward-order gradients of the segment's 64 entries summed over the block's
