@@ -286,8 +286,8 @@ scatter_kernel(int P, int gx, int64_t max_pairs, const int4* __restrict__ rect,
 // ------------------------------------------------------------------ K4
 // Merge-path split: number of elements taken from A among the first `diag` outputs of
 // merge(A[0..na), B[0..nb)); ties go to A (stable, although keys are unique here).
-__device__ __forceinline__ int merge_split(const uint64_t* A, int na, const uint64_t* B, int nb,
-                                           int diag) {
+template <class KA>
+__device__ __forceinline__ int merge_split(const KA& A, int na, const KA& B, int nb, int diag) {
   int lo = max(0, diag - nb), hi = min(diag, na);
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
@@ -295,6 +295,30 @@ __device__ __forceinline__ int merge_split(const uint64_t* A, int na, const uint
   }
   return lo;
 }
+
+// LDS key arrays are addressed through a swizzle (round 6). Every thread of the merge levels owns 8 consecutive output
+// positions: with keys stored in index order a wave's `dst[8 t + o]` (ds_write_b64: 16-lane groups over 32 banks) puts 8 lanes on
+// one bank pair — an 8-way conflict on every one of the 64 key writes of a 2048-key chunk sort, and the same on the window
+// reads (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.77, profiles/r06_pmc_raster_*.txt). Slot of key j: j ^ ((j >> 4) & 7) —
+// a permutation inside every aligned block of 8 keys that gives the 16 lanes of a write group 16 different slots of the
+// 128-byte bank row (reads of a window: 2-way); conflict cycles of the chunk sort 6.4 M -> 1.3 M per launch. Arrays hold a
+// multiple of 8 slots; LKeys is a run inside such an array. Used by the chunk sort (merge_sort_lds) only, see PKeys.
+__device__ __forceinline__ int ksl(int j) { return j ^ ((j >> 4) & 7); }
+struct LKeys {
+  uint64_t* buf; int off;
+  __device__ __forceinline__ uint64_t operator[](int i) const { return buf[ksl(off + i)]; }
+  __device__ __forceinline__ void set(int i, uint64_t v) const { buf[ksl(off + i)] = v; }
+  __device__ __forceinline__ LKeys operator+(int d) const { return LKeys{buf, off + d}; }
+};
+// the same interface over keys in index order: the merge launch's levels (one 1024-thread workgroup per CU: a pure
+// latency chain — the swizzle's three extra address instructions per dependent read made it slower, 162 -> 179 us at 5 M
+// pairs per frame, while the chunk sort, five workgroups per CU on one LDS pipe, gained: 178 -> 147 us)
+struct PKeys {
+  uint64_t* buf; int off;
+  __device__ __forceinline__ uint64_t operator[](int i) const { return buf[off + i]; }
+  __device__ __forceinline__ void set(int i, uint64_t v) const { buf[off + i] = v; }
+  __device__ __forceinline__ PKeys operator+(int d) const { return PKeys{buf, off + d}; }
+};
 
 // Merge sort of n <= 8 NT keys in LDS by NT threads (ping-pong between a and b; returns the buffer that holds the
 // result). Every thread owns 8 consecutive OUTPUT positions per level (merge path): a binary search for its split of the
@@ -310,8 +334,9 @@ __device__ __forceinline__ void cex(uint64_t& x, uint64_t& y) {
   x = lo; y = hi;
 }
 template <int NT>
-__device__ __forceinline__ uint64_t* merge_sort_lds(uint64_t* a, uint64_t* b, int n, int tid) {
+__device__ __forceinline__ LKeys merge_sort_lds(uint64_t* a_, uint64_t* b_, int n, int tid) {
   constexpr int ITEMS = 8;
+  const LKeys a{a_, 0}, b{b_, 0};
   const int g0 = tid * ITEMS;
   if (g0 < n) {       // sorting network on the thread's own 8 keys (19 compare-exchanges; absent keys = +inf)
     uint64_t k[ITEMS];
@@ -325,17 +350,16 @@ __device__ __forceinline__ uint64_t* merge_sort_lds(uint64_t* a, uint64_t* b, in
     cex(k[2], k[4]); cex(k[3], k[5]);
     cex(k[3], k[4]);
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) if (g0 + i < n) a[g0 + i] = k[i];
+    for (int i = 0; i < ITEMS; ++i) if (g0 + i < n) a.set(g0 + i, k[i]);
   }
   __syncthreads();
-  uint64_t* src = a;
-  uint64_t* dst = b;
+  LKeys src = a, dst = b;
   for (int run = ITEMS; run < n; run <<= 1) {
     if (g0 < n) {
       const int lo = (g0 / (2 * run)) * (2 * run);
       const int mid = min(lo + run, n), hi = min(lo + 2 * run, n);
-      const uint64_t* A = src + lo;
-      const uint64_t* B = src + mid;
+      const LKeys A = src + lo;
+      const LKeys B = src + mid;
       const int na = mid - lo, nb = hi - mid;
       int ia = merge_split(A, na, B, nb, g0 - lo);
       int ib = g0 - lo - ia;
@@ -345,13 +369,13 @@ __device__ __forceinline__ uint64_t* merge_sort_lds(uint64_t* a, uint64_t* b, in
       for (int o = 0; o < ITEMS; ++o) {
         if (o < cnt) {
           const bool takeA = va <= vb;                // keys are unique and < ~0: an exhausted run never wins
-          dst[g0 + o] = takeA ? va : vb;
+          dst.set(g0 + o, takeA ? va : vb);
           if (takeA) { ++ia; va = ia < na ? A[ia] : ~0ull; } else { ++ib; vb = ib < nb ? B[ib] : ~0ull; }
         }
       }
     }
     __syncthreads();
-    uint64_t* t = src; src = dst; dst = t;
+    const LKeys t = src; src = dst; dst = t;
   }
   return src;
 }
@@ -420,9 +444,9 @@ tile_sort_chunk_kernel(int T, int ordered, int64_t max_pairs, const uint32_t* __
       const int m = min(SORT_CHUNK, ts.n - c0);
       uint64_t* keys = pair_key + ts.start + c0;
       __syncthreads();                                      // the previous chunk's LDS image is dead
-      for (int i = tid; i < m; i += CHUNK_WG) s_key[0][i] = keys[i];
+      for (int i = tid; i < m; i += CHUNK_WG) s_key[0][ksl(i)] = keys[i];
       __syncthreads();
-      const uint64_t* sorted = merge_sort_lds<CHUNK_WG>(s_key[0], s_key[1], m, tid);
+      const LKeys sorted = merge_sort_lds<CHUNK_WG>(s_key[0], s_key[1], m, tid);
       if (ts.n <= SORT_CHUNK) {
         for (int i = tid; i < m; i += CHUNK_WG) point_list[ts.start + i] = (uint32_t)sorted[i];
       } else {
@@ -443,15 +467,16 @@ static_assert(MERGE_KEYS == 8 * MERGE_WG, "one 8-key window per thread");
 // The merge levels W = SORT_CHUNK, 2 SORT_CHUNK, ... of n <= MERGE_KEYS keys held in LDS as sorted chunks (src / dst ping-pong,
 // MERGE_WG threads, 8 consecutive outputs per thread and level: merge path). The last level goes to out32 (the low words:
 // the Gaussian indices) if given, else to LDS; returns the LDS buffer that holds the result in the second case.
-__device__ __forceinline__ uint64_t* lds_merge_levels(uint64_t* src, uint64_t* dst, int n, int tid, uint32_t* out32) {
+__device__ __forceinline__ PKeys lds_merge_levels(uint64_t* src_, uint64_t* dst_, int n, int tid, uint32_t* out32) {
+  PKeys src{src_, 0}, dst{dst_, 0};
   const int g0 = tid * 8;
   for (int W = SORT_CHUNK; W < n; W <<= 1) {
     const bool last = 2 * W >= n;                             // this level leaves one run = the sorted list
     if (g0 < n) {
       const int lo = (g0 / (2 * W)) * (2 * W);
       const int mid = min(lo + W, n), hi = min(lo + 2 * W, n);
-      const uint64_t* A = src + lo;
-      const uint64_t* B = src + mid;
+      const PKeys A = src + lo;
+      const PKeys B = src + mid;
       const int na = mid - lo, nb = hi - mid;
       int ia = merge_split(A, na, B, nb, g0 - lo);
       int ib = g0 - lo - ia;
@@ -462,12 +487,12 @@ __device__ __forceinline__ uint64_t* lds_merge_levels(uint64_t* src, uint64_t* d
           const bool takeA = (ib >= nb) || (ia < na && A[ia] <= B[ib]);
           const uint64_t v = takeA ? A[ia++] : B[ib++];
           if (last && out32) out32[g0 + o] = (uint32_t)v;
-          else dst[g0 + o] = v;
+          else dst.set(g0 + o, v);
         }
       }
     }
     __syncthreads();
-    uint64_t* t = src; src = dst; dst = t;
+    const PKeys t = src; src = dst; dst = t;
   }
   return src;
 }
@@ -482,7 +507,7 @@ __device__ __forceinline__ void merge_long_list(uint64_t* keys, uint64_t* tmp, u
     __syncthreads();                                          // the previous block's LDS image is dead
     for (int i = tid; i < m; i += MERGE_WG) s_merge[i] = keys[b0 + i];
     __syncthreads();
-    const uint64_t* r = lds_merge_levels(s_merge, s_merge + MERGE_KEYS, m, tid, nullptr);
+    const PKeys r = lds_merge_levels(s_merge, s_merge + MERGE_KEYS, m, tid, nullptr);
     for (int i = tid; i < m; i += MERGE_WG) keys[b0 + i] = r[i];
   }
   __syncthreads();                                            // workgroup-scope visibility of the blocks (one CU, shared L1)
@@ -539,8 +564,9 @@ __host__ __device__ inline int psrs_group(int runs) {
 // pairwise merge, level by level, of the nruns sorted runs [bnd[r], bnd[r + 1]) of src (LDS; runs may be empty) until one
 // is left; MERGE_WG threads, 8 consecutive outputs per thread and level (merge path); the last level writes the low
 // words to out32. nruns >= 2.
-__device__ __forceinline__ void lds_merge_runs(uint64_t* src, uint64_t* dst, const int* bnd, int nruns, int m, int tid,
+__device__ __forceinline__ void lds_merge_runs(uint64_t* src_, uint64_t* dst_, const int* bnd, int nruns, int m, int tid,
                                                uint32_t* out32) {
+  PKeys src{src_, 0}, dst{dst_, 0};
   const int g0 = tid * 8;
   for (int stride = 1; stride < nruns; stride <<= 1) {
     const bool last = 2 * stride >= nruns;
@@ -557,8 +583,8 @@ __device__ __forceinline__ void lds_merge_runs(uint64_t* src, uint64_t* dst, con
       while (o < 8 && g0 + o < m) {
         const int l0 = bnd[2 * u * stride], l1 = bnd[min(nruns, 2 * u * stride + stride)],
                   l2 = bnd[min(nruns, 2 * (u + 1) * stride)];
-        const uint64_t* A = src + l0;
-        const uint64_t* B = src + l1;
+        const PKeys A = src + l0;
+        const PKeys B = src + l1;
         const int na = l1 - l0, nb = l2 - l1, diag = g0 + o - l0;
         int ia = merge_split(A, na, B, nb, diag);
         int ib = diag - ia;
@@ -567,14 +593,14 @@ __device__ __forceinline__ void lds_merge_runs(uint64_t* src, uint64_t* dst, con
           const bool takeA = (ib >= nb) || (ia < na && A[ia] <= B[ib]);
           const uint64_t v = takeA ? A[ia++] : B[ib++];
           if (last) out32[g0 + o + c] = (uint32_t)v;
-          else dst[g0 + o + c] = v;
+          else dst.set(g0 + o + c, v);
         }
         o += cnt;
         ++u;                                                  // the next pair starts where this one ends
       }
     }
     __syncthreads();
-    uint64_t* t = src; src = dst; dst = t;
+    const PKeys t = src; src = dst; dst = t;
   }
 }
 
@@ -586,11 +612,11 @@ __device__ __forceinline__ void psrs_bucket(const uint64_t* keys, uint32_t* out,
   const int runs = (n + SORT_CHUNK - 1) / SORT_CHUNK;
   const int g = psrs_group(runs), S = n / g, p = (n + GSR_SORT_BUCKET - 1) / GSR_SORT_BUCKET;
   __syncthreads();                                            // the previous item's LDS image is dead
-  for (int i = tid; i < S; i += MERGE_WG) s_a[i] = keys[(int64_t)(i + 1) * g - 1];
+  for (int i = tid; i < S; i += MERGE_WG) s_a[ksl(i)] = keys[(int64_t)(i + 1) * g - 1];
   __syncthreads();
-  const uint64_t* ss = merge_sort_lds<MERGE_WG>(s_a, s_b, S, tid);
-  const uint64_t klo = b > 0 ? ss[(int64_t)b * S / p] : 0ull;
-  const uint64_t khi = b + 1 < p ? ss[(int64_t)(b + 1) * S / p] : ~0ull;
+  const LKeys ss = merge_sort_lds<MERGE_WG>(s_a, s_b, S, tid);
+  const uint64_t klo = b > 0 ? ss[(int)((int64_t)b * S / p)] : 0ull;
+  const uint64_t khi = b + 1 < p ? ss[(int)((int64_t)(b + 1) * S / p)] : ~0ull;
   __syncthreads();                                            // every thread holds the splitters: the buffers are free
   // keys of run j below each splitter: round 1 probes the last key of every group of 32 (the groups entirely below the
   // splitter), round 2 the 32 keys of the group the splitter falls in — lanes 0..31 for klo, 32..63 for khi
