@@ -154,6 +154,11 @@ tile_scan_kernel(int T, int64_t max_pairs, uint32_t* __restrict__ tile_count,
     status[5] = (int32_t)min(s_nwork, (uint32_t)work_cap);
     uint32_t run2 = 0;
     for (int c = NCLS - 1; c >= 0; --c) { const uint32_t v = s_cls[c]; s_cls[c] = run2; run2 += v; }
+    // ranks [0, status[6]) of the size order: the lists of SORT_CHUNK keys or more (only they can have a second chunk);
+    // [0, status[7]): those of 2 SORT_CHUNK or more (a third, a fourth chunk) — the start of the class below in the order
+    constexpr int CHUNK_CLS = 32 - __builtin_clz((unsigned)SORT_CHUNK);          // class of a list of exactly SORT_CHUNK keys
+    status[6] = ordered ? (int32_t)s_cls[CHUNK_CLS - 1] : T;
+    status[7] = ordered ? (int32_t)s_cls[CHUNK_CLS] : T;
   }
   __syncthreads();
   if (ordered) {
@@ -333,6 +338,14 @@ __device__ __forceinline__ void cex(uint64_t& x, uint64_t& y) {
   const uint64_t lo = x < y ? x : y, hi = x < y ? y : x;
   x = lo; y = hi;
 }
+#ifdef GSR_SORT_TRACE
+#define SORT_TRACE_CHUNKS (8192 / GSR_SORT_CHUNK)
+// development: s_memrealtime stamps (100 MHz) of the chunk sort's phases, workgroup (0, 0, 0), thread 0
+__device__ unsigned long long g_sort_trace[32];
+#define SORT_STAMP(I) do { if (tid == 0 && blockIdx.x == GSR_SORT_TRACE && blockIdx.y == 0 && blockIdx.z == gridDim.z - 1) g_sort_trace[I] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SORT_STAMP(I) do {} while (0)
+#endif
 template <int NT>
 __device__ __forceinline__ LKeys merge_sort_lds(uint64_t* a_, uint64_t* b_, int n, int tid) {
   constexpr int ITEMS = 8;
@@ -353,8 +366,10 @@ __device__ __forceinline__ LKeys merge_sort_lds(uint64_t* a_, uint64_t* b_, int 
     for (int i = 0; i < ITEMS; ++i) if (g0 + i < n) a.set(g0 + i, k[i]);
   }
   __syncthreads();
+  SORT_STAMP(3);
   LKeys src = a, dst = b;
-  for (int run = ITEMS; run < n; run <<= 1) {
+  int lvl_ = 0;
+  for (int run = ITEMS; run < n; run <<= 1, ++lvl_) {
     if (g0 < n) {
       const int lo = (g0 / (2 * run)) * (2 * run);
       const int mid = min(lo + run, n), hi = min(lo + 2 * run, n);
@@ -375,6 +390,7 @@ __device__ __forceinline__ LKeys merge_sort_lds(uint64_t* a_, uint64_t* b_, int 
       }
     }
     __syncthreads();
+    SORT_STAMP(4 + lvl_);
     const LKeys t = src; src = dst; dst = t;
   }
   return src;
@@ -426,32 +442,49 @@ __device__ __forceinline__ TileSpan tile_span(const uint32_t* tile_order, const 
 constexpr int SORT_GRID = GSR_SORT_GRID;
 constexpr int CHUNK_WG = SORT_CHUNK / 8;  // chunk sort: 8 keys per thread
 
-// chunk blockIdx.z of the tiles of rank blockIdx.x, + SORT_GRID, ...: merge-sorted in LDS (merge_sort_lds); a
+// chunk (gridDim.z - 1 - blockIdx.z) of the tiles of rank blockIdx.x, + SORT_GRID, ...: merge-sorted in LDS (merge_sort_lds); a
 // single-chunk list goes straight to point_list, otherwise the sorted run replaces the chunk in pair_key
 __global__ void __launch_bounds__(CHUNK_WG)
 tile_sort_chunk_kernel(int T, int ordered, int64_t max_pairs, const uint32_t* __restrict__ tile_order,
                        const uint32_t* __restrict__ tile_offset, uint64_t* __restrict__ pair_key,
-                       uint64_t* __restrict__ pair_tmp, uint32_t* __restrict__ point_list, size_t ws_stride) {
+                       uint64_t* __restrict__ pair_tmp, uint32_t* __restrict__ point_list,
+                       const int32_t* __restrict__ status, size_t ws_stride) {
   __shared__ uint64_t s_key[2][SORT_CHUNK];
   GSR_FRAME_PTRS();
+  status = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(status) + (size_t)blockIdx.y * ws_stride);
   const int tid = threadIdx.x;
-  for (int rank = blockIdx.x; rank < T; rank += gridDim.x) {
+  SORT_STAMP(0);
+  // blockIdx.z = chunk, dispatched LAST CHUNK FIRST (a launch's workgroups start in x, y, z order: with the first chunks in
+  // front, the later chunks of the long lists — 17 us each, tools/sort_trace.py — started only when the first round's
+  // workgroups left their LDS and the launch took two rounds for one round of work). Only the first status[6] / status[7]
+  // ranks of the size order have a second / third chunk (tile_scan_kernel): every other workgroup of those slices leaves
+  // after one load.
+  const int chunk0 = (int)(gridDim.z - 1 - blockIdx.z);
+  const int rank_end = chunk0 == 0 ? T : min(T, (int)status[chunk0 == 1 ? 6 : 7]);
+  for (int rank = blockIdx.x; rank < rank_end; rank += gridDim.x) {
     const TileSpan ts = tile_span(tile_order, tile_offset, max_pairs, rank);
     if (ts.n <= 0) { if (ordered) break; continue; }        // every later list is empty too
-    // chunks blockIdx.z, + SORT_MAX_CHUNKS, ...: one pass for the lists the merge launch stages whole (<= MERGE_KEYS keys),
+    SORT_STAMP(1);
+    // chunks chunk0, + SORT_MAX_CHUNKS, ...: one pass for the lists the merge launch stages whole (<= MERGE_KEYS keys),
     // every chunk of a longer list too (it used to be sorted from scratch by its merge workgroup)
-    for (int c0 = blockIdx.z * SORT_CHUNK; c0 < ts.n; c0 += SORT_MAX_CHUNKS * SORT_CHUNK) {
+    for (int c0 = chunk0 * SORT_CHUNK; c0 < ts.n; c0 += SORT_MAX_CHUNKS * SORT_CHUNK) {
       const int m = min(SORT_CHUNK, ts.n - c0);
       uint64_t* keys = pair_key + ts.start + c0;
       __syncthreads();                                      // the previous chunk's LDS image is dead
       for (int i = tid; i < m; i += CHUNK_WG) s_key[0][ksl(i)] = keys[i];
       __syncthreads();
+      SORT_STAMP(2);
       const LKeys sorted = merge_sort_lds<CHUNK_WG>(s_key[0], s_key[1], m, tid);
+      if (tid == 0) { SORT_STAMP(20); }
+#ifdef GSR_SORT_TRACE
+      if (tid == 0 && blockIdx.x == GSR_SORT_TRACE && blockIdx.y == 0 && blockIdx.z == gridDim.z - 1) g_sort_trace[30] = (unsigned long long)m;
+#endif
       if (ts.n <= SORT_CHUNK) {
         for (int i = tid; i < m; i += CHUNK_WG) point_list[ts.start + i] = (uint32_t)sorted[i];
       } else {
         for (int i = tid; i < m; i += CHUNK_WG) keys[i] = sorted[i];
       }
+      SORT_STAMP(21);
     }
   }
 }
@@ -703,6 +736,10 @@ tile_merge_all_kernel(int T, int ordered, int64_t max_pairs, const uint32_t* __r
 
 }  // namespace
 
+#ifdef GSR_SORT_TRACE
+extern "C" int gsr_dev_sort_trace(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sort_trace), sizeof(g_sort_trace)); }
+#endif
+
 hipError_t launch_binning(const Dims& d, const Workspace& ws, const Batch& bt, hipStream_t stream) {
   {
     ProfScope prof_(K_SCAN, stream);
@@ -729,7 +766,7 @@ hipError_t launch_binning(const Dims& d, const Workspace& ws, const Batch& bt, h
       const int ordered = tile_order_is_sorted(d.T);                          // tile_scan_kernel: MAXPER
       hipLaunchKernelGGL(tile_sort_chunk_kernel, dim3(gx, bt.frames, SORT_MAX_CHUNKS), dim3(CHUNK_WG), 0, stream, d.T,
                          ordered, d.max_pairs, ws.tile_count, ws.tile_offset, ws.pair_key, ws.pair_tmp, ws.point_list,
-                         bt.ws_stride);
+                         ws.status, bt.ws_stride);
       trace_sync(stream, "tile_sort_chunk");
       static PerDeviceFlag attr_set;
       constexpr size_t merge_lds = (size_t)2 * MERGE_KEYS * sizeof(uint64_t);
